@@ -1,0 +1,139 @@
+/*
+ * qpn_hip.h -- C-ABI of the MI355X-native QPNet node-AVI engine (libqpn_hip.so).
+ *
+ * Drop-in boundary for the hot path of forrestlaine/QuadraticProgramNetworks.jl v0.4.0
+ * (paths below are relative to the reference tree).  Every entry point is `extern "C"`,
+ * takes plain pointers and sizes, returns an int error code (0 = ok, <0 = API misuse or HIP
+ * error; per-item solver outcomes are ONLY reported in status[]), never throws, never
+ * keeps a caller pointer past return, and keeps no global state (one qpn_ctx per
+ * thread/stream is safe).  All matrices are dense COLUMN-MAJOR fp64 (Julia's layout);
+ * +-Inf bounds are literal IEEE infinities (src/avi.jl:125-126).
+ *
+ * `mem` says where the caller's buffers live: QPN_MEM_HOST (the library stages them
+ * through HBM itself -- what the Julia `ccall` shim uses) or QPN_MEM_DEVICE (pointers are
+ * already in HBM on the ctx's device; the call is asynchronous on the ctx stream).
+ */
+#ifndef QPN_HIP_H
+#define QPN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPN_ABI_VERSION 1
+
+/* per-item status: the reference enum StatusCode, src/avi.jl:1-6 */
+enum { QPN_SUCCESS = 1, QPN_RAY_TERM = 2, QPN_MAX_ITERS = 3, QPN_FAILURE = 4 };
+
+/* API error codes (function return values) */
+enum {
+    QPN_OK = 0,
+    QPN_ERR_ARG = -1,      /* bad argument (null pointer, size out of range)  */
+    QPN_ERR_HIP = -2,      /* a HIP runtime call failed; see qpn_ctx_last_error */
+    QPN_ERR_NODEVICE = -3, /* no gfx950 device visible                        */
+    QPN_ERR_SIZE = -4      /* problem size not supported by any kernel        */
+};
+
+enum { QPN_MEM_HOST = 0, QPN_MEM_DEVICE = 1 };
+
+/* row kinds of the mixed complementarity problem solved per item
+ *   QPN_ROW_STD : (Mz+q)_i  _|_  l_i <= z_i <= u_i       AVI row,  src/avi.jl:56-61
+ *   QPN_ROW_GAVI:  z_i      _|_  l_i <= (Mz+q)_i <= u_i  second GAVI condition, src/avi.jl:22-24
+ * A batch with kind == NULL is a plain box-MCP: exactly PATHSolver.solve_mcp's problem. */
+enum { QPN_ROW_STD = 0, QPN_ROW_GAVI = 1 };
+
+typedef struct qpn_ctx qpn_ctx;
+
+typedef struct {
+    double check_tol;  /* post-check tolerance, 1e-6       (src/avi.jl:148)                 */
+    double piv_tol;    /* smallest admissible pivot, 1e-11                                   */
+    double feas_tol;   /* basic infeasibility treated as zero, 1e-12                         */
+    double comp_tol;   /* active-set classification tolerance, 1e-2 (src/avi_solutions.jl:511) */
+    int32_t max_pivots; /* <= 0: 50*N + 100 (cf. PATH limits at src/avi.jl:67-70)             */
+    int32_t reserved;
+} qpn_avi_opts;
+
+/* ---- context ------------------------------------------------------------------- */
+int qpn_abi_version(void);
+int qpn_ctx_create(int device_id, qpn_ctx **out);
+int qpn_ctx_destroy(qpn_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+int qpn_ctx_set_stream(qpn_ctx *ctx, void *hip_stream);
+int qpn_ctx_synchronize(qpn_ctx *ctx);
+const char *qpn_ctx_last_error(qpn_ctx *ctx);
+const char *qpn_strerror(int code);
+void qpn_avi_default_opts(qpn_avi_opts *opts);
+
+/* ---- (A2+A3+A9) batched AVI solve ------------------------------------------------
+ * Replaces PATHSolver.solve_mcp as called at src/avi.jl:64-70 and src/qp_processing.jl:22-27,
+ * including the post-check of src/avi.jl:71-76 (check_avi_solution, :148-156) and the
+ * active-set classification of src/avi_solutions.jl:511-562 / :587-612.
+ *   M       [batch][N*N] column-major, item stride strideM doubles (0: one M shared by all items)
+ *   q,l,u   [batch][N]
+ *   kind    [batch][N] uint8 row kinds, item stride stride_kind (0: shared), or NULL (all STD)
+ *   z       [batch][N] in: z0 (warm start of the bounded STD variables; duals start cold as
+ *                       src/avi.jl:404)   out: solution
+ *   status  [batch] int32 (QPN_SUCCESS..QPN_FAILURE), resid [batch] natural-map residual,
+ *   pivots  [batch] int32, active [batch][N] uint8: bit (c-1) set for code c of
+ *           src/avi_solutions.jl:511-562 on STD rows, bit (c+3) on GAVI rows (codes 5..8).
+ *   Any of resid/pivots/active may be NULL.  N <= 64 in ABI version 1. */
+int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, int64_t strideM,
+                        const double *q, const double *l, const double *u, const uint8_t *kind,
+                        int64_t stride_kind, double *z, int32_t *status, double *resid,
+                        int32_t *pivots, uint8_t *active, const qpn_avi_opts *opts, int mem);
+
+/* One problem in Julia's own SparseMatrixCSC{Float64,Int32} layout (1-based colptr/rowval):
+ * the exact argument list of PATHSolver.solve_mcp(M, q, l, u, z0) at src/avi.jl:64.
+ * Host pointers only.  z: in z0, out solution. */
+int qpn_solve_mcp_csc(qpn_ctx *ctx, int32_t N, const int32_t *colptr, const int32_t *rowval,
+                      const double *nzval, const double *q, const double *l, const double *u,
+                      double *z, int32_t *status, double *resid, int32_t *pivots,
+                      const qpn_avi_opts *opts);
+
+/* ---- (A3) batched check_avi_solution, src/avi.jl:148-156 --------------------------
+ *   degree [batch] int32 violation count (sol_bad = degree > 0), r [batch][N] = Mz+q (may be NULL) */
+int qpn_check_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, int64_t strideM,
+                        const double *q, const double *l, const double *u, const uint8_t *kind,
+                        int64_t stride_kind, const double *z, double tol, int32_t *degree,
+                        double *r, int mem);
+
+/* ---- (A9) comp_indices core, src/avi_solutions.jl:511-562 --------------------------
+ * Flat arrays of `count` rows; mask bit (c-1+shift) for code c in 1..4 (shift = 4 for the
+ * s2 block of the GAVI wrapper, :587-612). */
+int qpn_comp_indices(qpn_ctx *ctx, int64_t count, const double *zv, const double *rv,
+                     const double *l, const double *u, double tol, int32_t shift, uint8_t *mask,
+                     int mem);
+
+/* ---- (A5+A6) per-node KKT assembly, single-node pools, reduced form -----------------
+ * src/avi.jl:205-251 + :305-377 restated densely without the dead xi block and the slack
+ * block: per node i with n decision variables, m constraint rows,
+ * p parameters,
+ *     M_i = [[Qd_i, -Ad_i'],[Ad_i, 0]]   (N = n+m),   q_i = [qd_i + R_i w ; B_i w],
+ *     l/u = [-Inf/+Inf x n ; l_i ; u_i],  kind = [STD x n ; GAVI x m].
+ *   Qd [batch][n*n], R [batch][n*p], qd [batch][n], Ad [batch][m*n], B [batch][m*p],
+ *   l,u [batch][m], w [batch][p] with item stride stride_w (0: one shared parameter vector). */
+int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p,
+                       const double *Qd, const double *R, const double *qd, const double *Ad,
+                       const double *B, const double *l, const double *u, const double *w,
+                       int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
+                       uint8_t *kind_out, int mem);
+
+/* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
+ *   xd [batch][n] current decision values, w as above.
+ *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower
+ *   bound, - at the upper, :120-123), path [batch] int32: 0 infeasible (:86-89), 1 m==0
+ *   shortcut (:91-96), 2 least-squares duals accepted (:114-124), 3 bounded-LSQ fallback
+ *   accepted (:129-139), 4 fallback rejected (:141), 5 fallback solver failed (:144).
+ *   tol = 1e-4 (:57).  n, m <= 64. */
+int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p,
+                     const double *Qd, const double *R, const double *qd, const double *Ad,
+                     const double *B, const double *l, const double *u, const double *xd,
+                     const double *w, int64_t stride_w, double tol, int32_t *solution,
+                     double *lambda, int32_t *path, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPN_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libqpn_hip.so (include/qpn_hip.h).  No CPU fallback exists: if the HIP
+library is missing or does not export the ABI, importing/using the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqpn_hip.so")
+
+# every symbol include/qpn_hip.h declares
+ABI_SYMBOLS = (
+    "qpn_abi_version", "qpn_ctx_create", "qpn_ctx_destroy", "qpn_ctx_set_stream",
+    "qpn_ctx_synchronize", "qpn_ctx_last_error", "qpn_strerror", "qpn_avi_default_opts",
+    "qpn_solve_avi_batch", "qpn_solve_mcp_csc", "qpn_check_avi_batch", "qpn_comp_indices",
+    "qpn_assemble_nodes", "qpn_verify_nodes",
+)
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class AviOpts(C.Structure):
+    _fields_ = [("check_tol", C.c_double), ("piv_tol", C.c_double), ("feas_tol", C.c_double),
+                ("comp_tol", C.c_double), ("max_pivots", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libqpn_hip.so and declare the prototypes.  Raises LibraryMissing -- never falls
+    back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for s in ABI_SYMBOLS:
+        if not hasattr(lib, s):
+            raise LibraryMissing(f"{LIB_PATH} does not export {s}")
+    dp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    lib.qpn_abi_version.restype = C.c_int
+    lib.qpn_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.qpn_ctx_destroy.argtypes = [vp]
+    lib.qpn_ctx_set_stream.argtypes = [vp, vp]
+    lib.qpn_ctx_synchronize.argtypes = [vp]
+    lib.qpn_ctx_last_error.argtypes = [vp]
+    lib.qpn_ctx_last_error.restype = C.c_char_p
+    lib.qpn_strerror.argtypes = [C.c_int]
+    lib.qpn_strerror.restype = C.c_char_p
+    lib.qpn_avi_default_opts.argtypes = [C.POINTER(AviOpts)]
+    lib.qpn_avi_default_opts.restype = None
+    # pointers are passed as raw addresses (c_void_p) so host numpy and device torch buffers
+    # go through the same call
+    lib.qpn_solve_avi_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp, vp,
+                                        C.c_int64, vp, vp, vp, vp, vp, C.POINTER(AviOpts), C.c_int]
+    lib.qpn_solve_mcp_csc.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                      C.POINTER(AviOpts)]
+    lib.qpn_check_avi_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp, vp,
+                                        C.c_int64, vp, C.c_double, vp, vp, C.c_int]
+    lib.qpn_comp_indices.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_double, C.c_int32, vp, C.c_int]
+    lib.qpn_assemble_nodes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int]
+    lib.qpn_verify_nodes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp,
+                                     vp, vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
+    for s in ABI_SYMBOLS:
+        f = getattr(lib, s)
+        if f.restype is C.c_int and s not in ("qpn_abi_version",):
+            pass
+    del dp, ip, bp
+    _lib = lib
+    return lib

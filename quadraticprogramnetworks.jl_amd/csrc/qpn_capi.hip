@@ -1,0 +1,429 @@
+// qpn_capi.hip -- the extern "C" boundary of libqpn_hip.so (include/qpn_hip.h).
+// Host-side staging, argument checking and error mapping only; all arithmetic is in the
+// HIP kernels (qpn_avi_solve.hip, qpn_kkt.hip, qpn_verify.hip).  No exceptions cross the ABI.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qpn_internal.h"
+
+struct qpn_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // grow-only device workspace used by the host-pointer paths and multi-kernel entry points
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+int fail_hip(qpn_ctx *ctx, hipError_t e, const char *where)
+{
+    if (ctx) {
+        ctx->last_error = std::string(where) + ": " + hipGetErrorString(e);
+    }
+    return QPN_ERR_HIP;
+}
+int fail_arg(qpn_ctx *ctx, const char *msg)
+{
+    if (ctx) ctx->last_error = msg;
+    return QPN_ERR_ARG;
+}
+
+#define HIPCHK(ctx, call)                                        \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return fail_hip(ctx, e__, #call); \
+    } while (0)
+
+// carve `bytes` (256-B aligned) out of the ctx workspace; grows it when needed
+struct Carver {
+    qpn_ctx *ctx;
+    size_t need = 0;
+    std::vector<std::pair<void **, size_t>> slots;
+    explicit Carver(qpn_ctx *c) : ctx(c) {}
+    void add(void **p, size_t bytes)
+    {
+        size_t off = need;
+        need += (bytes + 255) & ~(size_t)255;
+        slots.emplace_back(p, off);
+    }
+    int commit()
+    {
+        if (need > ctx->ws_bytes) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->ws) HIPCHK(ctx, hipFree(ctx->ws));
+            ctx->ws = nullptr; ctx->ws_bytes = 0;
+            size_t want = need + need / 4;
+            HIPCHK(ctx, hipMalloc(&ctx->ws, want));
+            ctx->ws_bytes = want;
+        }
+        for (auto &s : slots) *s.first = static_cast<char *>(ctx->ws) + s.second;
+        return QPN_OK;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int qpn_abi_version(void) { return QPN_ABI_VERSION; }
+
+const char *qpn_strerror(int code)
+{
+    switch (code) {
+    case QPN_OK: return "ok";
+    case QPN_ERR_ARG: return "bad argument";
+    case QPN_ERR_HIP: return "HIP runtime error";
+    case QPN_ERR_NODEVICE: return "no gfx950 device visible";
+    case QPN_ERR_SIZE: return "problem size not supported";
+    default: return "unknown error";
+    }
+}
+
+void qpn_avi_default_opts(qpn_avi_opts *o)
+{
+    if (!o) return;
+    o->check_tol = 1e-6;   // src/avi.jl:148
+    o->piv_tol = 1e-11;
+    o->feas_tol = 1e-12;
+    o->comp_tol = 1e-2;    // src/avi_solutions.jl:511
+    o->max_pivots = 0;
+    o->reserved = 0;
+}
+
+int qpn_ctx_create(int device_id, qpn_ctx **out)
+{
+    if (!out) return QPN_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return QPN_ERR_NODEVICE;
+    if (device_id < 0 || device_id >= count) return QPN_ERR_ARG;
+    qpn_ctx *ctx = new (std::nothrow) qpn_ctx();
+    if (!ctx) return QPN_ERR_ARG;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return QPN_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx; return QPN_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return QPN_OK;
+}
+
+int qpn_ctx_destroy(qpn_ctx *ctx)
+{
+    if (!ctx) return QPN_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return QPN_OK;
+}
+
+int qpn_ctx_set_stream(qpn_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return QPN_OK;
+}
+
+int qpn_ctx_synchronize(qpn_ctx *ctx)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return QPN_OK;
+}
+
+const char *qpn_ctx_last_error(qpn_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+// -------------------------------------------------------------------------------------------
+int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, int64_t strideM,
+                        const double *q, const double *l, const double *u, const uint8_t *kind,
+                        int64_t stride_kind, double *z, int32_t *status, double *resid,
+                        int32_t *pivots, uint8_t *active, const qpn_avi_opts *opts, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (batch < 0 || N <= 0) return fail_arg(ctx, "qpn_solve_avi_batch: batch < 0 or N <= 0");
+    if (batch == 0) return QPN_OK;
+    if (!M || !q || !l || !u || !z || !status) return fail_arg(ctx, "qpn_solve_avi_batch: null pointer");
+    if (strideM != 0 && strideM < (int64_t)N * N) return fail_arg(ctx, "qpn_solve_avi_batch: strideM < N*N");
+    if (kind && stride_kind != 0 && stride_kind < N) return fail_arg(ctx, "qpn_solve_avi_batch: stride_kind < N");
+    if (N > qpn_avi_max_n()) { ctx->last_error = "qpn_solve_avi_batch: N > 64 not supported by ABI v1"; return QPN_ERR_SIZE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    qpn_avi_opts o;
+    if (opts) o = *opts; else qpn_avi_default_opts(&o);
+
+    AviBatchArgs a{};
+    a.batch = batch; a.N = N; a.strideM = strideM; a.stride_kind = kind ? stride_kind : 0;
+    a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
+    a.max_pivots = o.max_pivots;
+
+    if (mem == QPN_MEM_DEVICE) {
+        a.M = M; a.q = q; a.l = l; a.u = u; a.kind = kind; a.z = z; a.status = status;
+        a.resid = resid; a.pivots = pivots; a.active = active;
+        HIPCHK(ctx, qpn_launch_avi_solve(a, ctx->stream));
+        return QPN_OK;
+    }
+    if (mem != QPN_MEM_HOST) return fail_arg(ctx, "qpn_solve_avi_batch: bad mem kind");
+
+    const size_t bN = (size_t)batch * N;
+    const size_t mBytes = sizeof(double) * (strideM ? (size_t)(batch - 1) * strideM + (size_t)N * N : (size_t)N * N);
+    const size_t kBytes = kind ? (stride_kind ? (size_t)(batch - 1) * stride_kind + N : (size_t)N) : 0;
+    double *dM, *dq, *dl, *du, *dz, *dres; int32_t *dst, *dpv; uint8_t *dk = nullptr, *dact;
+    Carver cv(ctx);
+    cv.add((void **)&dM, mBytes); cv.add((void **)&dq, bN * 8); cv.add((void **)&dl, bN * 8);
+    cv.add((void **)&du, bN * 8); cv.add((void **)&dz, bN * 8); cv.add((void **)&dres, (size_t)batch * 8);
+    cv.add((void **)&dst, (size_t)batch * 4); cv.add((void **)&dpv, (size_t)batch * 4);
+    cv.add((void **)&dact, bN); cv.add((void **)&dk, kBytes ? kBytes : 1);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dM, M, mBytes, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dq, q, bN * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dl, l, bN * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(du, u, bN * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dz, z, bN * 8, hipMemcpyHostToDevice, s));
+    if (kind) HIPCHK(ctx, hipMemcpyAsync(dk, kind, kBytes, hipMemcpyHostToDevice, s));
+    a.M = dM; a.q = dq; a.l = dl; a.u = du; a.kind = kind ? dk : nullptr; a.z = dz; a.status = dst;
+    a.resid = dres; a.pivots = dpv; a.active = dact;
+    HIPCHK(ctx, qpn_launch_avi_solve(a, s));
+    HIPCHK(ctx, hipMemcpyAsync(z, dz, bN * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(status, dst, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    if (resid) HIPCHK(ctx, hipMemcpyAsync(resid, dres, (size_t)batch * 8, hipMemcpyDeviceToHost, s));
+    if (pivots) HIPCHK(ctx, hipMemcpyAsync(pivots, dpv, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    if (active) HIPCHK(ctx, hipMemcpyAsync(active, dact, bN, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+int qpn_solve_mcp_csc(qpn_ctx *ctx, int32_t N, const int32_t *colptr, const int32_t *rowval,
+                      const double *nzval, const double *q, const double *l, const double *u,
+                      double *z, int32_t *status, double *resid, int32_t *pivots,
+                      const qpn_avi_opts *opts)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (N <= 0 || !colptr || !q || !l || !u || !z || !status) return fail_arg(ctx, "qpn_solve_mcp_csc: bad argument");
+    const int32_t nnz = colptr[N] - 1;
+    if (nnz < 0 || (nnz > 0 && (!rowval || !nzval))) return fail_arg(ctx, "qpn_solve_mcp_csc: bad CSC arrays");
+    std::vector<double> dense((size_t)N * N, 0.0);
+    for (int32_t j = 0; j < N; ++j) {
+        for (int32_t t = colptr[j] - 1; t < colptr[j + 1] - 1; ++t) {
+            int32_t i = rowval[t] - 1;
+            if (i < 0 || i >= N) return fail_arg(ctx, "qpn_solve_mcp_csc: row index out of range");
+            dense[(size_t)j * N + i] += nzval[t];
+        }
+    }
+    return qpn_solve_avi_batch(ctx, 1, N, dense.data(), 0, q, l, u, nullptr, 0, z, status, resid,
+                               pivots, nullptr, opts, QPN_MEM_HOST);
+}
+
+// -------------------------------------------------------------------------------------------
+int qpn_check_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, int64_t strideM,
+                        const double *q, const double *l, const double *u, const uint8_t *kind,
+                        int64_t stride_kind, const double *z, double tol, int32_t *degree,
+                        double *r, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (batch < 0 || N <= 0) return fail_arg(ctx, "qpn_check_avi_batch: bad sizes");
+    if (batch == 0) return QPN_OK;
+    if (!M || !q || !l || !u || !z || !degree) return fail_arg(ctx, "qpn_check_avi_batch: null pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_check_avi(batch, N, M, strideM, q, l, u, kind, kind ? stride_kind : 0, z,
+                                         tol, degree, r, ctx->stream));
+        return QPN_OK;
+    }
+    const size_t bN = (size_t)batch * N;
+    const size_t mBytes = sizeof(double) * (strideM ? (size_t)(batch - 1) * strideM + (size_t)N * N : (size_t)N * N);
+    const size_t kBytes = kind ? (stride_kind ? (size_t)(batch - 1) * stride_kind + N : (size_t)N) : 0;
+    double *dM, *dq, *dl, *du, *dz, *dr; int32_t *dd; uint8_t *dk;
+    Carver cv(ctx);
+    cv.add((void **)&dM, mBytes); cv.add((void **)&dq, bN * 8); cv.add((void **)&dl, bN * 8);
+    cv.add((void **)&du, bN * 8); cv.add((void **)&dz, bN * 8); cv.add((void **)&dr, bN * 8);
+    cv.add((void **)&dd, (size_t)batch * 4); cv.add((void **)&dk, kBytes ? kBytes : 1);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dM, M, mBytes, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dq, q, bN * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dl, l, bN * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(du, u, bN * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dz, z, bN * 8, hipMemcpyHostToDevice, s));
+    if (kind) HIPCHK(ctx, hipMemcpyAsync(dk, kind, kBytes, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_check_avi(batch, N, dM, strideM, dq, dl, du, kind ? dk : nullptr,
+                                     kind ? stride_kind : 0, dz, tol, dd, dr, s));
+    HIPCHK(ctx, hipMemcpyAsync(degree, dd, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    if (r) HIPCHK(ctx, hipMemcpyAsync(r, dr, bN * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+int qpn_comp_indices(qpn_ctx *ctx, int64_t count, const double *zv, const double *rv,
+                     const double *l, const double *u, double tol, int32_t shift, uint8_t *mask,
+                     int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (count < 0 || (shift != 0 && shift != 4)) return fail_arg(ctx, "qpn_comp_indices: bad count/shift");
+    if (count == 0) return QPN_OK;
+    if (!zv || !rv || !l || !u || !mask) return fail_arg(ctx, "qpn_comp_indices: null pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_comp_indices(count, zv, rv, l, u, tol, shift, mask, ctx->stream));
+        return QPN_OK;
+    }
+    double *dz, *dr, *dl, *du; uint8_t *dm;
+    Carver cv(ctx);
+    const size_t nb = (size_t)count * 8;
+    cv.add((void **)&dz, nb); cv.add((void **)&dr, nb); cv.add((void **)&dl, nb); cv.add((void **)&du, nb);
+    cv.add((void **)&dm, (size_t)count);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dz, zv, nb, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dr, rv, nb, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dl, l, nb, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(du, u, nb, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_comp_indices(count, dz, dr, dl, du, tol, shift, dm, s));
+    HIPCHK(ctx, hipMemcpyAsync(mask, dm, (size_t)count, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+namespace {
+struct NodeSizes { size_t Q, R, q, A, B, lu, w; };
+NodeSizes node_sizes(int32_t batch, int32_t n, int32_t m, int32_t p, int64_t stride_w)
+{
+    NodeSizes s;
+    s.Q = (size_t)batch * n * n * 8; s.R = (size_t)batch * n * p * 8; s.q = (size_t)batch * n * 8;
+    s.A = (size_t)batch * m * n * 8; s.B = (size_t)batch * m * p * 8; s.lu = (size_t)batch * m * 8;
+    s.w = (stride_w ? (size_t)(batch - 1) * stride_w + p : (size_t)p) * 8;
+    return s;
+}
+} // namespace
+
+int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p,
+                       const double *Qd, const double *R, const double *qd, const double *Ad,
+                       const double *B, const double *l, const double *u, const double *w,
+                       int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
+                       uint8_t *kind_out, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (batch < 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_assemble_nodes: bad sizes");
+    if (batch == 0) return QPN_OK;
+    if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || !w || (m > 0 && !B))) || !Mout || !qout ||
+        !lout || !uout || !kind_out)
+        return fail_arg(ctx, "qpn_assemble_nodes: null pointer");
+    if (stride_w != 0 && stride_w < p) return fail_arg(ctx, "qpn_assemble_nodes: stride_w < p");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, Mout,
+                                              qout, lout, uout, kind_out, ctx->stream));
+        return QPN_OK;
+    }
+    const NodeSizes sz = node_sizes(batch, n, m, p, stride_w);
+    const int N = n + m;
+    const size_t bN = (size_t)batch * N;
+    double *dQ, *dR, *dq, *dA, *dB, *dl, *du, *dw, *dM, *dqo, *dlo, *duo; uint8_t *dk;
+    Carver cv(ctx);
+    cv.add((void **)&dQ, sz.Q); cv.add((void **)&dR, sz.R + 8); cv.add((void **)&dq, sz.q);
+    cv.add((void **)&dA, sz.A + 8); cv.add((void **)&dB, sz.B + 8); cv.add((void **)&dl, sz.lu + 8);
+    cv.add((void **)&du, sz.lu + 8); cv.add((void **)&dw, sz.w + 8);
+    cv.add((void **)&dM, bN * N * 8); cv.add((void **)&dqo, bN * 8); cv.add((void **)&dlo, bN * 8);
+    cv.add((void **)&duo, bN * 8); cv.add((void **)&dk, bN);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dQ, Qd, sz.Q, hipMemcpyHostToDevice, s));
+    if (sz.R) HIPCHK(ctx, hipMemcpyAsync(dR, R, sz.R, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dq, qd, sz.q, hipMemcpyHostToDevice, s));
+    if (sz.A) HIPCHK(ctx, hipMemcpyAsync(dA, Ad, sz.A, hipMemcpyHostToDevice, s));
+    if (sz.B) HIPCHK(ctx, hipMemcpyAsync(dB, B, sz.B, hipMemcpyHostToDevice, s));
+    if (sz.lu) {
+        HIPCHK(ctx, hipMemcpyAsync(dl, l, sz.lu, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(du, u, sz.lu, hipMemcpyHostToDevice, s));
+    }
+    if (p > 0) HIPCHK(ctx, hipMemcpyAsync(dw, w, sz.w, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, dM,
+                                          dqo, dlo, duo, dk, s));
+    HIPCHK(ctx, hipMemcpyAsync(Mout, dM, bN * N * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(qout, dqo, bN * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(lout, dlo, bN * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(uout, duo, bN * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(kind_out, dk, bN, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p,
+                     const double *Qd, const double *R, const double *qd, const double *Ad,
+                     const double *B, const double *l, const double *u, const double *xd,
+                     const double *w, int64_t stride_w, double tol, int32_t *solution,
+                     double *lambda, int32_t *path, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (batch < 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_verify_nodes: bad sizes");
+    if (batch == 0) return QPN_OK;
+    if (n > 64 || m > 64) { ctx->last_error = "qpn_verify_nodes: n, m <= 64 in ABI v1"; return QPN_ERR_SIZE; }
+    if (!Qd || !qd || !xd || (m > 0 && (!Ad || !l || !u || !lambda)) || (p > 0 && (!R || !w || (m > 0 && !B))) ||
+        !solution || !path)
+        return fail_arg(ctx, "qpn_verify_nodes: null pointer");
+    if (stride_w != 0 && stride_w < p) return fail_arg(ctx, "qpn_verify_nodes: stride_w < p");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t mm = (size_t)(m > 0 ? m : 1);
+    // scratch of the bounded-LSQ fallback (src/qp_processing.jl:129-137): Gram block + vectors
+    double *sG, *sq, *slb, *sub, *sz, *sres; int32_t *sst;
+    if (mem == QPN_MEM_DEVICE) {
+        Carver cv(ctx);
+        cv.add((void **)&sG, (size_t)batch * mm * mm * 8); cv.add((void **)&sq, (size_t)batch * mm * 8);
+        cv.add((void **)&slb, (size_t)batch * mm * 8); cv.add((void **)&sub, (size_t)batch * mm * 8);
+        cv.add((void **)&sz, (size_t)batch * mm * 8); cv.add((void **)&sres, (size_t)batch * 8);
+        cv.add((void **)&sst, (size_t)batch * 4);
+        int rc = cv.commit();
+        if (rc != QPN_OK) return rc;
+        HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, Qd, R, qd, Ad, B, l, u, xd, w, stride_w, tol,
+                                            solution, lambda, path, sG, sq, slb, sub, sz, sres, sst, s));
+        return QPN_OK;
+    }
+    const NodeSizes sz_ = node_sizes(batch, n, m, p, stride_w);
+    double *dQ, *dR, *dq, *dA, *dB, *dl, *du, *dw, *dx, *dlam; int32_t *dsol, *dpath;
+    Carver cv(ctx);
+    cv.add((void **)&dQ, sz_.Q); cv.add((void **)&dR, sz_.R + 8); cv.add((void **)&dq, sz_.q);
+    cv.add((void **)&dA, sz_.A + 8); cv.add((void **)&dB, sz_.B + 8); cv.add((void **)&dl, sz_.lu + 8);
+    cv.add((void **)&du, sz_.lu + 8); cv.add((void **)&dw, sz_.w + 8); cv.add((void **)&dx, sz_.q);
+    cv.add((void **)&dlam, sz_.lu + 8); cv.add((void **)&dsol, (size_t)batch * 4);
+    cv.add((void **)&dpath, (size_t)batch * 4);
+    cv.add((void **)&sG, (size_t)batch * mm * mm * 8); cv.add((void **)&sq, (size_t)batch * mm * 8);
+    cv.add((void **)&slb, (size_t)batch * mm * 8); cv.add((void **)&sub, (size_t)batch * mm * 8);
+    cv.add((void **)&sz, (size_t)batch * mm * 8); cv.add((void **)&sres, (size_t)batch * 8);
+    cv.add((void **)&sst, (size_t)batch * 4);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(dQ, Qd, sz_.Q, hipMemcpyHostToDevice, s));
+    if (sz_.R) HIPCHK(ctx, hipMemcpyAsync(dR, R, sz_.R, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dq, qd, sz_.q, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dx, xd, sz_.q, hipMemcpyHostToDevice, s));
+    if (sz_.A) HIPCHK(ctx, hipMemcpyAsync(dA, Ad, sz_.A, hipMemcpyHostToDevice, s));
+    if (sz_.B) HIPCHK(ctx, hipMemcpyAsync(dB, B, sz_.B, hipMemcpyHostToDevice, s));
+    if (sz_.lu) {
+        HIPCHK(ctx, hipMemcpyAsync(dl, l, sz_.lu, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(du, u, sz_.lu, hipMemcpyHostToDevice, s));
+    }
+    if (p > 0) HIPCHK(ctx, hipMemcpyAsync(dw, w, sz_.w, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dx, dw, stride_w, tol,
+                                        dsol, dlam, dpath, sG, sq, slb, sub, sz, sres, sst, s));
+    HIPCHK(ctx, hipMemcpyAsync(solution, dsol, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(path, dpath, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    if (sz_.lu) HIPCHK(ctx, hipMemcpyAsync(lambda, dlam, sz_.lu, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+} // extern "C"

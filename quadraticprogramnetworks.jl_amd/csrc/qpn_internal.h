@@ -1,0 +1,96 @@
+// Internal declarations shared by the HIP translation units of libqpn_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qpn_hip.h"
+
+struct AviBatchArgs {
+    int32_t batch;
+    int32_t N;
+    const double *M;
+    int64_t strideM;
+    const double *q;
+    const double *l;
+    const double *u;
+    const uint8_t *kind;
+    int64_t stride_kind;
+    double *z;
+    int32_t *status;
+    double *resid;
+    int32_t *pivots;
+    uint8_t *active;
+    double check_tol, piv_tol, feas_tol, comp_tol;
+    int32_t max_pivots;
+    // optional gate: item b runs only when only_if[b] == only_if_value (others are left untouched)
+    const int32_t *only_if;
+    int32_t only_if_value;
+};
+
+// qpn_avi_solve.hip
+hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream);
+int qpn_avi_max_n();
+
+// qpn_kkt.hip
+hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,
+                                const double *q, const double *l, const double *u,
+                                const uint8_t *kind, int64_t stride_kind, const double *z,
+                                double tol, int32_t *degree, double *r, hipStream_t stream);
+hipError_t qpn_launch_comp_indices(int64_t count, const double *zv, const double *rv,
+                                   const double *l, const double *u, double tol, int32_t shift,
+                                   uint8_t *mask, hipStream_t stream);
+hipError_t qpn_launch_assemble_nodes(int32_t batch, int32_t n, int32_t m, int32_t p,
+                                     const double *Qd, const double *R, const double *qd,
+                                     const double *Ad, const double *B, const double *l,
+                                     const double *u, const double *w, int64_t stride_w,
+                                     double *Mout, double *qout, double *lout, double *uout,
+                                     uint8_t *kind_out, hipStream_t stream);
+hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t p,
+                                   const double *Qd, const double *R, const double *qd,
+                                   const double *Ad, const double *B, const double *l,
+                                   const double *u, const double *xd, const double *w,
+                                   int64_t stride_w, double tol, int32_t *solution, double *lambda,
+                                   int32_t *path, double *sG, double *sq, double *slb, double *sub,
+                                   double *sz, double *sres, int32_t *sst, hipStream_t stream);
+
+// ---- wave64 helpers (CDNA4: one wavefront = 64 lanes) --------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// lowest lane whose predicate holds, or -1 (wave-uniform result)
+__device__ __forceinline__ int wave_first(bool pred)
+{
+    unsigned long long b = __ballot(pred);
+    return b ? (__ffsll((long long)b) - 1) : -1;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif

@@ -1,0 +1,158 @@
+// qpn_kkt.hip -- the array kernels around the AVI solve, for gfx950 (CDNA4):
+//   check_avi      src/avi.jl:148-156          (A3)
+//   comp_indices   src/avi_solutions.jl:511-562 (A9)
+//   assemble_nodes src/avi.jl:205-251 + :305-377, single-node pools, reduced form (A5+A6)
+// All are HBM-bound streaming kernels: one wavefront per item, coalesced column accesses
+// (lane i <-> row i of a column-major block), no LDS staging needed.
+#include "qpn_internal.h"
+
+#define QINF __builtin_huge_val()
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// ---- (A3) check_avi_solution: one wave per item, lanes stride the rows -------------------
+__global__ __launch_bounds__(256) void check_avi_kernel(int32_t batch, int32_t N, const double *M,
+                                                        int64_t strideM, const double *q,
+                                                        const double *l, const double *u,
+                                                        const uint8_t *kind, int64_t stride_kind,
+                                                        const double *z, double tol,
+                                                        int32_t *degree, double *r_out)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int b = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (b >= batch) return;
+    const double *Mg = M + (size_t)b * (size_t)strideM;
+    const size_t vo = (size_t)b * (size_t)N;
+    int bad = 0;
+    for (int i = lane; i < N; i += WAVE) {
+        double r = q[vo + i];
+        for (int j = 0; j < N; ++j) {
+            double zj = z[vo + j];
+            if (zj != 0.0) r = fma(Mg[(size_t)j * N + i], zj, r);
+        }
+        if (r_out) r_out[vo + i] = r;
+        const int g = kind ? (int)kind[(size_t)b * (size_t)stride_kind + i] : 0;
+        const double zi = z[vo + i];
+        const double p = g ? r : zi, d = g ? zi : r;
+        const double li = l[vo + i], ui = u[vo + i];
+        if (d > tol && fabs(p - li) > tol) bad++;   // :152
+        if (d < -tol && fabs(p - ui) > tol) bad++;  // :153
+        if (p - li < -tol) bad++;                   // :154
+        if (p - ui > tol) bad++;
+        if (isnan(p) || isnan(d)) bad++;
+    }
+    bad = wave_sum_i32(bad);
+    if (lane == 0) degree[b] = bad;
+}
+
+// ---- (A9) comp_indices core: flat, one thread per row ------------------------------------
+__global__ __launch_bounds__(256) void comp_indices_kernel(int64_t count, const double *zv,
+                                                           const double *rv, const double *l,
+                                                           const double *u, double tol,
+                                                           int32_t shift, uint8_t *mask)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const double z = zv[i], r = rv[i], li = l[i], ui = u[i];
+        auto approx = [&](double x, double y) {
+            return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= tol);
+        };
+        unsigned m = 0;
+        if (!approx(li, ui)) {                                                   // :512
+            if (approx(z, li) && r >= -tol) m |= 1u;                             // :543
+            if (li - tol <= z && z <= ui + tol && fabs(r) <= tol) m |= 2u;       // :546
+            if (approx(z, ui) && r <= tol) m |= 4u;                              // :549
+        } else m = 8u;                                                           // :552-558
+        mask[i] = (uint8_t)(m << shift);
+    }
+}
+
+// ---- (A5+A6) reduced single-node KKT assembly: one wave per node ---------------------------
+// Output column j of M_i (length N = n+m) is written by lanes striding the rows: coalesced.
+__global__ __launch_bounds__(256) void assemble_nodes_kernel(
+    int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
+    const double *qd, const double *Ad, const double *B, const double *l, const double *u,
+    const double *w, int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
+    uint8_t *kind_out)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int b = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (b >= batch) return;
+    const int N = n + m;
+    const double *Q_ = Qd + (size_t)b * n * n;
+    const double *A_ = Ad + (size_t)b * m * n;
+    const double *R_ = R + (size_t)b * n * p;
+    const double *B_ = B + (size_t)b * m * p;
+    const double *w_ = w + (size_t)b * (size_t)stride_w;
+    double *Mo = Mout + (size_t)b * N * N;
+    const size_t vo = (size_t)b * (size_t)N;
+    // columns 0..n-1: [Qd(:,j) ; Ad(:,j)]
+    for (int j = 0; j < n; ++j) {
+        for (int i = lane; i < N; i += WAVE)
+            Mo[(size_t)j * N + i] = i < n ? Q_[(size_t)j * n + i] : A_[(size_t)j * m + (i - n)];
+    }
+    // columns n..N-1: [-Ad(c,:)' ; 0]
+    for (int c = 0; c < m; ++c) {
+        for (int i = lane; i < N; i += WAVE)
+            Mo[(size_t)(n + c) * N + i] = i < n ? -A_[(size_t)i * m + c] : 0.0;
+    }
+    for (int i = lane; i < N; i += WAVE) {
+        double s;
+        if (i < n) {
+            s = qd[(size_t)b * n + i];
+            for (int k = 0; k < p; ++k) s = fma(R_[(size_t)k * n + i], w_[k], s);
+            lout[vo + i] = -QINF; uout[vo + i] = QINF; kind_out[vo + i] = QPN_ROW_STD;
+        } else {
+            const int r = i - n;
+            s = 0.0;
+            for (int k = 0; k < p; ++k) s = fma(B_[(size_t)k * m + r], w_[k], s);
+            lout[vo + i] = l[(size_t)b * m + r]; uout[vo + i] = u[(size_t)b * m + r];
+            kind_out[vo + i] = QPN_ROW_GAVI;
+        }
+        qout[vo + i] = s;
+    }
+}
+
+} // namespace
+
+hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,
+                                const double *q, const double *l, const double *u,
+                                const uint8_t *kind, int64_t stride_kind, const double *z,
+                                double tol, int32_t *degree, double *r, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    const int wpb = 4;
+    hipLaunchKernelGGL(check_avi_kernel, dim3((batch + wpb - 1) / wpb), dim3(wpb * WAVE), 0, stream,
+                       batch, N, M, strideM, q, l, u, kind, stride_kind, z, tol, degree, r);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_comp_indices(int64_t count, const double *zv, const double *rv,
+                                   const double *l, const double *u, double tol, int32_t shift,
+                                   uint8_t *mask, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(comp_indices_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, count, zv,
+                       rv, l, u, tol, shift, mask);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_assemble_nodes(int32_t batch, int32_t n, int32_t m, int32_t p,
+                                     const double *Qd, const double *R, const double *qd,
+                                     const double *Ad, const double *B, const double *l,
+                                     const double *u, const double *w, int64_t stride_w,
+                                     double *Mout, double *qout, double *lout, double *uout,
+                                     uint8_t *kind_out, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    const int wpb = 4;
+    hipLaunchKernelGGL(assemble_nodes_kernel, dim3((batch + wpb - 1) / wpb), dim3(wpb * WAVE), 0,
+                       stream, batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, Mout, qout,
+                       lout, uout, kind_out);
+    return hipGetLastError();
+}

@@ -1,0 +1,261 @@
+// qpn_verify.hip -- batched per-node KKT verification for gfx950 (CDNA4).
+//
+// Restates verify_solution, src/qp_processing.jl:57-149, on dense per-node records
+// (Qd, R, qd, Ad, B, l, u) with the reference's tolerances: feasibility 1e-3 (:86), active
+// rows 1e-2 (:98-99), sign / residual `tol` = 1e-4 (:57, :119), fallback residual 1e-4 (:138).
+//
+// Three launches on one stream, no host round trip:
+//   verify_stage1   one wavefront per node: gradient q~ (:58-60), Ax (:84), feasibility,
+//                   active-row classes, least-squares duals by the normal equations
+//                   G y = A_bar' q~ with a diagonally pivoted Cholesky kept in LDS (the sparse
+//                   `\` of :115), sign/residual test (:119).  Nodes that fail it get their
+//                   bounded-LSQ box-AVI (Ad Ad', -Ad q~, sign bounds; :129-137 with the PATH MCP
+//                   of :12-27 reduced to its lambda block) written to scratch, path = -1.
+//   avi_solve_lds1  (qpn_avi_solve.hip) gated on path == -1.
+//   verify_stage2   accepts iff || Ad' lambda - q~ ||_2 <= 1e-4 (:138).
+#include "qpn_internal.h"
+
+#define QINF __builtin_huge_val()
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int LDV = 65;   // odd leading dimension: column and row sweeps are both conflict-light
+
+struct VerifyArgs {
+    int32_t batch, n, m, p;
+    const double *Qd, *R, *qd, *Ad, *B, *l, *u, *xd, *w;
+    int64_t stride_w;
+    double tol;
+    int32_t *solution;
+    double *lambda;
+    int32_t *path;
+    double *sG, *sq, *slb, *sub, *sz;
+};
+
+__global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
+{
+    const int n = a.n, m = a.m, p = a.p;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    __shared__ double sA[LDV * 64];   // Ad, column-major, ld = LDV
+    __shared__ double sGa[LDV * 64];  // Gram block of the active rows, then its Cholesky factor
+    __shared__ double sqt[64];        // q~
+    __shared__ double svec[64];       // broadcast vector (xd, factor column, y)
+    __shared__ int srow[64];          // active column -> row
+    __shared__ double ssg[64];        // active column -> sign
+
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *B_ = a.B + (size_t)b * m * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double *lam = a.lambda + (size_t)b * m;
+
+    if (lane < n) svec[lane] = a.xd[(size_t)b * n + lane];
+    if (lane < m)
+        for (int j = 0; j < n; ++j) sA[j * LDV + lane] = A_[(size_t)j * m + lane];
+    __syncthreads();
+
+    // :58-60  q~ = Q[dec,:] x + q[dec]   (lane i < n)
+    double qt = 0.0;
+    if (lane < n) {
+        qt = a.qd[(size_t)b * n + lane];
+        for (int j = 0; j < n; ++j) qt = fma(Q_[(size_t)j * n + lane], svec[j], qt);
+        for (int k = 0; k < p; ++k) qt = fma(R_[(size_t)k * n + lane], w_[k], qt);
+        sqt[lane] = qt;
+    }
+    // :84  ax (lane r < m)
+    double ax = 0.0, lr = 0.0, ur = 0.0;
+    if (lane < m) {
+        for (int j = 0; j < n; ++j) ax = fma(sA[j * LDV + lane], svec[j], ax);
+        for (int k = 0; k < p; ++k) ax = fma(B_[(size_t)k * m + lane], w_[k], ax);
+        lr = a.l[(size_t)b * m + lane]; ur = a.u[(size_t)b * m + lane];
+        lam[lane] = 0.0;
+    }
+    __syncthreads();
+
+    // :86  feasibility, tol 1e-3 (Slice membership, src/sets.jl:851-854)
+    const bool infeas = lane < m && !(lr - 1e-3 <= ax && ax - 1e-3 <= ur);
+    if (__ballot(infeas)) {
+        if (lane == 0) { a.solution[b] = 0; a.path[b] = 0; }
+        return;
+    }
+    if (m == 0) {   // :91-96
+        double s = wave_sum_f64(lane < n ? qt * qt : 0.0);
+        if (lane == 0) { a.solution[b] = sqrt(s) <= a.tol ? 1 : 0; a.path[b] = 1; }
+        return;
+    }
+    // :98-103  active-row classes
+    const bool pos0 = lane < m && ax < lr + 1e-2, neg0 = lane < m && ax > ur - 1e-2;
+    const int cls = (pos0 ? 1 : 0) | (neg0 ? 2 : 0);
+    const unsigned long long bp = __ballot(cls == 1), bn = __ballot(cls == 2), bb = __ballot(cls == 3);
+    const int np = __popcll(bp), nn = __popcll(bn), nb = __popcll(bb);
+    const int k = np + nn + nb;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int mycol = -1;
+    if (cls == 1) mycol = __popcll(bp & below);
+    else if (cls == 2) mycol = np + __popcll(bn & below);
+    else if (cls == 3) mycol = np + nn + __popcll(bb & below);
+    if (mycol >= 0) { srow[mycol] = lane; ssg[mycol] = cls == 2 ? -1.0 : 1.0; }
+    __syncthreads();
+
+    // ---- :114-115  least squares  A_bar y ~ q~  through the normal equations --------------
+    // lane c < k owns active column c:  A_bar(:,c) = sg_c * Ad(row_c,:)'
+    const int myrow = lane < k ? srow[lane] : 0;
+    const double mysg = lane < k ? ssg[lane] : 0.0;
+    double rhs = 0.0;
+    if (lane < k) {
+        for (int c2 = 0; c2 < k; ++c2) {
+            const int r2 = srow[c2];
+            double s = 0.0;
+            for (int t = 0; t < n; ++t) s = fma(sA[t * LDV + myrow], sA[t * LDV + r2], s);
+            sGa[c2 * LDV + lane] = s * mysg * ssg[c2];
+        }
+        for (int t = 0; t < n; ++t) rhs = fma(sA[t * LDV + myrow], sqt[t], rhs);
+        rhs *= mysg;
+    }
+    __syncthreads();
+    // diagonally pivoted Cholesky, in place: column ord[s] of sGa becomes column s of the factor
+    bool done = !(lane < k);       // this lane's column already pivoted (or not a column)
+    int mystep = -1;               // elimination step at which this lane was the pivot
+    double diag = lane < k ? sGa[lane * LDV + lane] : 0.0;
+    const double dscale = wave_max_f64(lane < k ? diag : 0.0);
+    int rank = 0;
+    double bvec = rhs;             // running right-hand side of the forward substitution
+    for (int s = 0; s < k; ++s) {
+        const double dmax = wave_max_f64(done ? -1.0 : diag);
+        if (!(dmax > 1e-12 * (dscale > 1.0 ? dscale : 1.0))) break;
+        const int pv = wave_first(!done && diag == dmax);
+        const double lpp = sqrt(dmax);
+        // factor column: L(i,s) = G(i,pv)/lpp for the remaining i; L(pv,s) = lpp
+        double lis = 0.0;
+        if (lane < k && !done) lis = lane == pv ? lpp : sGa[pv * LDV + lane] / lpp;
+        if (lane < k) svec[lane] = (done || lane == pv) ? 0.0 : lis;
+        __syncthreads();
+        if (lane < k && !done && lane != pv) {
+            for (int j = 0; j < k; ++j) {
+                const double lj = svec[j];
+                if (lj != 0.0) sGa[j * LDV + lane] = fma(-lis, lj, sGa[j * LDV + lane]);
+            }
+            diag = sGa[lane * LDV + lane];
+        }
+        if (lane < k && !done) sGa[pv * LDV + lane] = lis;   // store L(:,s) in the freed column
+        // forward substitution step: w_s = b_pv / lpp ; b_i -= L(i,s) w_s
+        const double ws = __shfl(bvec, pv, WAVE) / lpp;
+        if (lane < k && !done && lane != pv) bvec = fma(-lis, ws, bvec);
+        if (lane == pv) { done = true; mystep = s; bvec = ws; }
+        rank++;
+        __syncthreads();
+    }
+    // back substitution  L' y = w  over the pivoted columns, last step first
+    double y = 0.0;
+    for (int s = rank - 1; s >= 0; --s) {
+        const int pv = wave_first(mystep == s);
+        // sum over columns pivoted later: L(i, s) * y_i, with L(:,s) stored in column pv
+        const double term = (lane < k && mystep > s) ? sGa[pv * LDV + lane] * y : 0.0;
+        const double acc = wave_sum_f64(term);
+        if (lane == pv) y = (bvec - acc) / sGa[pv * LDV + pv];
+    }
+    // :119  sign and residual tests
+    const bool badsign = lane < np + nn && !(y > -a.tol);
+    __syncthreads();
+    if (lane < k) svec[lane] = y * mysg;
+    __syncthreads();
+    double res = 0.0;
+    if (lane < n) {
+        double s = -qt;
+        for (int c = 0; c < k; ++c) s = fma(sA[lane * LDV + srow[c]], svec[c], s);
+        res = s * s;
+    }
+    res = wave_sum_f64(res);
+    const bool ok = !__ballot(badsign) && sqrt(res) <= a.tol;
+    if (ok) {
+        if (lane < k) lam[myrow] = (mysg < 0.0) ? -y : y;   // :120-123
+        if (lane == 0) { a.solution[b] = 1; a.path[b] = 2; }
+        return;
+    }
+    // ---- :129-137  bounded least squares as a box-AVI in lambda, handed to the AVI kernel ---
+    if (lane < m) {
+        double *G = a.sG + (size_t)b * m * m;
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < n; ++t) s = fma(sA[t * LDV + lane], sA[t * LDV + j], s);
+            G[(size_t)j * m + lane] = s;
+        }
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s = fma(sA[t * LDV + lane], sqt[t], s);
+        a.sq[(size_t)b * m + lane] = -s;
+        a.slb[(size_t)b * m + lane] = (cls & 2) ? -QINF : 0.0;   // :129-131
+        a.sub[(size_t)b * m + lane] = (cls & 1) ? QINF : 0.0;    // :132-134
+        a.sz[(size_t)b * m + lane] = 0.0;
+    }
+    if (lane == 0) { a.solution[b] = 0; a.path[b] = -1; }
+}
+
+__global__ __launch_bounds__(WAVE) void verify_stage2(VerifyArgs a, const int32_t *avi_status)
+{
+    const int n = a.n, m = a.m, p = a.p;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (a.path[b] != -1) return;
+    double *lam = a.lambda + (size_t)b * m;
+    if (avi_status[b] != QPN_SUCCESS) {   // :143-145
+        if (lane < m) lam[lane] = 0.0;
+        if (lane == 0) { a.solution[b] = 0; a.path[b] = 5; }
+        return;
+    }
+    __shared__ double sl_[64], sx[64];
+    if (lane < m) { sl_[lane] = a.sz[(size_t)b * m + lane]; lam[lane] = sl_[lane]; }
+    if (lane < n) sx[lane] = a.xd[(size_t)b * n + lane];
+    __syncthreads();
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double res = 0.0;
+    if (lane < n) {
+        double qt = a.qd[(size_t)b * n + lane];
+        for (int j = 0; j < n; ++j) qt = fma(Q_[(size_t)j * n + lane], sx[j], qt);
+        for (int k = 0; k < p; ++k) qt = fma(R_[(size_t)k * n + lane], w_[k], qt);
+        double s = -qt;
+        for (int i = 0; i < m; ++i) s = fma(A_[(size_t)lane * m + i], sl_[i], s);
+        res = s * s;
+    }
+    res = wave_sum_f64(res);
+    if (lane == 0) {
+        const bool ok = sqrt(res) <= 1e-4;   // :138
+        a.solution[b] = ok ? 1 : 0;
+        a.path[b] = ok ? 3 : 4;
+    }
+}
+
+} // namespace
+
+hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t p,
+                                   const double *Qd, const double *R, const double *qd,
+                                   const double *Ad, const double *B, const double *l,
+                                   const double *u, const double *xd, const double *w,
+                                   int64_t stride_w, double tol, int32_t *solution, double *lambda,
+                                   int32_t *path, double *sG, double *sq, double *slb, double *sub,
+                                   double *sz, double *sres, int32_t *sst, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    VerifyArgs a{};
+    a.batch = batch; a.n = n; a.m = m; a.p = p;
+    a.Qd = Qd; a.R = R; a.qd = qd; a.Ad = Ad; a.B = B; a.l = l; a.u = u; a.xd = xd; a.w = w;
+    a.stride_w = stride_w; a.tol = tol; a.solution = solution; a.lambda = lambda; a.path = path;
+    a.sG = sG; a.sq = sq; a.slb = slb; a.sub = sub; a.sz = sz;
+    hipLaunchKernelGGL(verify_stage1, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || m == 0) return e;
+    AviBatchArgs s{};
+    s.batch = batch; s.N = m; s.M = sG; s.strideM = (int64_t)m * m; s.q = sq; s.l = slb; s.u = sub;
+    s.kind = nullptr; s.stride_kind = 0; s.z = sz; s.status = sst; s.resid = sres; s.pivots = nullptr;
+    s.active = nullptr; s.check_tol = 1e-6; s.piv_tol = 1e-11; s.feas_tol = 1e-12; s.comp_tol = 1e-2;
+    s.max_pivots = 0; s.only_if = path; s.only_if_value = -1;
+    e = qpn_launch_avi_solve(s, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(verify_stage2, dim3((unsigned)batch), dim3(WAVE), 0, stream, a, (const int32_t *)sst);
+    return hipGetLastError();
+}

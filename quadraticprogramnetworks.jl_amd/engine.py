@@ -1,0 +1,242 @@
+"""Host wrapper over the C-ABI (include/qpn_hip.h): one ``Engine`` = one ``qpn_ctx`` on one GPU.
+
+Buffers may be numpy arrays (host; the library stages them through HBM) or torch CUDA tensors
+(device; zero-copy, asynchronous on torch's current stream).  All matrix buffers are in the
+ABI layout: per item COLUMN-MAJOR (Julia), i.e. a ``(batch, N, N)`` array ``Mc`` holds
+``Mc[b, j, i] = M_b[i, j]``.  ``colmajor()`` converts from the usual math layout.
+
+There is no CPU path here: every method ends in a HIP kernel launch or raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MEM_DEVICE, MEM_HOST, AviOpts
+
+try:  # torch is plumbing (device memory, streams, torch.distributed), not a requirement to import
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class QpnError(RuntimeError):
+    pass
+
+
+def colmajor(M):
+    """(..., rows, cols) math-layout array -> same data in the ABI's column-major layout."""
+    if torch is not None and isinstance(M, torch.Tensor):
+        return M.transpose(-1, -2).contiguous()
+    return np.ascontiguousarray(np.swapaxes(np.asarray(M, dtype=np.float64), -1, -2))
+
+
+def _is_dev(x):
+    return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if torch is not None and isinstance(x, torch.Tensor):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)
+
+
+class Engine:
+    """One context on one GPU.  ``device`` is a HIP device ordinal."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        self.lib = _lib.load_library()
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.qpn_ctx_create(self.device, C.byref(h))
+        if rc != 0:
+            raise QpnError(f"qpn_ctx_create({device}) failed: {self.lib.qpn_strerror(rc).decode()}")
+        self.ctx = h
+        self.use_torch_stream = use_torch_stream
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.qpn_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.qpn_ctx_last_error(self.ctx).decode()
+            raise QpnError(f"{what}: {self.lib.qpn_strerror(rc).decode()} ({msg})")
+
+    def _bind_stream(self, dev):
+        if dev and self.use_torch_stream:
+            s = torch.cuda.current_stream(self.device).cuda_stream
+            self.lib.qpn_ctx_set_stream(self.ctx, C.c_void_p(s))
+
+    def synchronize(self):
+        self._chk(self.lib.qpn_ctx_synchronize(self.ctx), "qpn_ctx_synchronize")
+
+    def default_opts(self) -> AviOpts:
+        o = AviOpts()
+        self.lib.qpn_avi_default_opts(C.byref(o))
+        return o
+
+    def _mode(self, *arrs):
+        devs = [_is_dev(a) for a in arrs if a is not None]
+        if any(devs) and not all(devs):
+            raise QpnError("mixing host and device buffers in one call")
+        return bool(devs and devs[0])
+
+    def _host(self, a, dtype):
+        return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+    def _alloc(self, dev, shape, dtype):
+        if dev:
+            tdt = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8}[dtype]
+            return torch.empty(shape, dtype=tdt, device=f"cuda:{self.device}")
+        return np.empty(shape, dtype=dtype)
+
+    # -- (A2+A3+A9) ------------------------------------------------------------------------
+    def solve_avi_batch(self, Mc, q, l, u, z0=None, kind=None, opts=None, want_active=True):
+        """Batched AVI solve; replaces PATHSolver.solve_mcp (src/avi.jl:64-70) per item.
+
+        Mc: (batch, N, N) column-major per item, or (N, N) shared.  q, l, u: (batch, N).
+        kind: None | (N,) shared | (batch, N) uint8.  Returns dict(z, status, resid, pivots, active).
+        """
+        dev = self._mode(Mc, q, l, u, z0, kind)
+        self._bind_stream(dev)
+        if not dev:
+            Mc, q, l, u = (self._host(a, np.float64) for a in (Mc, q, l, u))
+            kind = self._host(kind, np.uint8)
+        elif not all(t.is_contiguous() for t in (Mc, q, l, u)):
+            raise QpnError("device buffers must be contiguous")
+        batch, N = q.shape
+        strideM = 0 if Mc.ndim == 2 else N * N
+        sk = 0 if (kind is None or kind.ndim == 1) else N
+        if z0 is None:
+            z = torch.zeros_like(q) if dev else np.zeros_like(q)
+        else:
+            z = z0.clone() if dev else np.array(z0, dtype=np.float64, order="C", copy=True)
+        status = self._alloc(dev, (batch,), np.int32)
+        resid = self._alloc(dev, (batch,), np.float64)
+        pivots = self._alloc(dev, (batch,), np.int32)
+        active = self._alloc(dev, (batch, N), np.uint8) if want_active else None
+        o = opts if opts is not None else self.default_opts()
+        rc = self.lib.qpn_solve_avi_batch(self.ctx, batch, N, _ptr(Mc), strideM, _ptr(q), _ptr(l),
+                                          _ptr(u), _ptr(kind), sk, _ptr(z), _ptr(status),
+                                          _ptr(resid), _ptr(pivots), _ptr(active), C.byref(o),
+                                          MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_solve_avi_batch")
+        return dict(z=z, status=status, resid=resid, pivots=pivots, active=active)
+
+    def solve_mcp_csc(self, N, colptr, rowval, nzval, q, l, u, z0, opts=None):
+        """One box-MCP in Julia's SparseMatrixCSC{Float64,Int32} layout (1-based): the argument
+        list of PATHSolver.solve_mcp at src/avi.jl:64.  Returns (status, z, info)."""
+        colptr = np.ascontiguousarray(colptr, dtype=np.int32)
+        rowval = np.ascontiguousarray(rowval, dtype=np.int32)
+        nzval = np.ascontiguousarray(nzval, dtype=np.float64)
+        q, l, u = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, l, u))
+        z = np.array(z0, dtype=np.float64, copy=True)
+        st, res, piv = C.c_int32(0), C.c_double(0), C.c_int32(0)
+        o = opts if opts is not None else self.default_opts()
+        rc = self.lib.qpn_solve_mcp_csc(self.ctx, int(N), _ptr(colptr), _ptr(rowval), _ptr(nzval),
+                                        _ptr(q), _ptr(l), _ptr(u), _ptr(z), C.byref(st),
+                                        C.byref(res), C.byref(piv), C.byref(o))
+        self._chk(rc, "qpn_solve_mcp_csc")
+        return int(st.value), z, dict(resid=res.value, pivots=piv.value)
+
+    # -- (A3) ------------------------------------------------------------------------------
+    def check_avi_batch(self, Mc, q, l, u, z, kind=None, tol=1e-6, want_r=True):
+        dev = self._mode(Mc, q, l, u, z, kind)
+        self._bind_stream(dev)
+        if not dev:
+            Mc, q, l, u, z = (self._host(a, np.float64) for a in (Mc, q, l, u, z))
+            kind = self._host(kind, np.uint8)
+        batch, N = q.shape
+        strideM = 0 if Mc.ndim == 2 else N * N
+        sk = 0 if (kind is None or kind.ndim == 1) else N
+        degree = self._alloc(dev, (batch,), np.int32)
+        r = self._alloc(dev, (batch, N), np.float64) if want_r else None
+        rc = self.lib.qpn_check_avi_batch(self.ctx, batch, N, _ptr(Mc), strideM, _ptr(q), _ptr(l),
+                                          _ptr(u), _ptr(kind), sk, _ptr(z), float(tol),
+                                          _ptr(degree), _ptr(r), MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_check_avi_batch")
+        return degree, r
+
+    # -- (A9) ------------------------------------------------------------------------------
+    def comp_indices(self, zv, rv, l, u, tol=1e-2, shift=0):
+        dev = self._mode(zv, rv, l, u)
+        self._bind_stream(dev)
+        if not dev:
+            zv, rv, l, u = (self._host(a, np.float64) for a in (zv, rv, l, u))
+        count = int(np.prod(zv.shape))
+        mask = self._alloc(dev, tuple(zv.shape), np.uint8)
+        rc = self.lib.qpn_comp_indices(self.ctx, count, _ptr(zv), _ptr(rv), _ptr(l), _ptr(u),
+                                       float(tol), int(shift), _ptr(mask),
+                                       MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_comp_indices")
+        return mask
+
+    # -- (A5+A6) ---------------------------------------------------------------------------
+    def assemble_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w):
+        """Per-node reduced KKT blocks.  Qc (batch,n,n), Rc (batch,p,n), Ac (batch,n,m),
+        Bc (batch,p,m): all column-major per item (see ``colmajor``); w (p,) shared or (batch,p)."""
+        dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, w)
+        self._bind_stream(dev)
+        if not dev:
+            Qc, Rc, qd, Ac, Bc, l, u, w = (self._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u, w))
+        batch, n = qd.shape
+        m = l.shape[1]
+        p = w.shape[-1]
+        sw = 0 if w.ndim == 1 else p
+        N = n + m
+        Mout = self._alloc(dev, (batch, N, N), np.float64)
+        qout = self._alloc(dev, (batch, N), np.float64)
+        lout = self._alloc(dev, (batch, N), np.float64)
+        uout = self._alloc(dev, (batch, N), np.float64)
+        kind = self._alloc(dev, (batch, N), np.uint8)
+        rc = self.lib.qpn_assemble_nodes(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd),
+                                         _ptr(Ac), _ptr(Bc), _ptr(l), _ptr(u), _ptr(w), sw,
+                                         _ptr(Mout), _ptr(qout), _ptr(lout), _ptr(uout), _ptr(kind),
+                                         MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_assemble_nodes")
+        return Mout, qout, lout, uout, kind
+
+    # -- (A8) ------------------------------------------------------------------------------
+    def verify_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, xd, w, tol=1e-4):
+        """Batched verify_solution (src/qp_processing.jl:57-149) -> (solution, lambda, path)."""
+        dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, xd, w)
+        self._bind_stream(dev)
+        if not dev:
+            Qc, Rc, qd, Ac, Bc, l, u, xd, w = (self._host(a, np.float64)
+                                               for a in (Qc, Rc, qd, Ac, Bc, l, u, xd, w))
+        batch, n = qd.shape
+        m = l.shape[1]
+        p = w.shape[-1]
+        sw = 0 if w.ndim == 1 else p
+        sol = self._alloc(dev, (batch,), np.int32)
+        path = self._alloc(dev, (batch,), np.int32)
+        lam = self._alloc(dev, (batch, max(m, 1)), np.float64)
+        rc = self.lib.qpn_verify_nodes(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd),
+                                       _ptr(Ac), _ptr(Bc), _ptr(l), _ptr(u), _ptr(xd), _ptr(w), sw,
+                                       float(tol), _ptr(sol), _ptr(lam), _ptr(path),
+                                       MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_verify_nodes")
+        return sol, lam[:, :m], path
+
+
+_default = {}
+
+
+def default_engine(device: int = 0) -> Engine:
+    """Process-wide engine per device (created on first use)."""
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]
