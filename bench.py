@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- node-AVI solves/sec (fp64) on the synthetic 10 000-node x 32-var QPNet.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under torch.distributed.run,
+one rank per GPU, RCCL).  One STEP = one pass of the hot path over the whole net:
+    per rank, for its contiguous node range:
+        (A5+A6) qpn_assemble_nodes   per-node KKT blocks from the node records and the parameters w
+        (A2+A3+A9) qpn_solve_avi_batch   every node-AVI from cold duals, post-check + active sets
+    all ranks: RCCL all-gather of the primal blocks (the iterate x the outer loop needs), N > 1 only.
+Inputs (node records) are resident in HBM before the timed region.  Total work is fixed at 10 000
+nodes (BASELINE.json configs[3]) => "scaling": "strong".  value = solved node-AVIs / second over
+all ranks (failed items do not count; there are none on this workload).
+
+Extra objects on the JSON line: "roofline" (HBM bound; achieved = algorithmic bytes of SURVEY.md
+section 8(d) per solve-kernel launch / mean launch duration, measured with HIP events on the launch
+stream) and "cpu_baseline" (the CPU oracle -- a port, not PATH -- on the host cores, rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+NODES, NVAR, NCON, NPAR = 10_000, 32, 32, 8
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nodes", type=int, default=NODES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    import qpn_amd
+    from qpn_amd import sharding, synthetic
+    from qpn_amd.engine import colmajor
+
+    eng = qpn_amd.Engine(local_rank)
+    n, m, p = NVAR, NCON, NPAR
+    N = n + m
+    lo_id, hi_id = sharding.node_range(args.nodes, world, rank)
+    cnt = hi_id - lo_id
+
+    # ---- this rank's node records, generated from the per-node Philox streams, then made resident
+    Q, R, qd, A, B, l, u = synthetic.synth_nodes(lo_id, cnt, n, m, p)
+    w_host = synthetic.shared_params(p)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    dQ, dR, dqd, dA, dB, dl, du, dw = (t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)),
+                                       t(colmajor(B)), t(l), t(u), t(w_host))
+    x_all = torch.zeros((args.nodes, n), dtype=torch.float64, device=dev)
+    counts = [sharding.node_range(args.nodes, world, r) for r in range(world)]
+    z0 = torch.zeros((cnt, N), dtype=torch.float64, device=dev)
+
+    ev_pairs = []
+
+    def step(record):
+        Mc, q, lo, hi, kind = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw)
+        if record:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        res = eng.solve_avi_batch(Mc, q, lo, hi, z0=z0, kind=kind)
+        if record:
+            e1.record(); ev_pairs.append((e0, e1))
+        xloc = res["z"][:, :n].contiguous()
+        if world > 1:
+            sharding.all_gather_primal(x_all, xloc, counts, dist)
+        else:
+            x_all[lo_id:hi_id].copy_(xloc)
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    solved_local = int((res["status"] == 1).sum().item())
+    max_resid = float(res["resid"].max().item())
+    tt = torch.tensor([dt, float(solved_local), max_resid], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, solved, max_resid = float(mx[0]), int(sm[1]), float(mx[2])
+    else:
+        solved = solved_local
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
+
+    if rank == 0:
+        per_solve = synthetic.algorithmic_bytes(n, m)
+        achieved = per_solve * cnt / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("avi_solve_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "node-AVI solves/sec (fp64) on synthetic N-node QPNet",
+            "value": solved * args.steps / dt / 1.0,
+            "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.nodes}-node x {n}-var two-level QPNet "
+                                   f"(n=m={n}, N_red={N}, p={p}; BASELINE.json configs[3]); step = "
+                                   "assemble + cold-start AVI solve + check + active sets"
+                                   + (" + RCCL all-gather of primals" if world > 1 else ""),
+                       "nodes": args.nodes, "n": n, "m": m, "params": p,
+                       "sharding": f"node ranges over {world} GPU(s)",
+                       "max_resid": max_resid, "solved": solved},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "avi_solve", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Q, R, qd, A, B, l, u, w_host)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(Q, R, qd, A, B, l, u, w):
+    """The CPU oracle (a port -- NOT Julia+PATH, which cannot run here) on the same node records,
+    all host cores, OpenMP over nodes.  Bounded: the 10 000-node batch, best of 3 passes."""
+    from oracle import binding as ob
+    ob.build()
+    cnt, n = qd.shape
+    m = l.shape[1]
+    N = n + m
+    Mc = np.zeros((cnt, N, N))           # column-major per item: Mc[b, j, i] = M[i, j]
+    Mc[:, :n, :n] = np.swapaxes(Q, 1, 2)
+    Mc[:, :n, n:] = np.swapaxes(A, 1, 2)     # M[n+r, j] = A[r, j]
+    Mc[:, n:, :n] = -A                        # M[i, n+r] = -A[r, i]
+    q = np.concatenate([qd + R @ w, B @ w], axis=1)
+    lo = np.concatenate([np.full((cnt, n), -np.inf), l], axis=1)
+    hi = np.concatenate([np.full((cnt, n), np.inf), u], axis=1)
+    kind = np.concatenate([np.zeros((cnt, n), np.uint8), np.ones((cnt, m), np.uint8)], axis=1)
+    z0 = np.zeros((cnt, N))
+    Mc = np.ascontiguousarray(Mc.reshape(cnt, N * N))
+    best = None
+    cores = ob.num_threads()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = ob.solve_avi_batch_colmajor(Mc, N * N, q, lo, hi, z0, np.ascontiguousarray(kind), N, nthreads=cores)
+        dt = time.perf_counter() - t0
+        rate = (cnt - r["nfail"]) / dt
+        best = rate if best is None else max(best, rate)
+    return {"value": best, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"the same {cnt}-node batch (solve only, blocks pre-assembled), best of 3 passes, "
+                      "CPU restatement oracle/qpn_oracle.c with OpenMP -- not Julia+PATH"}
+
+
+if __name__ == "__main__":
+    main()

@@ -181,8 +181,8 @@ static void do_pivot(tab_t *S, int r, int c, double delta, double leave_val)
         if (i == r) continue;
         double *Ti = T + (size_t)i * NC;
         double cm = Ti[c];
-        for (int j = 0; j < NC; ++j)
-            if (j != c) Ti[j] = fma(-cm, Tr[j], Ti[j]);
+        double ncm = -cm;
+        for (int j = 0; j < NC; ++j) Ti[j] = fma(ncm, Tr[j], Ti[j]); /* entry c rewritten below */
         Ti[c] = cm * inv;
     }
     for (int j = 0; j < NC; ++j)
@@ -210,9 +210,18 @@ static int is_must_leave(const tab_t *S, int v, double *target)
 
 static int is_ordinary_pair(const tab_t *S, int k) { return !pair_free(S, k) && !pair_fixed(S, k); }
 
-int qpo_solve_avi(int N, const double *M, const double *q, const double *l, const double *u,
-                  const uint8_t *rowkind, double *z, const qpo_opts *opts_in,
-                  double *resid_out, int *pivots_out, uint8_t *active)
+/* bytes of scratch one solve of size N needs */
+static size_t avi_ws_bytes(int N)
+{
+    size_t NC = (size_t)N + 1;
+    size_t d = (size_t)N * NC + N + NC + N;              /* T, xb, nbval, r */
+    size_t i = (size_t)N + NC + 2 * (2 * (size_t)N + 1) + (8 * (size_t)N + 8);
+    return d * sizeof(double) + i * sizeof(int) + (size_t)N + 64;
+}
+
+static int solve_avi_ws(int N, const double *M, const double *q, const double *l, const double *u,
+                        const uint8_t *rowkind, double *z, const qpo_opts *opts_in,
+                        double *resid_out, int *pivots_out, uint8_t *active, void *ws)
 {
     qpo_opts opts;
     if (opts_in) opts = *opts_in; else qpo_default_opts(&opts);
@@ -223,15 +232,19 @@ int qpo_solve_avi(int N, const double *M, const double *q, const double *l, cons
 
     tab_t S;
     S.N = N; S.NC = NC; S.l = l; S.u = u; S.piv_tol = opts.piv_tol;
-    S.T = (double *)malloc(sizeof(double) * (size_t)N * NC);
-    S.xb = (double *)malloc(sizeof(double) * (size_t)N);
-    S.nbval = (double *)malloc(sizeof(double) * (size_t)NC);
-    S.rowvar = (int *)malloc(sizeof(int) * (size_t)N);
-    S.colvar = (int *)malloc(sizeof(int) * (size_t)NC);
-    S.posb = (int *)malloc(sizeof(int) * (size_t)(2 * N + 1));
-    S.posn = (int *)malloc(sizeof(int) * (size_t)(2 * N + 1));
-    S.at_upper = (uint8_t *)calloc((size_t)N, 1);
-    int *enter_list = (int *)malloc(sizeof(int) * (size_t)(8 * N + 8));
+    double *dws = (double *)ws;
+    S.T = dws; dws += (size_t)N * NC;
+    S.xb = dws; dws += N;
+    S.nbval = dws; dws += NC;
+    double *r = dws; dws += N;
+    int *iws = (int *)dws;
+    S.rowvar = iws; iws += N;
+    S.colvar = iws; iws += NC;
+    S.posb = iws; iws += 2 * N + 1;
+    S.posn = iws; iws += 2 * N + 1;
+    int *enter_list = iws; iws += 8 * N + 8;
+    S.at_upper = (uint8_t *)iws;
+    memset(S.at_upper, 0, (size_t)N);
     int n_enter = 0;
 
     for (int v = 0; v <= 2 * N; ++v) { S.posb[v] = -1; S.posn[v] = -1; }
@@ -439,10 +452,22 @@ int qpo_solve_avi(int N, const double *M, const double *q, const double *l, cons
     }
 
     /* ---- post-check, src/avi.jl:71-76 ---- */
-    double *r = (double *)malloc(sizeof(double) * (size_t)N);
     int bad = qpo_check_avi_solution(N, M, q, l, u, rowkind, z, opts.check_tol, r);
     if (bad > 0) { if (status == QPO_SUCCESS) status = QPO_FAILURE; }
-    if (resid_out) *resid_out = qpo_natural_residual(N, M, q, l, u, rowkind, z);
+    if (resid_out) { /* natural-map residual from the r = Mz+q just computed */
+        double res = 0.0;
+        for (int i = 0; i < N; ++i) {
+            int g = rowkind ? rowkind[i] : 0;
+            double p = g ? r[i] : z[i], d = g ? z[i] : r[i];
+            double t = p - d;
+            if (t < l[i]) t = l[i];
+            if (t > u[i]) t = u[i];
+            double e = fabs(p - t);
+            if (isnan(e)) e = QINF;
+            if (e > res) res = e;
+        }
+        *resid_out = res;
+    }
     if (pivots_out) *pivots_out = pivots;
     if (active) {
         for (int k = 0; k < N; ++k) {
@@ -451,10 +476,17 @@ int qpo_solve_avi(int N, const double *M, const double *q, const double *l, cons
             qpo_comp_indices(1, &p, &d, l + k, u + k, 1e-2, g ? 4 : 0, active + k);
         }
     }
-    free(r);
-    free(S.T); free(S.xb); free(S.nbval); free(S.rowvar); free(S.colvar);
-    free(S.posb); free(S.posn); free(S.at_upper); free(enter_list);
     return status;
+}
+
+int qpo_solve_avi(int N, const double *M, const double *q, const double *l, const double *u,
+                  const uint8_t *rowkind, double *z, const qpo_opts *opts_in,
+                  double *resid_out, int *pivots_out, uint8_t *active)
+{
+    void *ws = malloc(avi_ws_bytes(N));
+    int st = solve_avi_ws(N, M, q, l, u, rowkind, z, opts_in, resid_out, pivots_out, active, ws);
+    free(ws);
+    return st;
 }
 
 int qpo_solve_avi_batch(int batch, int N, const double *M, long strideM, const double *q,
@@ -465,19 +497,26 @@ int qpo_solve_avi_batch(int batch, int N, const double *M, long strideM, const d
     int nfail = 0;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) reduction(+ : nfail)
+#pragma omp parallel num_threads(nthreads) reduction(+ : nfail)
 #endif
-    for (int b = 0; b < batch; ++b) {
-        double res; int piv;
-        int st = qpo_solve_avi(N, M + (size_t)b * strideM, q + (size_t)b * N, l + (size_t)b * N,
-                               u + (size_t)b * N,
-                               rowkind ? rowkind + (size_t)b * stride_kind : NULL,
-                               z + (size_t)b * N, opts, &res, &piv,
-                               active ? active + (size_t)b * N : NULL);
-        if (status) status[b] = st;
-        if (resid) resid[b] = res;
-        if (pivots) pivots[b] = piv;
-        if (st != QPO_SUCCESS) nfail++;
+    {
+        void *ws = malloc(avi_ws_bytes(N)); /* one scratch block per thread, reused */
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (int b = 0; b < batch; ++b) {
+            double res; int piv;
+            int st = solve_avi_ws(N, M + (size_t)b * strideM, q + (size_t)b * N, l + (size_t)b * N,
+                                  u + (size_t)b * N,
+                                  rowkind ? rowkind + (size_t)b * stride_kind : NULL,
+                                  z + (size_t)b * N, opts, &res, &piv,
+                                  active ? active + (size_t)b * N : NULL, ws);
+            if (status) status[b] = st;
+            if (resid) resid[b] = res;
+            if (pivots) pivots[b] = piv;
+            if (st != QPO_SUCCESS) nfail++;
+        }
+        free(ws);
     }
     (void)nthreads;
     return nfail;

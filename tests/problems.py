@@ -7,39 +7,13 @@ from __future__ import annotations
 
 import numpy as np
 
+import qpn_amd  # noqa: F401  (import shim)
+
 SEED = 20240422
 INF = np.inf
 
 
-def node_rng(node_id: int, seed: int = SEED):
-    return np.random.Generator(np.random.Philox(key=[seed, node_id]))
-
-
-def shared_params(p: int = 8, seed: int = SEED):
-    return np.random.Generator(np.random.Philox(key=[seed, 2**40])).standard_normal(p)
-
-
-def synth_node(node_id: int, n: int, m: int, p: int = 8, seed: int = SEED):
-    """One strongly convex node record (Qd, R, qd, Ad, B, l, u)."""
-    g = node_rng(node_id, seed)
-    G = g.standard_normal((n, n))
-    Q = G.T @ G / n + 0.1 * np.eye(n)
-    R = 0.1 * g.standard_normal((n, p))
-    qd = g.standard_normal(n)
-    A = g.standard_normal((m, n)) / np.sqrt(n)
-    l = -1.0 - np.abs(g.standard_normal(m))
-    u = 1.0 + np.abs(g.standard_normal(m))
-    B = np.zeros((m, p))
-    return Q, R, qd, A, B, l, u
-
-
-def synth_nodes(first: int, count: int, n: int, m: int, p: int = 8, seed: int = SEED):
-    """Stacked node records for node ids first..first+count-1."""
-    Q = np.empty((count, n, n)); R = np.empty((count, n, p)); qd = np.empty((count, n))
-    A = np.empty((count, m, n)); B = np.zeros((count, m, p)); l = np.empty((count, m)); u = np.empty((count, m))
-    for i in range(count):
-        Q[i], R[i], qd[i], A[i], B[i], l[i], u[i] = synth_node(first + i, n, m, p, seed)
-    return Q, R, qd, A, B, l, u
+from qpn_amd.synthetic import node_rng, shared_params, synth_node, synth_nodes  # noqa: E402,F401
 
 
 def reduced_blocks(Q, R, qd, A, B, l, u, w):

@@ -78,7 +78,8 @@ def _verify_case(engine, oracle, Q, R, qd, A, B, l, u, xd, w, what):
         if sc and m:
             qt = Q[i] @ xd[i] + R[i] @ w + qd[i]
             assert np.linalg.norm(A[i].T @ lam[i] - qt) <= 2e-4       # the accept test of :119 / :138
-            if pc == 2 and np.linalg.matrix_rank(A[i][np.abs(lc) > 0]) == np.sum(np.abs(lc) > 0):
+            nz = np.abs(lc) > 0
+            if pc == 2 and nz.any() and np.linalg.matrix_rank(A[i][nz]) == np.sum(nz):
                 assert np.max(np.abs(lam[i] - lc)) <= 1e-7, f"{what}[{i}]: duals differ"
     return sol, lam, path
 
