@@ -59,8 +59,11 @@ typedef struct {
 int qpn_abi_version(void);
 int qpn_ctx_create(int device_id, qpn_ctx **out);
 int qpn_ctx_destroy(qpn_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+/* Launch on an existing hipStream_t (e.g. torch's current stream).  NULL is HIP's legacy default
+ * (null) stream, NOT "no stream".  A new ctx launches on a private non-blocking stream;
+ * qpn_ctx_use_own_stream returns to it. */
 int qpn_ctx_set_stream(qpn_ctx *ctx, void *hip_stream);
+int qpn_ctx_use_own_stream(qpn_ctx *ctx);
 int qpn_ctx_synchronize(qpn_ctx *ctx);
 const char *qpn_ctx_last_error(qpn_ctx *ctx);
 const char *qpn_strerror(int code);

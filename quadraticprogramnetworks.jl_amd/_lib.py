@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libqpn_hip.so")
 # every symbol include/qpn_hip.h declares
 ABI_SYMBOLS = (
     "qpn_abi_version", "qpn_ctx_create", "qpn_ctx_destroy", "qpn_ctx_set_stream",
+    "qpn_ctx_use_own_stream",
     "qpn_ctx_synchronize", "qpn_ctx_last_error", "qpn_strerror", "qpn_avi_default_opts",
     "qpn_solve_avi_batch", "qpn_solve_mcp_csc", "qpn_check_avi_batch", "qpn_comp_indices",
     "qpn_assemble_nodes", "qpn_verify_nodes",
@@ -51,6 +52,7 @@ def load_library():
     lib.qpn_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.qpn_ctx_destroy.argtypes = [vp]
     lib.qpn_ctx_set_stream.argtypes = [vp, vp]
+    lib.qpn_ctx_use_own_stream.argtypes = [vp]
     lib.qpn_ctx_synchronize.argtypes = [vp]
     lib.qpn_ctx_last_error.argtypes = [vp]
     lib.qpn_ctx_last_error.restype = C.c_char_p

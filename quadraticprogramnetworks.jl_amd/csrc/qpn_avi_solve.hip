@@ -12,6 +12,9 @@
 // with 512-byte coalesced column loads.  Pivot selection (Stage A partial pivoting, Stage B
 // two-pass ratio test) uses wave-wide reductions (__shfl_xor / __ballot); every branch is
 // wave-uniform.  Algorithm: see DESIGN.md section 3 ("pair dictionary, crash, Lemke").
+#include <cstdlib>
+#include <cstring>
+
 #include "qpn_internal.h"
 
 #define QINF __builtin_huge_val()
@@ -394,7 +397,18 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
 
 int qpn_avi_max_n() { return 64; }
 
+// Kernel choice: the register-tableau kernel (qpn_avi_reg.hip) is the production path; the
+// LDS-tableau kernel of this file stays selectable (QPN_AVI_KERNEL=lds1) for A/B measurements.
 hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream)
+{
+    static const int use_lds1 = [] {
+        const char *e = getenv("QPN_AVI_KERNEL");
+        return (e && strcmp(e, "lds1") == 0) ? 1 : 0;
+    }();
+    return use_lds1 ? qpn_launch_avi_solve_lds1(a, stream) : qpn_launch_avi_solve_reg(a, stream);
+}
+
+hipError_t qpn_launch_avi_solve_lds1(const AviBatchArgs &a, hipStream_t stream)
 {
     if (a.batch <= 0) return hipSuccess;
     const LdsLayout L = lds_layout(a.N);

@@ -129,7 +129,14 @@ int qpn_ctx_destroy(qpn_ctx *ctx)
 int qpn_ctx_set_stream(qpn_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return QPN_ERR_ARG;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL = HIP's legacy default stream
+    return QPN_OK;
+}
+
+int qpn_ctx_use_own_stream(qpn_ctx *ctx)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    ctx->stream = ctx->own_stream;
     return QPN_OK;
 }
 

@@ -29,8 +29,12 @@ struct AviBatchArgs {
 };
 
 // qpn_avi_solve.hip
-hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream);
+hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream);      // dispatcher
+hipError_t qpn_launch_avi_solve_lds1(const AviBatchArgs &a, hipStream_t stream); // LDS-tableau kernel
 int qpn_avi_max_n();
+
+// qpn_avi_reg.hip
+hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream);  // register-tableau kernel
 
 // qpn_kkt.hip
 hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,

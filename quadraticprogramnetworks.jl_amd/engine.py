@@ -76,9 +76,13 @@ class Engine:
             raise QpnError(f"{what}: {self.lib.qpn_strerror(rc).decode()} ({msg})")
 
     def _bind_stream(self, dev):
+        # device buffers: launch on torch's current stream so torch ops before/after the call are
+        # ordered with the kernels (cuda_stream == 0 is the legacy default stream, a real stream)
         if dev and self.use_torch_stream:
             s = torch.cuda.current_stream(self.device).cuda_stream
             self.lib.qpn_ctx_set_stream(self.ctx, C.c_void_p(s))
+        elif not dev:
+            self.lib.qpn_ctx_use_own_stream(self.ctx)
 
     def synchronize(self):
         self._chk(self.lib.qpn_ctx_synchronize(self.ctx), "qpn_ctx_synchronize")
