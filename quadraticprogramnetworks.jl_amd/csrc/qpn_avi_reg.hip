@@ -20,6 +20,18 @@ namespace {
 
 constexpr int WAVE = 64;
 
+#ifdef QPN_STAMPS
+#define STAMP(slot)                                                     \
+    do {                                                                \
+        unsigned long long now__ = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        stamp_acc[slot] += now__ - stamp_last;                          \
+        stamp_last = now__;                                             \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 template <int BS> struct Geo {
     static constexpr int NB = 8 * BS;        // padded dimension held in registers
     static constexpr int PB = BS + 2;        // padded block stride (doubles) in the LDS vectors
@@ -60,6 +72,10 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     __shared__ double sl[NB], su[NB], snb[2 * NB + 2];
     __shared__ int sat[NB], elist[8 * NB + 8];
 
+#ifdef QPN_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     const double *Mg = a.M + (size_t)b * (size_t)a.strideM;
     const size_t vo = (size_t)b * (size_t)N;
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
@@ -138,23 +154,28 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         __syncthreads();
     }
 
+    STAMP(0);   // setup + load
     int pivots = 0;
 
-    // copy column c of the dictionary into ucol (LDS) and return this row-lane's entry
-    auto extract_col = [&](int c) -> double {
+    // Dynamic row / column selection without dynamic register indexing.  The selector becomes a
+    // one-hot mask tested bit by bit with wave-uniform branches; the branch bodies are either LDS
+    // stores or `asm volatile` register writes, which hipcc can neither speculate nor turn into
+    // selects, so every body touches statically named registers IN PLACE.  (A `switch`, or plain
+    // C++ assignments, make hipcc compute all BS*BS candidates and select -- hundreds of moves.)
+    auto extract_col = [&](int c_in) -> double {
+        const int c = uni(c_in);
         if (c == XC) {
             if (lane < NB) ucol[G::pidx(lane)] = tcol;
-        } else if (cb == c / BS) {
-            switch (c % BS) {
-#define QPN_CASE(L)                                                          \
-    case L:                                                                  \
-        if (L < BS) {                                                        \
-            _Pragma("unroll") for (int k = 0; k < BS; ++k) ucol[ra * PB + k] = t[k][L < BS ? L : 0]; \
-        }                                                                    \
-        break;
-                QPN_CASE(0) QPN_CASE(1) QPN_CASE(2) QPN_CASE(3)
-                QPN_CASE(4) QPN_CASE(5) QPN_CASE(6) QPN_CASE(7)
-#undef QPN_CASE
+        } else {
+            const unsigned hot = 1u << (c % BS);
+            if (cb == c / BS) {
+#pragma unroll
+                for (int L = 0; L < BS; ++L) {
+                    if (hot & (1u << L)) {
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) ucol[ra * PB + k] = t[k][L];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -163,72 +184,70 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 
     // exchange the entering variable (column c, moved by delta) with the basic variable of row r;
     // cm = this row-lane's entry of column c (ucol still holds the column)
-    auto do_pivot = [&](int r, int c, double delta, double leave_val, double cm) {
+    auto do_pivot = [&](int r_in, int c_in, double delta, double leave_val, double cm) {
+        const int r = uni(r_in), c = uni(c_in);
         xb = fma(delta, cm, xb);
-        const double enter_old = (c == XC) ? cNval : __shfl(nbval, c, WAVE);
+        const double enter_old = (c == XC) ? cNval : readlane_f64(nbval, c);
         const double enter_val = enter_old + delta;
-        const double inv = 1.0 / __shfl(cm, r, WAVE);
-        // scaled pivot row -> vrow; the entry of column c is stored as -inv (row fix-up below)
-        if (ra == r / BS) {
-            switch (r % BS) {
-#define QPN_CASE(K)                                                          \
-    case K:                                                                  \
-        if (K < BS) {                                                        \
-            _Pragma("unroll") for (int l = 0; l < BS; ++l)                   \
-                vrow[cb * PB + l] = (BS * cb + l == c) ? -inv : t[K < BS ? K : 0][l] * inv; \
-        }                                                                    \
-        break;
-                QPN_CASE(0) QPN_CASE(1) QPN_CASE(2) QPN_CASE(3)
-                QPN_CASE(4) QPN_CASE(5) QPN_CASE(6) QPN_CASE(7)
-#undef QPN_CASE
+        const double inv = 1.0 / readlane_f64(cm, r);
+        const unsigned rhot = 1u << (r % BS);
+        const bool rmine = ra == r / BS;
+        const unsigned chot = (c == XC) ? 0u : (1u << (c % BS));
+        const bool cmine = (c != XC) && cb == c / BS;
+        // raw pivot row -> vrow (scaled by the readers)
+        if (rmine) {
+#pragma unroll
+            for (int K = 0; K < BS; ++K) {
+                if (rhot & (1u << K)) {
+#pragma unroll
+                    for (int l = 0; l < BS; ++l) vrow[cb * PB + l] = t[K][l];
+                }
             }
         }
-        if (lane == r) vrow[NP] = (c == XC) ? -inv : tcol * inv;
+        if (lane == r) vrow[NP] = tcol;
         __syncthreads();
         double u[BS], v[BS];
 #pragma unroll
         for (int k = 0; k < BS; ++k) u[k] = ucol[ra * PB + k];
 #pragma unroll
-        for (int l = 0; l < BS; ++l) v[l] = vrow[cb * PB + l];
-        const double vx = vrow[NP];
+        for (int l = 0; l < BS; ++l) {
+            const double raw = vrow[cb * PB + l];
+            // prow_j = T[r][j] * inv; the slot of column c carries -inv (row fix-up below)
+            v[l] = (BS * cb + l == c) ? -inv : raw * inv;
+        }
+        const double vx = (c == XC) ? -inv : vrow[NP] * inv;
 #pragma unroll
         for (int k = 0; k < BS; ++k)
 #pragma unroll
             for (int l = 0; l < BS; ++l) t[k][l] = fma(-u[k], v[l], t[k][l]);
         // column c of the new dictionary: T[i][c] = cm_i * inv
-        if (c != XC && cb == c / BS) {
-            switch (c % BS) {
-#define QPN_CASE(L)                                                          \
-    case L:                                                                  \
-        if (L < BS) {                                                        \
-            _Pragma("unroll") for (int k = 0; k < BS; ++k) t[k][L < BS ? L : 0] = u[k] * inv; \
-        }                                                                    \
-        break;
-                QPN_CASE(0) QPN_CASE(1) QPN_CASE(2) QPN_CASE(3)
-                QPN_CASE(4) QPN_CASE(5) QPN_CASE(6) QPN_CASE(7)
-#undef QPN_CASE
+        if (cmine) {
+#pragma unroll
+            for (int L = 0; L < BS; ++L) {
+                if (chot & (1u << L)) {
+#pragma unroll
+                    for (int k = 0; k < BS; ++k)
+                        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t[k][L]) : "v"(u[k]), "v"(inv));
+                }
             }
         }
         // row r of the new dictionary: T[r][j] = -prow_j, T[r][c] = inv (v holds -inv there)
-        if (ra == r / BS) {
-            switch (r % BS) {
-#define QPN_CASE(K)                                                          \
-    case K:                                                                  \
-        if (K < BS) {                                                        \
-            _Pragma("unroll") for (int l = 0; l < BS; ++l) t[K < BS ? K : 0][l] = -v[l]; \
-        }                                                                    \
-        break;
-                QPN_CASE(0) QPN_CASE(1) QPN_CASE(2) QPN_CASE(3)
-                QPN_CASE(4) QPN_CASE(5) QPN_CASE(6) QPN_CASE(7)
-#undef QPN_CASE
+        if (rmine) {
+#pragma unroll
+            for (int K = 0; K < BS; ++K) {
+                if (rhot & (1u << K)) {
+#pragma unroll
+                    for (int l = 0; l < BS; ++l)
+                        asm volatile("v_mul_f64 %0, %1, -1.0" : "=v"(t[K][l]) : "v"(v[l]));
+                }
             }
         }
         // extra column
         if (c == XC) tcol = (lane == r) ? inv : cm * inv;
         else tcol = (lane == r) ? -vx : fma(-cm, vx, tcol);
         // bookkeeping
-        const int ve = (c == XC) ? cNvar : __shfl(colvar, c, WAVE);
-        const int vl = __shfl(rowvar, r, WAVE);
+        const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
+        const int vl = readlane_i32(rowvar, r);
         if (lane == r) { rowvar = ve; xb = enter_val; }
         if (c == XC) { cNvar = vl; cNval = leave_val; }
         else if (lane == c) { colvar = vl; nbval = leave_val; }
@@ -240,7 +259,10 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         return c;
     };
 
-    // ---- Stage A: crash -----------------------------------------------------------------
+    // ---- one pivot loop for both stages (a single instance of the update code) --------------
+    //   stage 0: crash -- free variables / multipliers of equality GAVI rows enter (Stage A)
+    //   stage 1: build the covering column from the basic infeasibilities
+    //   stage 2: Lemke's complementary pivoting (Stage B)
     int n_enter;
     {
         bool want = act && ((!gk && freek) || (gk && fixedk));
@@ -253,73 +275,26 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     }
     __syncthreads();
     int budget = 4 * N + 4;
-    for (int idx = 0; idx < n_enter && budget > 0; ++idx) {
-        int e = uni(elist[idx]);
-        int c = wave_first(act && colvar == e);
-        if (c < 0) continue;
-        const double cm = extract_col(c);
-        double av = act ? fabs(cm) : 0.0;
-        double colmax = wave_max_f64(av);
-        bool ml = false, ord = false;
-        double tg = 0.0;
-        if (act) {
-            int v = rowvar;
-            if (v < 2 * N) {
-                int k = v < N ? v : v - N;
-                double Lk = sl[k], Uk = su[k];
-                bool fr = Lk == -QINF && Uk == QINF, fx = Lk == Uk;
-                if (v >= N) { if (fr) { ml = true; tg = 0.0; } }
-                else if (fx && !fr) { ml = true; tg = Lk; }
-                ord = !fr && !fx;
-            }
-        }
-        double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
-        double best = wave_max_f64(ml ? av : -1.0);
-        if (best > thresh) {
-            int r = wave_first(ml && av == best);
-            double target = __shfl(tg, r, WAVE);
-            double delta = (target - __shfl(xb, r, WAVE)) / __shfl(cm, r, WAVE);
-            do_pivot(r, c, delta, target, cm);
-            pivots++; budget--;
-            continue;
-        }
-        best = wave_max_f64(ord ? av : -1.0);
-        if (!(best > thresh)) continue;
-        int r = wave_first(ord && av == best);
-        int v = __shfl(rowvar, r, WAVE);
-        double target;
-        if (v < N) {
-            double x = __shfl(xb, r, WAVE), lo = sl[v], hi = su[v];
-            int au;
-            if (x <= lo) { target = lo; au = 0; }
-            else if (x >= hi) { target = hi; au = 1; }
-            else if (lo == -QINF) { target = hi; au = 1; }
-            else if (hi == QINF) { target = lo; au = 0; }
-            else if (hi - x < x - lo) { target = hi; au = 1; }
-            else { target = lo; au = 0; }
-            if (lane == 0) { sat[v] = au; elist[n_enter] = N + v; }
-        } else {
-            target = 0.0;
-            if (lane == 0) elist[n_enter] = v - N;
-        }
-        n_enter++;
-        double delta = (target - __shfl(xb, r, WAVE)) / __shfl(cm, r, WAVE);
-        do_pivot(r, c, delta, target, cm);
-        pivots++; budget--;
-        if (n_enter >= 8 * N) break;
-    }
-
-    // ---- Stage B: Lemke -------------------------------------------------------------------
-    int status;
-    {
-        double lo, hi;
-        var_interval_r(rowvar, N, sl, su, sat, lo, hi);
-        double viol = 0.0;
-        if (act) viol = xb < lo ? lo - xb : (xb > hi ? xb - hi : 0.0);
-        const double theta0 = wave_max_f64(viol);
-        if (theta0 <= a.feas_tol) {
-            status = QPN_SUCCESS;
-        } else {
+    int stage_ = 0, idx = 0;
+    int status = QPN_FAILURE;
+    int c = XC;
+    double sigma = -1.0, self_lim = 0.0;
+    const double slack = 1e-10;
+    const double ptol = a.piv_tol;
+    for (;;) {
+        if (stage_ == 0) {
+            if (!(idx < n_enter && budget > 0)) { stage_ = 1; continue; }
+            const int e = uni(elist[idx]);
+            idx++;
+            c = wave_first(act && colvar == e);
+            if (c < 0) continue;
+        } else if (stage_ == 1) {
+            double lo, hi;
+            var_interval_r(rowvar, N, sl, su, sat, lo, hi);
+            double viol = 0.0;
+            if (act) viol = xb < lo ? lo - xb : (xb > hi ? xb - hi : 0.0);
+            const double theta0 = wave_max_f64(viol);
+            if (theta0 <= a.feas_tol) { status = QPN_SUCCESS; break; }
             if (act) {
                 double cov = 0.0;
                 if (xb < lo) {
@@ -334,82 +309,145 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                 tcol = cov;
             }
             cNval = theta0;
-            int c = XC;
-            double sigma = -1.0, self_lim = theta0;
+            c = XC; sigma = -1.0; self_lim = theta0;
             status = QPN_MAX_ITERS;
-            const double slack = 1e-10;
-            const double ptol = a.piv_tol;
-            while (pivots < max_piv) {
-                var_interval_r(rowvar, N, sl, su, sat, lo, hi);
-                const double cm = extract_col(c);
-                const double g = act ? sigma * cm : 0.0;
-                double d1 = QINF;
-                bool cnd = false;
-                double d = 0.0, lv = 0.0;
-                if (act) {
-                    if (g < -ptol && lo > -QINF) { d1 = (xb - lo + slack) / (-g); d = (xb - lo) / (-g); lv = lo; cnd = true; }
-                    else if (g > ptol && hi < QINF) { d1 = (hi - xb + slack) / g; d = (hi - xb) / g; lv = hi; cnd = true; }
+            stage_ = 2;
+            continue;
+        } else {
+            if (pivots >= max_piv) break;
+        }
+
+        STAMP(1);   // loop control / stage setup
+        const double cm = extract_col(c);
+        STAMP(2);   // column extraction
+        int r;
+        double delta, leave_val;
+        if (stage_ == 0) {
+            const double av = act ? fabs(cm) : 0.0;
+            const double colmax = wave_max_f64(av);
+            bool ml = false, ord = false;
+            double tg = 0.0;
+            if (act) {
+                const int v = rowvar;
+                if (v < 2 * N) {
+                    const int k = v < N ? v : v - N;
+                    const double Lk = sl[k], Uk = su[k];
+                    const bool fr = Lk == -QINF && Uk == QINF, fx = Lk == Uk;
+                    if (v >= N) { if (fr) { ml = true; tg = 0.0; } }
+                    else if (fx && !fr) { ml = true; tg = Lk; }
+                    ord = !fr && !fx;
                 }
-                double dmax = wave_min_f64(d1);
-                if (self_lim < dmax) dmax = self_lim;
-                if (dmax == QINF) { status = QPN_RAY_TERM; break; }
-                if (cnd && d > dmax) cnd = false;
-                double ag = cnd ? fabs(g) : -1.0;
-                if (cnd && rowvar == 2 * N) ag = QINF;
-                double bestg = wave_max_f64(ag);
-                if (bestg < 0.0) {
-                    double delta = sigma * self_lim;
-                    if (act) xb = fma(delta, cm, xb);
-                    int ve = (c == XC) ? cNvar : __shfl(colvar, c, WAVE);
-                    if (ve == 2 * N) {
-                        if (c == XC) cNval = 0.0; else if (lane == c) nbval = 0.0;
-                        status = QPN_SUCCESS; break;
-                    }
-                    int k = ve;
-                    int au = sigma > 0.0 ? 1 : 0;
-                    double nv = au ? su[k] : sl[k];
-                    if (lane == 0) sat[k] = au;
-                    if (c == XC) cNval = nv; else if (lane == c) nbval = nv;
-                    pivots++;
-                    c = col_of(N + k);
-                    if (c < 0) { status = QPN_FAILURE; break; }
-                    sigma = au ? -1.0 : 1.0;
-                    self_lim = QINF;
-                    __syncthreads();
-                    continue;
-                }
-                int r = wave_first(cnd && ag == bestg);
-                double step = __shfl(d, r, WAVE);
-                if (step < 0.0) step = 0.0;
-                double leave_val = __shfl(lv, r, WAVE);
-                int vl = __shfl(rowvar, r, WAVE);
-                do_pivot(r, c, sigma * step, leave_val, cm);
-                pivots++;
-                if (vl == 2 * N) { status = QPN_SUCCESS; break; }
-                int vn;
-                if (vl < N) {
-                    int k = vl;
-                    double Lk = sl[k], Uk = su[k];
-                    int au = sat[k];
-                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; if (lane == 0) sat[k] = au; }
-                    vn = N + k;
-                    sigma = au ? -1.0 : 1.0;
-                    self_lim = QINF;
-                } else {
-                    int k = vl - N;
-                    double Lk = sl[k], Uk = su[k];
-                    vn = k;
-                    sigma = sat[k] ? -1.0 : 1.0;
-                    self_lim = Uk - Lk;
-                    if (Lk == -QINF && Uk == QINF) { self_lim = QINF; sigma = 1.0; }
-                }
-                c = col_of(vn);
-                if (c < 0) { status = QPN_FAILURE; break; }
-                __syncthreads();
             }
+            const double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
+            double best = wave_max_f64(ml ? av : -1.0);
+            if (best > thresh) {
+                r = wave_first(ml && av == best);
+                leave_val = readlane_f64(tg, r);
+            } else {
+                // no equation row can take it: 2x2 principal block pivot through an ordinary pair
+                best = wave_max_f64(ord ? av : -1.0);
+                if (!(best > thresh)) continue;
+                r = wave_first(ord && av == best);
+                const int v = readlane_i32(rowvar, r);
+                if (v < N) {
+                    const double x = readlane_f64(xb, r), lo = sl[v], hi = su[v];
+                    int au;
+                    if (x <= lo) { leave_val = lo; au = 0; }
+                    else if (x >= hi) { leave_val = hi; au = 1; }
+                    else if (lo == -QINF) { leave_val = hi; au = 1; }
+                    else if (hi == QINF) { leave_val = lo; au = 0; }
+                    else if (hi - x < x - lo) { leave_val = hi; au = 1; }
+                    else { leave_val = lo; au = 0; }
+                    if (lane == 0) { sat[v] = au; elist[n_enter] = N + v; }
+                } else {
+                    leave_val = 0.0;
+                    if (lane == 0) elist[n_enter] = v - N;
+                }
+                n_enter++;
+            }
+            delta = (leave_val - readlane_f64(xb, r)) / readlane_f64(cm, r);
+        } else {
+            double lo, hi;
+            var_interval_r(rowvar, N, sl, su, sat, lo, hi);
+            const double g = act ? sigma * cm : 0.0;
+            double d1 = QINF;
+            bool cnd = false;
+            double d = 0.0, lv = 0.0;
+            if (act) {
+                if (g < -ptol && lo > -QINF) { d1 = (xb - lo + slack) / (-g); d = (xb - lo) / (-g); lv = lo; cnd = true; }
+                else if (g > ptol && hi < QINF) { d1 = (hi - xb + slack) / g; d = (hi - xb) / g; lv = hi; cnd = true; }
+            }
+            double dmax = wave_min_f64(d1);
+            if (self_lim < dmax) dmax = self_lim;
+            if (dmax == QINF) { status = QPN_RAY_TERM; break; }
+            if (cnd && d > dmax) cnd = false;
+            double ag = cnd ? fabs(g) : -1.0;
+            if (cnd && rowvar == 2 * N) ag = QINF;
+            const double bestg = wave_max_f64(ag);
+            if (bestg < 0.0) {
+                // the entering variable reaches its own far bound first
+                const double dl = sigma * self_lim;
+                if (act) xb = fma(dl, cm, xb);
+                const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
+                if (ve == 2 * N) {
+                    if (c == XC) cNval = 0.0; else if (lane == c) nbval = 0.0;
+                    status = QPN_SUCCESS; break;
+                }
+                const int k = ve;
+                const int au = sigma > 0.0 ? 1 : 0;
+                const double nv = au ? su[k] : sl[k];
+                if (lane == 0) sat[k] = au;
+                if (c == XC) cNval = nv; else if (lane == c) nbval = nv;
+                pivots++;
+                c = col_of(N + k);
+                if (c < 0) { status = QPN_FAILURE; break; }
+                sigma = au ? -1.0 : 1.0;
+                self_lim = QINF;
+                __syncthreads();
+                continue;
+            }
+            r = wave_first(cnd && ag == bestg);
+            double step = readlane_f64(d, r);
+            if (step < 0.0) step = 0.0;
+            leave_val = readlane_f64(lv, r);
+            delta = sigma * step;
+        }
+
+        const int vl = readlane_i32(rowvar, r);
+        STAMP(3);   // pivot selection (ratio tests, reductions)
+        do_pivot(r, c, delta, leave_val, cm);
+        STAMP(4);   // rank-1 update
+        pivots++;
+
+        if (stage_ == 0) {
+            budget--;
+            if (n_enter >= 8 * N) stage_ = 1;
+        } else {
+            if (vl == 2 * N) { status = QPN_SUCCESS; break; }
+            int vn;
+            if (vl < N) {
+                const int k = vl;
+                const double Lk = sl[k], Uk = su[k];
+                int au = sat[k];
+                if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; if (lane == 0) sat[k] = au; }
+                vn = N + k;
+                sigma = au ? -1.0 : 1.0;
+                self_lim = QINF;
+            } else {
+                const int k = vl - N;
+                const double Lk = sl[k], Uk = su[k];
+                vn = k;
+                sigma = sat[k] ? -1.0 : 1.0;
+                self_lim = Uk - Lk;
+                if (Lk == -QINF && Uk == QINF) { self_lim = QINF; sigma = 1.0; }
+            }
+            c = col_of(vn);
+            if (c < 0) { status = QPN_FAILURE; break; }
+            __syncthreads();
         }
     }
 
+    STAMP(1);
     // ---- read the point back ----------------------------------------------------------------
     __syncthreads();
     if (act) { snb[rowvar] = xb; snb[colvar] = nbval; }
@@ -465,6 +503,11 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         if (a.resid) a.resid[b] = nres;
         if (a.pivots) a.pivots[b] = pivots;
     }
+    STAMP(5);   // read-back + post-check + stores
+#ifdef QPN_STAMPS
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[(size_t)b * 8 + i] = stamp_acc[i];
+#endif
 }
 
 } // namespace

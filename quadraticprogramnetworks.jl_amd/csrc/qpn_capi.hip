@@ -150,6 +150,12 @@ int qpn_ctx_synchronize(qpn_ctx *ctx)
 
 const char *qpn_ctx_last_error(qpn_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
+#ifdef QPN_STAMPS
+// diagnostic builds only: where the next device-path solve writes its [batch][8] cycle sums
+static unsigned long long *g_stamps = nullptr;
+int qpn_debug_set_stamps(void *p) { g_stamps = static_cast<unsigned long long *>(p); return 0; }
+#endif
+
 // -------------------------------------------------------------------------------------------
 int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, int64_t strideM,
                         const double *q, const double *l, const double *u, const uint8_t *kind,
@@ -175,6 +181,9 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
     if (mem == QPN_MEM_DEVICE) {
         a.M = M; a.q = q; a.l = l; a.u = u; a.kind = kind; a.z = z; a.status = status;
         a.resid = resid; a.pivots = pivots; a.active = active;
+#ifdef QPN_STAMPS
+        a.stamps = g_stamps;
+#endif
         HIPCHK(ctx, qpn_launch_avi_solve(a, ctx->stream));
         return QPN_OK;
     }

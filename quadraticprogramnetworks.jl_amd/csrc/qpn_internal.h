@@ -26,6 +26,8 @@ struct AviBatchArgs {
     // optional gate: item b runs only when only_if[b] == only_if_value (others are left untouched)
     const int32_t *only_if;
     int32_t only_if_value;
+    // diagnostic builds only (-DQPN_STAMPS): per-item cycle sums per phase, [batch][8] uint64
+    unsigned long long *stamps;
 };
 
 // qpn_avi_solve.hip
@@ -60,23 +62,49 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
 
 // ---- wave64 helpers (CDNA4: one wavefront = 64 lanes) --------------------------------
 #ifdef __HIPCC__
+// ---- DPP / readlane based wave64 primitives (no LDS round trips) -------------------------
+// dpp_ctrl encodings (GFX9): quad_perm = 0x00..0xFF, row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// value of `v` in lane `l`; l must be wave-uniform (it is turned into an SGPR)
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    l = __builtin_amdgcn_readfirstlane(l);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int readlane_i32(int v, int l)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
+}
+#define QPN_ROW_REDUCE(v, OP)                                  \
+    do {                                                       \
+        double o__;                                            \
+        o__ = dpp_f64<0xB1>(v); v = OP(v, o__); /* quad_perm [1,0,3,2] */ \
+        o__ = dpp_f64<0x4E>(v); v = OP(v, o__); /* quad_perm [2,3,0,1] */ \
+        o__ = dpp_f64<0x141>(v); v = OP(v, o__); /* row_half_mirror */    \
+        o__ = dpp_f64<0x140>(v); v = OP(v, o__); /* row_mirror      */    \
+    } while (0)
+__device__ __forceinline__ double qpn_max2(double a, double b) { return fmax(a, b); }  // v_max_f64
+__device__ __forceinline__ double qpn_min2(double a, double b) { return fmin(a, b); }  // v_min_f64
+// NaN-free inputs assumed by callers (they feed -1 / +inf sentinels for inactive lanes)
 __device__ __forceinline__ double wave_max_f64(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    QPN_ROW_REDUCE(v, qpn_max2);
+    double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return qpn_max2(qpn_max2(r0, r1), qpn_max2(r2, r3));
 }
 __device__ __forceinline__ double wave_min_f64(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
+    QPN_ROW_REDUCE(v, qpn_min2);
+    double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return qpn_min2(qpn_min2(r0, r1), qpn_min2(r2, r3));
 }
 __device__ __forceinline__ double wave_sum_f64(double v)
 {

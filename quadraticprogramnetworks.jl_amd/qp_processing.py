@@ -1,0 +1,99 @@
+"""Host-side mirror of src/qp_processing.jl for the hot path: verify_solution (:57-149),
+solve_qp(...; solver=:PATH) (:12-33) and the batch boundary process_qp (:151-241).  The
+arithmetic runs on the GPU (qpn_verify_nodes / qpn_solve_avi_batch)."""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .avi import StatusCode, _eng
+from .avi_solutions import local_pieces_strict
+from .engine import colmajor
+from .programs import Poly
+
+INF = np.inf
+
+
+def node_record(qp, constraints: List[Poly], dec_inds, x):
+    """Dense per-node record (Qd, R, qd, Ad, B, l, u, xd, w) of the C-ABI from a QP, its stacked
+    constraint rows (src/qp_processing.jl:62-66) and the current point."""
+    n_tot = len(x)
+    dec = list(dec_inds)
+    par = [i for i in range(n_tot) if i not in set(dec)]
+    Q = qp.f.Q
+    if constraints:
+        A = np.vstack([c.vectorize()[0] for c in constraints])
+        l = np.concatenate([c.vectorize()[1] for c in constraints])
+        u = np.concatenate([c.vectorize()[2] for c in constraints])
+    else:
+        A = np.zeros((0, n_tot)); l = np.zeros(0); u = np.zeros(0)
+    return dict(Qd=Q[np.ix_(dec, dec)], R=Q[np.ix_(dec, par)], qd=qp.f.q[dec], Ad=A[:, dec], B=A[:, par],
+                l=l, u=u, xd=np.asarray(x)[dec], w=np.asarray(x)[par], A=A)
+
+
+def verify_solution(qp, pid, constraints: List[Poly], dec_inds, x, check_convexity=False, tol=1e-4,
+                    engine=None):
+    """src/qp_processing.jl:57-149 -> dict(solution, lam, e, path)."""
+    rec = node_record(qp, constraints, dec_inds, x)
+    m = len(rec["l"])
+    sol, lam, path = _eng(engine).verify_nodes(colmajor(rec["Qd"])[None], colmajor(rec["R"])[None], rec["qd"][None],
+                                               colmajor(rec["Ad"])[None], colmajor(rec["B"])[None],
+                                               rec["l"][None], rec["u"][None], rec["xd"][None], rec["w"], tol=tol)
+    path = int(path[0])
+    msgs = {0: f"Current point is infeasible when using tolerance {tol}.", 1: "Current point is suboptimal",
+            4: "Current point is suboptimal (via QP).", 5: "Solving for duals failed."}
+    ok = bool(sol[0])
+    return dict(solution=ok, lam=(np.asarray(lam[0])[:m].copy() if path in (1, 2, 3, 4) else None),
+                e=None if ok else msgs.get(path, ""), path=path)
+
+
+def solve_qp(Q, q, A, l, u, solver="PATH", engine=None):
+    """src/qp_processing.jl:12-33 (PATH branch): min 1/2 x'Qx + q'x  s.t. l <= Ax <= u, as the box-MCP
+    [Q -A' 0; A 0 -I; 0 I 0] of :16-21 -- sent to the engine in its reduced GAVI-row form."""
+    if solver != "PATH":
+        raise ValueError("Solver not supported")        # the OSQP branch (:2-11) is out of scope
+    Q = np.asarray(Q, dtype=np.float64); A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+    n, m = Q.shape[0], A.shape[0]
+    M = np.block([[Q, -A.T], [A, np.zeros((m, m))]])
+    qq = np.concatenate([q, np.zeros(m)])
+    lo = np.concatenate([np.full(n, -INF), l]); hi = np.concatenate([np.full(n, INF), u])
+    kind = np.concatenate([np.zeros(n, np.uint8), np.ones(m, np.uint8)])
+    res = _eng(engine).solve_avi_batch(colmajor(M), qq[None], lo[None], hi[None], kind=kind)
+    if int(res["status"][0]) != StatusCode.SUCCESS:
+        raise RuntimeError(f"Solver failure. Status value is {int(res['status'][0])}")     # :30
+    return np.asarray(res["z"][0])[:n]
+
+
+def process_qp(qpn, pid: int, x, S: Dict[int, list], engine=None, exploration_vertices=0):
+    """src/qp_processing.jl:151-241.  S maps child id -> list of Poly pieces.  For every combination
+    of the children's pieces (:162-169) the node is verified (:187); solution-graph generation
+    (:193-198, :231) is done for strictly convex nodes by local_pieces_strict and is otherwise
+    out of scope (polyhedral)."""
+    qp = qpn.qps[pid]
+    base = [qpn.constraints[c].poly for c in qp.constraint_indices]
+    dec_inds = qpn.decision_inds(pid)
+    gen = (pid not in qpn.network_depth_map[1]) or qpn.options.gen_solution_map
+    children = sorted(qpn.network_edges[pid])
+    if children:
+        cards = [range(len(S[j])) for j in children]
+        if any(len(c) < 1 for c in cards):
+            raise RuntimeError("Solution graphs were not properly populated.")
+        for combo in itertools.product(*cards):
+            cons = base + [S[j][ji] for j, ji in zip(children, combo)]
+            ret = verify_solution(qp, pid, cons, dec_inds, x, engine=engine)
+            if not ret["solution"]:
+                return dict(solution=False, e=ret["e"], failed=False,
+                            subpiece_assignments={j: ji for j, ji in zip(children, combo)})
+        return dict(solution=True, S=None, failed=False)     # combine(): polyhedral, out of scope
+    ret = verify_solution(qp, pid, base, dec_inds, x, engine=engine)
+    if not ret["solution"]:
+        return dict(solution=False, e=ret["e"], failed=False, subpiece_assignments={})
+    S_out = None
+    if gen:
+        rec = node_record(qp, base, dec_inds, x)
+        S_out = local_pieces_strict(qp.f.Q, qp.f.q, rec["A"], rec["l"], rec["u"], dec_inds, np.asarray(x), ret["lam"])
+        if len(S_out) == 0:
+            raise RuntimeError("This shouldn't happen. Solution graph is empty.")
+    return dict(solution=True, S=S_out, failed=False)

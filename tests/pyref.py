@@ -44,7 +44,15 @@ def solve_newton(M, q, l, u, kind=None, z0=None, iters=200, tol=1e-11):
             dz = np.linalg.solve(J, rhs)
         except np.linalg.LinAlgError:
             dz = np.linalg.lstsq(J, rhs, rcond=None)[0]
-        z = z + dz
+        # backtracking on ||phi||_inf (plain primal-dual active-set steps can cycle)
+        t = 1.0
+        f0 = np.max(np.abs(phi))
+        while t > 1e-4:
+            f1 = np.max(np.abs(natural_map(M, q, l, u, kind, z + t * dz)[0]))
+            if f1 < (1 - 1e-4 * t) * f0:
+                break
+            t *= 0.5
+        z = z + t * dz
     phi, _, _ = natural_map(M, q, l, u, kind, z)
     return z, float(np.max(np.abs(phi)))
 

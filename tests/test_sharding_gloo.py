@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Each rank owns a contiguous node range, solves its own
+node-AVIs (oracle test double as the arithmetic), and the primal iterate is reassembled with the
+same all-gather the GPU path issues over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, n, m, ragged, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import qpn_amd  # noqa: F401
+    from qpn_amd import sharding, synthetic
+    from oracle_engine import OracleEngine
+    import problems as P
+    eng = OracleEngine()
+    lo, hi = sharding.node_range(total, world, rank)
+    Q, R, qd, A, B, l, u = synthetic.synth_nodes(lo, hi - lo, n, m)
+    w = synthetic.shared_params()
+    M, q, lo_, hi_, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+    res = eng.solve_avi_batch(np.swapaxes(M, 1, 2), q, lo_, hi_, kind=kind)
+    xloc = torch.tensor(res["z"][:, :n])
+    x_all = torch.zeros((total, n), dtype=torch.float64)
+    ranges = [sharding.node_range(total, world, r) for r in range(world)]
+    sharding.all_gather_primal(x_all, xloc, ranges, dist)
+    nfail, maxres = sharding.all_reduce_status(int((res["status"] != 1).sum()), float(res["resid"].max()), "cpu", dist)
+    if rank == 0:
+        np.save(out, x_all.numpy())
+        assert nfail == 0 and maxres <= 1e-8
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,ragged", [(12, False), (13, True)])
+def test_two_rank_sweep_equals_single_process(tmp_path, total, ragged):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import qpn_amd  # noqa: F401
+    from qpn_amd import sharding, synthetic
+    from oracle import binding as ob
+    import problems as P
+    n, m = 5, 6
+    out = str(tmp_path / "x.npy")
+    mp.spawn(_worker, args=(2, _free_port(), total, n, m, ragged, out), nprocs=2, join=True)
+    x2 = np.load(out)
+    Q, R, qd, A, B, l, u = synthetic.synth_nodes(0, total, n, m)
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, synthetic.shared_params())
+    x1 = ob.solve_avi_batch(M, q, lo, hi, kind=kind)["z"][:, :n]
+    assert np.array_equal(x1, x2)
+    assert [sharding.node_range(13, 2, r) for r in range(2)] == [(0, 7), (7, 13)]
+    assert [sharding.node_range(10000, 8, r)[1] - sharding.node_range(10000, 8, r)[0] for r in range(8)] == [1250] * 8

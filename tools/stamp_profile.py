@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic only: per-phase cycle shares of the register-tableau AVI kernel.
+
+Builds a SEPARATE library with -DQPN_STAMPS (in-kernel s_memtime stamps; never the product
+build, never a timed number -- read the SHARES), runs the config-4 batch once, prints the
+mean cycles per phase per solve."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc")
+out = "/tmp/libqpn_hip_stamps.so"
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQPN_STAMPS",
+                       "-o", out] + [os.path.join(csrc, f) for f in
+                       ("qpn_capi.hip", "qpn_avi_solve.hip", "qpn_avi_reg.hip", "qpn_kkt.hip", "qpn_verify.hip")])
+import numpy as np, torch
+import qpn_amd
+from qpn_amd import _lib, synthetic
+from qpn_amd.engine import colmajor
+_lib.LIB_PATH = out
+_lib._lib = None
+eng = qpn_amd.Engine(0)
+cnt, n, m = int(os.environ.get("CNT", "10000")), 32, 32
+Q, R, qd, A, B, l, u = synthetic.synth_nodes(0, cnt, n, m)
+w = synthetic.shared_params()
+t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+Mc, q, lo, hi, kind = eng.assemble_nodes(t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(w))
+st = torch.zeros((cnt, 8), dtype=torch.int64, device="cuda:0")
+eng.lib.qpn_debug_set_stamps(C.c_void_p(st.data_ptr()))
+for _ in range(2):
+    res = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind)
+torch.cuda.synchronize()
+s = st.cpu().numpy().astype(np.float64)
+piv = res["pivots"].cpu().numpy().mean()
+names = ["setup+load", "loop control", "extract column", "pivot selection", "rank-1 update", "readback+check"]
+tot = s.sum(axis=1).mean()
+print(f"mean pivots {piv:.1f}, mean cycles per solve {tot:.0f} ({tot/piv:.0f} per pivot)")
+for i, nm in enumerate(names):
+    print(f"  {nm:18s} {s[:, i].mean():10.0f} cycles  {100*s[:, i].mean()/tot:5.1f} %")
