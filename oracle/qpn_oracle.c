@@ -302,8 +302,15 @@ static int solve_avi_ws(int N, const double *M, const double *q, const double *l
             if (is_must_leave(&S, S.rowvar[i], &tg) && a > best) { best = a; r = i; target = tg; }
         }
         double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
+        /* diagonal first (threshold pivoting, u = 0.01): a free variable takes its own equation
+         * row when that pivot is not small against the column -- no search, no growth for the
+         * (semi)definite blocks QP nodes produce; otherwise the largest admissible row. */
+        if (e < N && S.rowvar[e] == N + e) {
+            double ad = fabs(S.T[(size_t)e * NC + c]);
+            if (ad > thresh && ad >= 0.01 * colmax) { r = e; best = ad; target = 0.0; }
+        }
         if (r >= 0 && best > thresh) {
-            double delta = (target - S.xb[r]) / S.T[(size_t)r * NC + c];
+            double delta = (target - S.xb[r]) * (1.0 / S.T[(size_t)r * NC + c]);
             do_pivot(&S, r, c, delta, target);
             pivots++; stageA_budget--;
             continue;
@@ -334,7 +341,7 @@ static int solve_avi_ws(int N, const double *M, const double *q, const double *l
             target = 0.0;
             enter_list[n_enter++] = v - N;
         }
-        double delta = (target - S.xb[r]) / S.T[(size_t)r * NC + c];
+        double delta = (target - S.xb[r]) * (1.0 / S.T[(size_t)r * NC + c]);
         do_pivot(&S, r, c, delta, target);
         pivots++; stageA_budget--;
         if (n_enter >= 8 * N) break;
@@ -381,8 +388,8 @@ static int solve_avi_ws(int N, const double *M, const double *q, const double *l
                 double g = sigma * S.T[(size_t)i * NC + c];
                 double lo, hi; var_interval(&S, S.rowvar[i], &lo, &hi);
                 double d;
-                if (g < -S.piv_tol && lo > -QINF) d = (S.xb[i] - lo + slack) / (-g);
-                else if (g > S.piv_tol && hi < QINF) d = (hi - S.xb[i] + slack) / g;
+                if (g < -S.piv_tol && lo > -QINF) { double rc = 1.0 / g; d = (S.xb[i] - lo) * (-rc) + slack * (-rc); }
+                else if (g > S.piv_tol && hi < QINF) { double rc = 1.0 / g; d = (hi - S.xb[i]) * rc + slack * rc; }
                 else continue;
                 if (d < dmax) dmax = d;
             }
@@ -393,8 +400,8 @@ static int solve_avi_ws(int N, const double *M, const double *q, const double *l
                 double g = sigma * S.T[(size_t)i * NC + c];
                 double lo, hi; var_interval(&S, S.rowvar[i], &lo, &hi);
                 double d, lv;
-                if (g < -S.piv_tol && lo > -QINF) { d = (S.xb[i] - lo) / (-g); lv = lo; }
-                else if (g > S.piv_tol && hi < QINF) { d = (hi - S.xb[i]) / g; lv = hi; }
+                if (g < -S.piv_tol && lo > -QINF) { d = (S.xb[i] - lo) * (-(1.0 / g)); lv = lo; }
+                else if (g > S.piv_tol && hi < QINF) { d = (hi - S.xb[i]) * (1.0 / g); lv = hi; }
                 else continue;
                 if (d > dmax) continue;
                 double ag = fabs(g);

@@ -1,17 +1,22 @@
 // qpn_avi_reg.hip -- register-resident batched box-MCP / GAVI pivotal solver for gfx950 (CDNA4).
 //
-// Same algorithm and the same arithmetic (bit for bit) as qpn_avi_solve.hip / the CPU oracle;
-// different machine mapping.  ONE 64-lane wavefront per AVI; the 64 lanes form an 8 x 8 grid and
-// lane (ra, cb) keeps the BS x BS block  T[BS*ra .. , BS*cb ..]  of the dictionary in VGPRs
-// (BS = 8 for N <= 64: 128 VGPRs).  A pivot is a rank-1 update  T -= u v'  in which every lane
-// needs only BS entries of u (pivot column) and BS entries of v (scaled pivot row): both
-// vectors go through two tiny padded LDS arrays (conflict-free ds_read_b128), so a pivot costs
-// BS*BS v_fma_f64 per lane and ~16 LDS instructions instead of streaming the whole tableau
-// through LDS.  Dynamic row/column selection never indexes registers dynamically: the pivot
-// column / row are copied out by the 8 lanes that own them inside a wave-uniform switch.
-// Row- and column-vectors (basic values, covering column, bookkeeping) live one element per lane.
-// HBM traffic: the stacked M block is read with coalesced 512-byte column loads, staged BS
-// columns at a time through LDS; the post-check (src/avi.jl:71-76) re-reads it (L2/MALL).
+// Replaces PATHSolver.solve_mcp as called at src/avi.jl:64-70 / src/qp_processing.jl:22-27 (+ the
+// post-check of src/avi.jl:71-76, :148-156 and comp_indices, src/avi_solutions.jl:511-562) for
+// batches of independent node-AVIs, N <= 64.  Same algorithm and the same arithmetic, bit for
+// bit, as the CPU checker used by the tests -- see DESIGN.md section 3.
+//
+// Machine mapping.  ONE 64-lane wavefront per AVI.  The lanes form an 8 x 8 grid; lane (ra, cb)
+// keeps the BS x BS block T[BS*ra.., BS*cb..] of the dictionary in VGPRs (BS = 8 for N <= 64:
+// 128 VGPRs, 2 waves/SIMD).  A pivot is the rank-1 update T -= u v': a lane needs only BS entries
+// of u (pivot column) and BS of v (scaled pivot row), fetched from two padded LDS vectors with
+// conflict-free ds_read_b128 -- BS*BS v_fma_f64 and ~16 LDS instructions per lane per pivot.
+// Row/column vectors (basic values, covering column, cached admissible intervals, bookkeeping)
+// live one element per lane.  All control is wave-uniform: pivot row/column ids are SGPRs
+// (ballot/ffs, v_readlane), reductions run on DPP row operations + v_readlane (no LDS round trips),
+// and the dynamically selected pivot row/column are read/written IN PLACE by the 8 owner lanes
+// behind a scalar binary dispatch on the block-local index (no dynamic VGPR indexing, no copies).
+// HBM: the stacked M block is read with coalesced 512-byte column loads, BS columns at a time,
+// transposed through a 5 KB LDS stage; the post-check re-reads it (served by L2 / Infinity Cache).
 #include "qpn_internal.h"
 
 #define QINF __builtin_huge_val()
@@ -39,17 +44,41 @@ template <int BS> struct Geo {
     __device__ static __forceinline__ int pidx(int i) { return (i / BS) * PB + (i % BS); }
 };
 
-__device__ __forceinline__ void var_interval_r(int v, int N, const double *sl, const double *su,
-                                               const int *sat, double &lo, double &hi)
+// Scalar binary dispatch on a wave-uniform block-local index sel in [0, 8): three s_cmp/s_cbranch
+// levels, each leaf names its registers statically.  (Written as a macro: lambdas capturing the
+// register block by reference make hipcc keep the block in scratch.)
+#define QPN_DISPATCH8(sel, LEAF)                                                               \
+    do {                                                                                       \
+        if ((sel) < 4) {                                                                       \
+            if ((sel) < 2) { if ((sel) < 1) { LEAF(0) } else { LEAF(1) } }                     \
+            else { if ((sel) < 3) { LEAF(2) } else { LEAF(3) } }                               \
+        } else {                                                                               \
+            if ((sel) < 6) { if ((sel) < 5) { LEAF(4) } else { LEAF(5) } }                     \
+            else { if ((sel) < 7) { LEAF(6) } else { LEAF(7) } }                               \
+        }                                                                                      \
+    } while (0)
+
+// The BS x BS register block is 64 individually named scalars (E(k,l)), never an array: any
+// array form (even fully unrolled) ends up address-taken somewhere and hipcc parks it in scratch.
+#define E(k, l) t_##k##_##l
+#define QPN_FOR_L(M, k) M(k, 0) M(k, 1) M(k, 2) M(k, 3) M(k, 4) M(k, 5) M(k, 6) M(k, 7)
+#define QPN_FOR_K(M, l) M(0, l) M(1, l) M(2, l) M(3, l) M(4, l) M(5, l) M(6, l) M(7, l)
+#define QPN_FOR_KL(M)                                                                          \
+    QPN_FOR_L(M, 0) QPN_FOR_L(M, 1) QPN_FOR_L(M, 2) QPN_FOR_L(M, 3)                            \
+    QPN_FOR_L(M, 4) QPN_FOR_L(M, 5) QPN_FOR_L(M, 6) QPN_FOR_L(M, 7)
+#define QPN_FOR_1(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+
+// admissible interval of variable v (wave-uniform id) while it is basic
+__device__ __forceinline__ void interval_uni(int v, int N, const double *sl, const double *su,
+                                             const int *sat, double &lo, double &hi)
 {
-    if (v < 0) { lo = -QINF; hi = QINF; return; }
     if (v == 2 * N) { lo = 0.0; hi = QINF; return; }
-    if (v < N) { lo = sl[v]; hi = su[v]; return; }
-    int k = v - N;
-    double L = sl[k], U = su[k];
+    if (v < N) { lo = udbl(sl[v]); hi = udbl(su[v]); return; }
+    const int k = v - N;
+    const double L = udbl(sl[k]), U = udbl(su[k]);
     if (L == U) { lo = -QINF; hi = QINF; }
     else if (L == -QINF && U == QINF) { lo = 0.0; hi = 0.0; }
-    else if (sat[k]) { lo = -QINF; hi = 0.0; }
+    else if (uni(sat[k])) { lo = -QINF; hi = 0.0; }
     else { lo = 0.0; hi = QINF; }
 }
 
@@ -81,14 +110,21 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
 
     // ---- pair k = lane ----------------------------------------------------------------
-    const double lk = act ? a.l[vo + lane] : 0.0;
-    const double uk = act ? a.u[vo + lane] : 0.0;
-    const int gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + lane] : 0;
-    const bool freek = act && lk == -QINF && uk == QINF;
-    const bool fixedk = act && lk == uk;
+    int gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + lane] : 0;
+    bool freek, fixedk;
     int atup0 = 0;
     double v0 = 0.0;
     int rowvar = -1, colvar = -1;
+    double lo = -QINF, hi = QINF;   // admissible interval of this row's basic variable (kept current)
+    int cNvar = 2 * N;
+    double cNval = 0.0;
+    double tcol = 0.0;                      // extra column, one entry per row-lane
+    double xb = act ? a.q[vo + lane] : 0.0;
+    {
+    const double lk = act ? a.l[vo + lane] : 0.0;
+    const double uk = act ? a.u[vo + lane] : 0.0;
+    freek = act && lk == -QINF && uk == QINF;
+    fixedk = act && lk == uk;
     if (act) {
         if (gk) { colvar = N + lane; rowvar = lane; }
         else {
@@ -108,19 +144,21 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         }
         sl[lane] = lk; su[lane] = uk; sat[lane] = atup0; snb[lane] = v0;
     }
+    if (act) {
+        if (gk) { lo = lk; hi = uk; }                       // p_k = (Mz+q)_k basic
+        else if (fixedk) { lo = -QINF; hi = QINF; }         // d_k of a fixed pair: free
+        else if (freek) { lo = 0.0; hi = 0.0; }             // equation row
+        else if (atup0) { lo = -QINF; hi = 0.0; }
+        else { lo = 0.0; hi = QINF; }
+    }
+    }
     double nbval = v0;
-    int cNvar = 2 * N;
-    double cNval = 0.0;
-    double tcol = 0.0;                      // extra column, one entry per row-lane
-    double xb = act ? a.q[vo + lane] : 0.0;
     __syncthreads();
 
     // ---- load M: coalesced HBM -> LDS stage (BS columns at a time) -> register blocks ------
-    double t[BS][BS];
-#pragma unroll
-    for (int k = 0; k < BS; ++k)
-#pragma unroll
-        for (int l = 0; l < BS; ++l) t[k][l] = 0.0;
+#define M_DECL(k, l) double E(k, l) = 0.0;
+    QPN_FOR_KL(M_DECL)
+#undef M_DECL
     for (int cbk = 0; cbk < 8; ++cbk) {
         const int col0 = BS * cbk;
         if (col0 >= N) break;
@@ -137,122 +175,23 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
             }
         }
         __syncthreads();
-        // initial basic values  xb = q + M z_nb, columns in ascending order (as the oracle)
+        // initial basic values  xb = q + M z_nb, columns in ascending order (as the checker)
         for (int l = 0; l < ncols; ++l) {
             const double zj = snb[col0 + l];
             if (zj != 0.0 && act) xb = fma(stage[l * NP + G::pidx(lane)], zj, xb);
         }
         if (cb == cbk) {
-#pragma unroll
-            for (int l = 0; l < BS; ++l)
-#pragma unroll
-                for (int k = 0; k < BS; ++k) {
-                    const int row = BS * ra + k;
-                    t[k][l] = (row < N && l < ncols) ? stage[l * NP + ra * PB + k] : 0.0;
-                }
+#define M_LOAD(k, l)                                                                            \
+    if constexpr ((k) < BS && (l) < BS)                                                         \
+        E(k, l) = (BS * ra + (k) < N && (l) < ncols) ? stage[(l) * NP + ra * PB + (k)] : 0.0;
+            QPN_FOR_KL(M_LOAD)
+#undef M_LOAD
         }
         __syncthreads();
     }
-
     STAMP(0);   // setup + load
     int pivots = 0;
 
-    // Dynamic row / column selection without dynamic register indexing.  The selector becomes a
-    // one-hot mask tested bit by bit with wave-uniform branches; the branch bodies are either LDS
-    // stores or `asm volatile` register writes, which hipcc can neither speculate nor turn into
-    // selects, so every body touches statically named registers IN PLACE.  (A `switch`, or plain
-    // C++ assignments, make hipcc compute all BS*BS candidates and select -- hundreds of moves.)
-    auto extract_col = [&](int c_in) -> double {
-        const int c = uni(c_in);
-        if (c == XC) {
-            if (lane < NB) ucol[G::pidx(lane)] = tcol;
-        } else {
-            const unsigned hot = 1u << (c % BS);
-            if (cb == c / BS) {
-#pragma unroll
-                for (int L = 0; L < BS; ++L) {
-                    if (hot & (1u << L)) {
-#pragma unroll
-                        for (int k = 0; k < BS; ++k) ucol[ra * PB + k] = t[k][L];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        return lane < NB ? ucol[G::pidx(lane)] : 0.0;
-    };
-
-    // exchange the entering variable (column c, moved by delta) with the basic variable of row r;
-    // cm = this row-lane's entry of column c (ucol still holds the column)
-    auto do_pivot = [&](int r_in, int c_in, double delta, double leave_val, double cm) {
-        const int r = uni(r_in), c = uni(c_in);
-        xb = fma(delta, cm, xb);
-        const double enter_old = (c == XC) ? cNval : readlane_f64(nbval, c);
-        const double enter_val = enter_old + delta;
-        const double inv = 1.0 / readlane_f64(cm, r);
-        const unsigned rhot = 1u << (r % BS);
-        const bool rmine = ra == r / BS;
-        const unsigned chot = (c == XC) ? 0u : (1u << (c % BS));
-        const bool cmine = (c != XC) && cb == c / BS;
-        // raw pivot row -> vrow (scaled by the readers)
-        if (rmine) {
-#pragma unroll
-            for (int K = 0; K < BS; ++K) {
-                if (rhot & (1u << K)) {
-#pragma unroll
-                    for (int l = 0; l < BS; ++l) vrow[cb * PB + l] = t[K][l];
-                }
-            }
-        }
-        if (lane == r) vrow[NP] = tcol;
-        __syncthreads();
-        double u[BS], v[BS];
-#pragma unroll
-        for (int k = 0; k < BS; ++k) u[k] = ucol[ra * PB + k];
-#pragma unroll
-        for (int l = 0; l < BS; ++l) {
-            const double raw = vrow[cb * PB + l];
-            // prow_j = T[r][j] * inv; the slot of column c carries -inv (row fix-up below)
-            v[l] = (BS * cb + l == c) ? -inv : raw * inv;
-        }
-        const double vx = (c == XC) ? -inv : vrow[NP] * inv;
-#pragma unroll
-        for (int k = 0; k < BS; ++k)
-#pragma unroll
-            for (int l = 0; l < BS; ++l) t[k][l] = fma(-u[k], v[l], t[k][l]);
-        // column c of the new dictionary: T[i][c] = cm_i * inv
-        if (cmine) {
-#pragma unroll
-            for (int L = 0; L < BS; ++L) {
-                if (chot & (1u << L)) {
-#pragma unroll
-                    for (int k = 0; k < BS; ++k)
-                        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t[k][L]) : "v"(u[k]), "v"(inv));
-                }
-            }
-        }
-        // row r of the new dictionary: T[r][j] = -prow_j, T[r][c] = inv (v holds -inv there)
-        if (rmine) {
-#pragma unroll
-            for (int K = 0; K < BS; ++K) {
-                if (rhot & (1u << K)) {
-#pragma unroll
-                    for (int l = 0; l < BS; ++l)
-                        asm volatile("v_mul_f64 %0, %1, -1.0" : "=v"(t[K][l]) : "v"(v[l]));
-                }
-            }
-        }
-        // extra column
-        if (c == XC) tcol = (lane == r) ? inv : cm * inv;
-        else tcol = (lane == r) ? -vx : fma(-cm, vx, tcol);
-        // bookkeeping
-        const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
-        const int vl = readlane_i32(rowvar, r);
-        if (lane == r) { rowvar = ve; xb = enter_val; }
-        if (c == XC) { cNvar = vl; cNval = leave_val; }
-        else if (lane == c) { colvar = vl; nbval = leave_val; }
-        __syncthreads();
-    };
     auto col_of = [&](int v) -> int {
         int c = wave_first(act && colvar == v);
         if (c < 0 && cNvar == v) c = XC;
@@ -282,19 +221,18 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     const double slack = 1e-10;
     const double ptol = a.piv_tol;
     for (;;) {
+        int e = 0;
         if (stage_ == 0) {
             if (!(idx < n_enter && budget > 0)) { stage_ = 1; continue; }
-            const int e = uni(elist[idx]);
+            e = uni(elist[idx]);
             idx++;
             c = wave_first(act && colvar == e);
             if (c < 0) continue;
         } else if (stage_ == 1) {
-            double lo, hi;
-            var_interval_r(rowvar, N, sl, su, sat, lo, hi);
             double viol = 0.0;
             if (act) viol = xb < lo ? lo - xb : (xb > hi ? xb - hi : 0.0);
             const double theta0 = wave_max_f64(viol);
-            if (theta0 <= a.feas_tol) { status = QPN_SUCCESS; break; }
+            if (ubool(theta0 <= a.feas_tol)) { status = QPN_SUCCESS; break; }
             if (act) {
                 double cov = 0.0;
                 if (xb < lo) {
@@ -316,75 +254,98 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         } else {
             if (pivots >= max_piv) break;
         }
-
+        c = uni(c);
         STAMP(1);   // loop control / stage setup
-        const double cm = extract_col(c);
+        double cm;
+        {
+        if (c == XC) {
+            if (lane < NB) ucol[G::pidx(lane)] = tcol;
+        } else if (cb == c / BS) {
+            const int csel = c % BS;
+#define M_XC(k, L) if constexpr ((k) < BS && (L) < BS) ucol[ra * PB + (k)] = E(k, L);
+#define QPN_LEAF(L) QPN_FOR_K(M_XC, L)
+            QPN_DISPATCH8(csel, QPN_LEAF);
+#undef QPN_LEAF
+#undef M_XC
+        }
+        __syncthreads();
+            cm = lane < NB ? ucol[G::pidx(lane)] : 0.0;
+        }
         STAMP(2);   // column extraction
         int r;
-        double delta, leave_val;
+        double delta, leave_val, inv;
         if (stage_ == 0) {
             const double av = act ? fabs(cm) : 0.0;
             const double colmax = wave_max_f64(av);
-            bool ml = false, ord = false;
-            double tg = 0.0;
-            if (act) {
-                const int v = rowvar;
-                if (v < 2 * N) {
-                    const int k = v < N ? v : v - N;
-                    const double Lk = sl[k], Uk = su[k];
-                    const bool fr = Lk == -QINF && Uk == QINF, fx = Lk == Uk;
-                    if (v >= N) { if (fr) { ml = true; tg = 0.0; } }
-                    else if (fx && !fr) { ml = true; tg = Lk; }
-                    ord = !fr && !fx;
-                }
-            }
             const double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
-            double best = wave_max_f64(ml ? av : -1.0);
-            if (best > thresh) {
-                r = wave_first(ml && av == best);
-                leave_val = readlane_f64(tg, r);
-            } else {
-                // no equation row can take it: 2x2 principal block pivot through an ordinary pair
-                best = wave_max_f64(ord ? av : -1.0);
-                if (!(best > thresh)) continue;
-                r = wave_first(ord && av == best);
-                const int v = readlane_i32(rowvar, r);
-                if (v < N) {
-                    const double x = readlane_f64(xb, r), lo = sl[v], hi = su[v];
-                    int au;
-                    if (x <= lo) { leave_val = lo; au = 0; }
-                    else if (x >= hi) { leave_val = hi; au = 1; }
-                    else if (lo == -QINF) { leave_val = hi; au = 1; }
-                    else if (hi == QINF) { leave_val = lo; au = 0; }
-                    else if (hi - x < x - lo) { leave_val = hi; au = 1; }
-                    else { leave_val = lo; au = 0; }
-                    if (lane == 0) { sat[v] = au; elist[n_enter] = N + v; }
-                } else {
-                    leave_val = 0.0;
-                    if (lane == 0) elist[n_enter] = v - N;
+            r = -1;
+            leave_val = 0.0;
+            // diagonal first (threshold pivoting, u = 0.01): a free variable takes its own
+            // equation row -- no search
+            if (e < N && readlane_i32(rowvar, e) == N + e) {
+                const double ad = readlane_f64(av, e);
+                if (ubool(ad > thresh && ad >= 0.01 * colmax)) r = e;
+            }
+            if (r < 0) {
+                bool ml = false, ord = false;
+                double tg = 0.0;
+                if (act) {
+                    const int v = rowvar;
+                    if (v < 2 * N) {
+                        const int k = v < N ? v : v - N;
+                        const double Lk = sl[k], Uk = su[k];
+                        const bool fr = Lk == -QINF && Uk == QINF, fx = Lk == Uk;
+                        if (v >= N) { if (fr) { ml = true; tg = 0.0; } }
+                        else if (fx && !fr) { ml = true; tg = Lk; }
+                        ord = !fr && !fx;
+                    }
                 }
-                n_enter++;
+                double best = wave_max_f64(ml ? av : -1.0);
+                if (ubool(best > thresh)) {
+                    r = wave_first(ml && av == best);
+                    leave_val = readlane_f64(tg, r);
+                } else {
+                    // no equation row can take it: 2x2 principal block pivot through an ordinary pair
+                    best = wave_max_f64(ord ? av : -1.0);
+                    if (ubool(!(best > thresh))) continue;
+                    r = wave_first(ord && av == best);
+                    const int v = readlane_i32(rowvar, r);
+                    if (v < N) {
+                        const double x = readlane_f64(xb, r), plo = udbl(sl[v]), phi = udbl(su[v]);
+                        int au;
+                        if (x <= plo) { leave_val = plo; au = 0; }
+                        else if (x >= phi) { leave_val = phi; au = 1; }
+                        else if (plo == -QINF) { leave_val = phi; au = 1; }
+                        else if (phi == QINF) { leave_val = plo; au = 0; }
+                        else if (phi - x < x - plo) { leave_val = phi; au = 1; }
+                        else { leave_val = plo; au = 0; }
+                        if (lane == 0) { sat[v] = au; elist[n_enter] = N + v; }
+                    } else {
+                        leave_val = 0.0;
+                        if (lane == 0) elist[n_enter] = v - N;
+                    }
+                    n_enter++;
+                }
             }
-            delta = (leave_val - readlane_f64(xb, r)) / readlane_f64(cm, r);
+            r = uni(r);
+            inv = 1.0 / readlane_f64(cm, r);
+            delta = (leave_val - readlane_f64(xb, r)) * inv;
         } else {
-            double lo, hi;
-            var_interval_r(rowvar, N, sl, su, sat, lo, hi);
-            const double g = act ? sigma * cm : 0.0;
-            double d1 = QINF;
-            bool cnd = false;
-            double d = 0.0, lv = 0.0;
-            if (act) {
-                if (g < -ptol && lo > -QINF) { d1 = (xb - lo + slack) / (-g); d = (xb - lo) / (-g); lv = lo; cnd = true; }
-                else if (g > ptol && hi < QINF) { d1 = (hi - xb + slack) / g; d = (hi - xb) / g; lv = hi; cnd = true; }
-            }
-            double dmax = wave_min_f64(d1);
+            const double g = sigma * cm;
+            const double rc = 1.0 / g;
+            const bool cndlo = act && g < -ptol && lo > -QINF;
+            const bool cndhi = act && g > ptol && hi < QINF;
+            const bool cnd = cndlo || cndhi;
+            const double arc = cndlo ? -rc : rc;
+            const double d = (cndlo ? xb - lo : hi - xb) * arc;
+            const double d1 = d + slack * arc;
+            double dmax = wave_min_f64(cnd ? d1 : QINF);
             if (self_lim < dmax) dmax = self_lim;
-            if (dmax == QINF) { status = QPN_RAY_TERM; break; }
-            if (cnd && d > dmax) cnd = false;
-            double ag = cnd ? fabs(g) : -1.0;
-            if (cnd && rowvar == 2 * N) ag = QINF;
-            const double bestg = wave_max_f64(ag);
-            if (bestg < 0.0) {
+            dmax = udbl(dmax);
+            if (ubool(dmax == QINF)) { status = QPN_RAY_TERM; break; }
+            const bool cand = cnd && d <= dmax;
+            const unsigned long long bal = __ballot(cand);
+            if (bal == 0ull) {
                 // the entering variable reaches its own far bound first
                 const double dl = sigma * self_lim;
                 if (act) xb = fma(dl, cm, xb);
@@ -394,8 +355,8 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                     status = QPN_SUCCESS; break;
                 }
                 const int k = ve;
-                const int au = sigma > 0.0 ? 1 : 0;
-                const double nv = au ? su[k] : sl[k];
+                const int au = ubool(sigma > 0.0) ? 1 : 0;
+                const double nv = udbl(au ? su[k] : sl[k]);
                 if (lane == 0) sat[k] = au;
                 if (c == XC) cNval = nv; else if (lane == c) nbval = nv;
                 pivots++;
@@ -406,16 +367,97 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                 __syncthreads();
                 continue;
             }
-            r = wave_first(cnd && ag == bestg);
+            if (__popcll(bal) == 1) {
+                r = __ffsll((long long)bal) - 1;
+            } else {
+                // several rows inside the step bound: largest pivot, the artificial first
+                double ag = cand ? fabs(g) : -1.0;
+                if (cand && rowvar == 2 * N) ag = QINF;
+                const double bestg = wave_max_f64(ag);
+                r = wave_first(cand && ag == bestg);
+            }
+            r = uni(r);
             double step = readlane_f64(d, r);
-            if (step < 0.0) step = 0.0;
-            leave_val = readlane_f64(lv, r);
+            if (ubool(step < 0.0)) step = 0.0;
+            leave_val = readlane_f64(cndlo ? lo : hi, r);
+            inv = sigma * readlane_f64(rc, r);
             delta = sigma * step;
         }
 
         const int vl = readlane_i32(rowvar, r);
         STAMP(3);   // pivot selection (ratio tests, reductions)
-        do_pivot(r, c, delta, leave_val, cm);
+        {   // ---- the pivot: exchange entering column c with the basic variable of row r ----
+        const double delta_u = udbl(delta), leave_u = udbl(leave_val), inv_u = udbl(inv);
+        const double enter_val = udbl(((c == XC) ? cNval : readlane_f64(nbval, c)) + delta_u);
+        const bool rmine = ra == r / BS;
+        const bool cmine = (c != XC) && cb == c / BS;
+        // raw pivot row -> vrow (scaled by the readers)
+        if (rmine) {
+            const int rsel = r % BS;
+#define M_XR(K, l) if constexpr ((K) < BS && (l) < BS) vrow[cb * PB + (l)] = E(K, l);
+#define QPN_LEAF(K) QPN_FOR_L(M_XR, K)
+            QPN_DISPATCH8(rsel, QPN_LEAF);
+#undef QPN_LEAF
+#undef M_XR
+        }
+        if (lane == r) vrow[NP] = tcol;
+        __syncthreads();
+        // row-vector updates first (cm is dead afterwards): basic values and the extra column
+        {
+            const double vx = (c == XC) ? -inv_u : vrow[NP] * inv_u;
+            double xbn = fma(delta_u, cm, xb);
+            double tcn = (c == XC) ? cm * inv_u : fma(-cm, vx, tcol);
+            if (lane == r) { xbn = enter_val; tcn = (c == XC) ? inv_u : -vx; }
+            xb = xbn; tcol = tcn;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // u = pivot column block, v = scaled pivot row block; the slot of column c carries -inv_u
+#define M_LDU(k) double u_##k = 0.0; if constexpr ((k) < BS) u_##k = ucol[ra * PB + (k)];
+            QPN_FOR_1(M_LDU)
+#undef M_LDU
+#define M_LDV(l) double v_##l = 0.0; if constexpr ((l) < BS) v_##l = vrow[cb * PB + (l)];
+            QPN_FOR_1(M_LDV)
+#undef M_LDV
+#define M_SCV(l) if constexpr ((l) < BS) { const double sc = v_##l * inv_u; v_##l = (BS * cb + (l) == c) ? -inv_u : sc; }
+            QPN_FOR_1(M_SCV)
+#undef M_SCV
+#define M_FMA(k, l) if constexpr ((k) < BS && (l) < BS) E(k, l) = fma(-u_##k, v_##l, E(k, l));
+            QPN_FOR_KL(M_FMA)
+#undef M_FMA
+            // column c of the new dictionary: T[i][c] = cm_i * inv_u     (in place, owner lanes only)
+            if (cmine) {
+                const int csel = c % BS;
+#define M_FC(k, L)                                                                              \
+    if constexpr ((k) < BS && (L) < BS)                                                         \
+        asm volatile("v_mul_f64 %0, %1, %2" : "=v"(E(k, L)) : "v"(u_##k), "v"(inv_u));
+#define QPN_LEAF(L) QPN_FOR_K(M_FC, L)
+                QPN_DISPATCH8(csel, QPN_LEAF);
+#undef QPN_LEAF
+#undef M_FC
+            }
+            // row r of the new dictionary: T[r][j] = -prow_j, T[r][c] = inv_u (v holds -inv_u there)
+            if (rmine) {
+                const int rsel = r % BS;
+#define M_FR(K, l)                                                                              \
+    if constexpr ((K) < BS && (l) < BS)                                                         \
+        asm volatile("v_mul_f64 %0, %1, -1.0" : "=v"(E(K, l)) : "v"(v_##l));
+#define QPN_LEAF(K) QPN_FOR_L(M_FR, K)
+                QPN_DISPATCH8(rsel, QPN_LEAF);
+#undef QPN_LEAF
+#undef M_FR
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // bookkeeping: row r now holds the entering variable, column c the leaving one
+        const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
+        double nlo, nhi;
+        interval_uni(ve, N, sl, su, sat, nlo, nhi);
+        if (lane == r) { rowvar = ve; lo = nlo; hi = nhi; }
+        if (c == XC) { cNvar = vl; cNval = leave_u; }
+        else if (lane == c) { colvar = vl; nbval = leave_u; }
+        __syncthreads();
+        }
         STAMP(4);   // rank-1 update
         pivots++;
 
@@ -427,29 +469,30 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
             int vn;
             if (vl < N) {
                 const int k = vl;
-                const double Lk = sl[k], Uk = su[k];
-                int au = sat[k];
-                if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; if (lane == 0) sat[k] = au; }
+                const double Lk = udbl(sl[k]), Uk = udbl(su[k]);
+                int au = uni(sat[k]);
+                if (ubool(Lk != Uk)) { au = (leave_val == Uk) ? 1 : 0; if (lane == 0) sat[k] = au; }
                 vn = N + k;
                 sigma = au ? -1.0 : 1.0;
                 self_lim = QINF;
             } else {
                 const int k = vl - N;
-                const double Lk = sl[k], Uk = su[k];
+                const double Lk = udbl(sl[k]), Uk = udbl(su[k]);
                 vn = k;
-                sigma = sat[k] ? -1.0 : 1.0;
+                sigma = uni(sat[k]) ? -1.0 : 1.0;
                 self_lim = Uk - Lk;
-                if (Lk == -QINF && Uk == QINF) { self_lim = QINF; sigma = 1.0; }
+                if (ubool(Lk == -QINF && Uk == QINF)) { self_lim = QINF; sigma = 1.0; }
             }
             c = col_of(vn);
             if (c < 0) { status = QPN_FAILURE; break; }
             __syncthreads();
         }
     }
-
     STAMP(1);
+
     // ---- read the point back ----------------------------------------------------------------
     __syncthreads();
+    gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + lane] : 0;
     if (act) { snb[rowvar] = xb; snb[colvar] = nbval; }
     if (lane == 0) snb[cNvar] = cNval;
     __syncthreads();
@@ -469,6 +512,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     double nres = 0.0;
     unsigned mask = 0;
     if (act) {
+        const double lk = sl[lane], uk = su[lane];
         const double tol = a.check_tol;
         if (d > tol && fabs(p - lk) > tol) bad++;
         if (d < -tol && fabs(p - uk) > tol) bad++;

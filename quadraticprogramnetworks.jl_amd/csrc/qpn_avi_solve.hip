@@ -196,10 +196,15 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
         }
         double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
         double best = wave_max_f64(ml ? av : -1.0);
-        if (best > thresh) {
-            int r = wave_first(ml && av == best);
-            double target = __shfl(tg, r, WAVE);
-            double delta = (target - __shfl(xb, r, WAVE)) / T[c * LD + r];
+        int rdiag = -1;
+        if (e < N && __shfl(rowvar, e, WAVE) == N + e) {   // diagonal first (threshold pivoting)
+            const double ad = __shfl(av, e, WAVE);
+            if (ad > thresh && ad >= 0.01 * colmax) rdiag = e;
+        }
+        if (rdiag >= 0 || best > thresh) {
+            int r = rdiag >= 0 ? rdiag : wave_first(ml && av == best);
+            double target = rdiag >= 0 ? 0.0 : __shfl(tg, r, WAVE);
+            double delta = (target - __shfl(xb, r, WAVE)) * (1.0 / T[c * LD + r]);
             do_pivot(r, c, delta, target);
             pivots++; budget--;
             continue;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
             if (lane == 0) elist[n_enter] = v - N;
         }
         n_enter++;
-        double delta = (target - __shfl(xb, r, WAVE)) / T[c * LD + r];
+        double delta = (target - __shfl(xb, r, WAVE)) * (1.0 / T[c * LD + r]);
         do_pivot(r, c, delta, target);  // ends with a barrier: elist/sat writes are visible
         pivots++; budget--;
         if (n_enter >= 8 * N) break;
@@ -270,8 +275,9 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
                 bool cnd = false;
                 double d = 0.0, lv = 0.0;
                 if (act) {
-                    if (g < -ptol && lo > -QINF) { d1 = (xb - lo + slack) / (-g); d = (xb - lo) / (-g); lv = lo; cnd = true; }
-                    else if (g > ptol && hi < QINF) { d1 = (hi - xb + slack) / g; d = (hi - xb) / g; lv = hi; cnd = true; }
+                    const double rc = 1.0 / g;
+                    if (g < -ptol && lo > -QINF) { d = (xb - lo) * (-rc); d1 = d + slack * (-rc); lv = lo; cnd = true; }
+                    else if (g > ptol && hi < QINF) { d = (hi - xb) * rc; d1 = d + slack * rc; lv = hi; cnd = true; }
                 }
                 double dmax = wave_min_f64(d1);
                 if (self_lim < dmax) dmax = self_lim;

@@ -62,6 +62,7 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
 
 // ---- wave64 helpers (CDNA4: one wavefront = 64 lanes) --------------------------------
 #ifdef __HIPCC__
+__device__ __forceinline__ double udbl(double v);
 // ---- DPP / readlane based wave64 primitives (no LDS round trips) -------------------------
 // dpp_ctrl encodings (GFX9): quad_perm = 0x00..0xFF, row_half_mirror = 0x141, row_mirror = 0x140
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
@@ -98,13 +99,13 @@ __device__ __forceinline__ double wave_max_f64(double v)
 {
     QPN_ROW_REDUCE(v, qpn_max2);
     double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    return qpn_max2(qpn_max2(r0, r1), qpn_max2(r2, r3));
+    return udbl(qpn_max2(qpn_max2(r0, r1), qpn_max2(r2, r3)));
 }
 __device__ __forceinline__ double wave_min_f64(double v)
 {
     QPN_ROW_REDUCE(v, qpn_min2);
     double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    return qpn_min2(qpn_min2(r0, r1), qpn_min2(r2, r3));
+    return udbl(qpn_min2(qpn_min2(r0, r1), qpn_min2(r2, r3)));
 }
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
@@ -125,4 +126,12 @@ __device__ __forceinline__ int wave_first(bool pred)
     return b ? (__ffsll((long long)b) - 1) : -1;
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Tell the compiler a value is wave-uniform (moves it to SGPRs): branches on it become scalar.
+__device__ __forceinline__ bool ubool(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ double udbl(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 #endif
