@@ -159,21 +159,39 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 #define M_DECL(k, l) double E(k, l) = 0.0;
     QPN_FOR_KL(M_DECL)
 #undef M_DECL
+    // Software-pipelined: the (coalesced, 512 B per instruction) loads of column block k+1 are in
+    // flight while block k is transposed through the LDS stage.  Element idx of a block lives at
+    // (col, row) = (idx / N, idx % N); a lane fetches idx = lane + 64 s, s < BS.
+    double pf[BS];
+    auto issue_loads = [&](int cbk) {
+        const int col0 = BS * cbk;
+        const int ncols = (N - col0) < BS ? (N - col0) : BS;
+        const int cnt = col0 < N ? ncols * N : 0;
+        const double *base = Mg + (size_t)col0 * N;
+#pragma unroll
+        for (int sidx = 0; sidx < BS; ++sidx) {
+            const int idx = lane + WAVE * sidx;
+            pf[sidx] = idx < cnt ? base[idx] : 0.0;
+        }
+    };
+    issue_loads(0);
     for (int cbk = 0; cbk < 8; ++cbk) {
         const int col0 = BS * cbk;
         if (col0 >= N) break;
         const int ncols = (N - col0) < BS ? (N - col0) : BS;
         const int cnt = ncols * N;
-        const double *base = Mg + (size_t)col0 * N;
         {
             int row = lane, col = 0;
             while (row >= N) { row -= N; col++; }
-            for (int idx = lane; idx < cnt; idx += WAVE) {
-                stage[col * NP + G::pidx(row)] = base[idx];
+#pragma unroll
+            for (int sidx = 0; sidx < BS; ++sidx) {
+                const int idx = lane + WAVE * sidx;
+                if (idx < cnt) stage[col * NP + G::pidx(row)] = pf[sidx];
                 row += WAVE;
                 while (row >= N) { row -= N; col++; }
             }
         }
+        if (cbk + 1 < 8) issue_loads(cbk + 1);
         __syncthreads();
         // initial basic values  xb = q + M z_nb, columns in ascending order (as the checker)
         for (int l = 0; l < ncols; ++l) {
@@ -503,9 +521,24 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------
     double rk = act ? a.q[vo + lane] : 0.0;
-    for (int j = 0; j < N; ++j) {
-        double zj = ucol[j];
-        if (zj != 0.0 && act) rk = fma(Mg[(size_t)j * N + lane], zj, rk);
+    {
+        // 8 independent column loads in flight per step; a zero z_j contributes exactly nothing
+        // (M finite), so no per-column branch is needed to match the checker's skip of zeros
+        int j = 0;
+        for (; j + 8 <= N; j += 8) {
+            double mv[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = act ? Mg[(size_t)(j + q8) * N + lane] : 0.0;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) {
+                const double zj = ucol[j + q8];
+                rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk;
+            }
+        }
+        for (; j < N; ++j) {
+            const double zj = ucol[j];
+            if (zj != 0.0 && act) rk = fma(Mg[(size_t)j * N + lane], zj, rk);
+        }
     }
     const double p = gk ? rk : zk, d = gk ? zk : rk;
     int bad = 0;
