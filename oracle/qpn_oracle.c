@@ -283,6 +283,11 @@ static int solve_avi_ws(int N, const double *M, const double *q, const double *l
     }
     matvec_q(N, M, q, S.nbval, S.xb);
 
+    /* scale of the problem: max |M_ij|; a diagonal crash pivot must reach 1e-4 of it (error growth <= 1e4 eps) */
+    double mscale = 0.0;
+    for (size_t t = 0; t < (size_t)N * N; ++t) { double a = fabs(M[t]); if (a > mscale) mscale = a; }
+    const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
+
     /* ---- Stage A: crash.  Free variables (and multipliers of equality GAVI rows) enter. ---- */
     for (int k = 0; k < N; ++k) {
         int g = rowkind ? rowkind[k] : 0;
@@ -302,12 +307,13 @@ static int solve_avi_ws(int N, const double *M, const double *q, const double *l
             if (is_must_leave(&S, S.rowvar[i], &tg) && a > best) { best = a; r = i; target = tg; }
         }
         double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
-        /* diagonal first (threshold pivoting, u = 0.01): a free variable takes its own equation
-         * row when that pivot is not small against the column -- no search, no growth for the
-         * (semi)definite blocks QP nodes produce; otherwise the largest admissible row. */
-        if (e < N && S.rowvar[e] == N + e) {
+        /* diagonal first: a free variable whose column is still its own takes its own equation
+         * row when that pivot is not tiny against the scale of M -- no search (elimination
+         * without pivoting is stable for the (semi)definite blocks QP nodes produce);
+         * otherwise the largest admissible row (partial pivoting). */
+        if (e < N && c == e && S.rowvar[e] == N + e) {
             double ad = fabs(S.T[(size_t)e * NC + c]);
-            if (ad > thresh && ad >= 0.01 * colmax) { r = e; best = ad; target = 0.0; }
+            if (ad >= diag_thr) { r = e; best = ad; target = 0.0; thresh = 0.0; }
         }
         if (r >= 0 && best > thresh) {
             double delta = (target - S.xb[r]) * (1.0 / S.T[(size_t)r * NC + c]);

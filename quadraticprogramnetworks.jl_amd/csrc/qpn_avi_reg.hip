@@ -163,6 +163,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     // flight while block k is transposed through the LDS stage.  Element idx of a block lives at
     // (col, row) = (idx / N, idx % N); a lane fetches idx = lane + 64 s, s < BS.
     double pf[BS];
+    double mabs = 0.0;                       // running max |M_ij| of the elements this lane moves
     auto issue_loads = [&](int cbk) {
         const int col0 = BS * cbk;
         const int ncols = (N - col0) < BS ? (N - col0) : BS;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 #pragma unroll
             for (int sidx = 0; sidx < BS; ++sidx) {
                 const int idx = lane + WAVE * sidx;
-                if (idx < cnt) stage[col * NP + G::pidx(row)] = pf[sidx];
+                if (idx < cnt) { stage[col * NP + G::pidx(row)] = pf[sidx]; mabs = fmax(mabs, fabs(pf[sidx])); }
                 row += WAVE;
                 while (row >= N) { row -= N; col++; }
             }
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     }
     STAMP(0);   // setup + load
     int pivots = 0;
+    int pivots_init = 0;
 
     auto col_of = [&](int v) -> int {
         int c = wave_first(act && colvar == v);
@@ -234,6 +236,78 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     int budget = 4 * N + 4;
     int stage_ = 0, idx = 0;
     int status = QPN_FAILURE;
+
+    // ---- Stage A fast path: diagonal crash pivots, statically unrolled --------------------------
+    // While the next variable to enter is a free z_e whose column and equation row are still its
+    // own and |T[e][e]| >= 1e-4 max(1, max|M|), the pivot is (e, e): no search, no ratio test, and
+    // the block-local indices are compile-time constants (no dispatch).  Same arithmetic as the
+    // general loop below, which takes over at the first variable that does not qualify.
+    const double mscale = wave_max_f64(mabs);
+    const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
+    {
+        bool fast_ok = true;
+#define M_FAST(JB, JJ)                                                                              \
+    if constexpr ((JJ) < BS) {                                                                      \
+        const int e_ = BS * (JB) + (JJ);                                                            \
+        if (fast_ok && idx < n_enter && budget > 0 && uni(elist[idx < n_enter ? idx : 0]) == e_ &&  \
+            e_ < N) {                                                                               \
+            const bool own = readlane_i32(colvar, e_) == e_ && readlane_i32(rowvar, e_) == N + e_;  \
+            if (!own) { fast_ok = false; }                                                          \
+            else {                                                                                  \
+                if (cb == (JB)) { QPN_FOR_K(M_FXC, JJ) }                                            \
+                if (ra == (JB)) { QPN_FOR_L(M_FXR, JJ) }                                            \
+                __syncthreads();                                                                    \
+                const double piv = udbl(ucol[G::pidx(e_)]);                                         \
+                if (!ubool(fabs(piv) >= diag_thr)) { fast_ok = false; }                             \
+                else {                                                                              \
+                    const double cmf = lane < NB ? ucol[G::pidx(lane)] : 0.0;                       \
+                    const double inv = 1.0 / piv;                                                   \
+                    const double delta = udbl((0.0 - readlane_f64(xb, e_)) * inv);                  \
+                    const double ent = udbl(readlane_f64(nbval, e_) + delta);                       \
+                    xb = fma(delta, cmf, xb);                                                       \
+                    if (lane == e_) { xb = ent; rowvar = e_; colvar = N + e_; nbval = 0.0; lo = -QINF; hi = QINF; } \
+                    QPN_FOR_1(M_FLDU)                                                               \
+                    QPN_FOR_1(M_FLDV)                                                               \
+                    if (cb == (JB)) v_##JJ##_f = -inv;                                              \
+                    QPN_FOR_KL(M_FFMA)                                                              \
+                    if (cb == (JB)) { QPN_FOR_K(M_FFC, JJ) }                                        \
+                    if (ra == (JB)) { QPN_FOR_L(M_FFR, JJ) }                                        \
+                    pivots_fast++; idx++; budget--;                                                 \
+                    __syncthreads();                                                                \
+                }                                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+    }
+#define M_FXC(k, L) if constexpr ((k) < BS) ucol[ra * PB + (k)] = E(k, L);
+#define M_FXR(K, l) if constexpr ((l) < BS) vrow[cb * PB + (l)] = E(K, l);
+#define M_FLDU(k) double u_##k##_f = 0.0; if constexpr ((k) < BS) u_##k##_f = ucol[ra * PB + (k)];
+#define M_FLDV(l) double v_##l##_f = 0.0; if constexpr ((l) < BS) v_##l##_f = vrow[cb * PB + (l)] * inv;
+#define M_FFMA(k, l) if constexpr ((k) < BS && (l) < BS) E(k, l) = fma(-u_##k##_f, v_##l##_f, E(k, l));
+#define M_FFC(k, L) if constexpr ((k) < BS) E(k, L) = u_##k##_f * inv;
+#define M_FFR(K, l) if constexpr ((l) < BS) E(K, l) = -v_##l##_f;
+#define M_FAST_ROW(JB) M_FAST(JB, 0) M_FAST(JB, 1) M_FAST(JB, 2) M_FAST(JB, 3) M_FAST(JB, 4) M_FAST(JB, 5) M_FAST(JB, 6) M_FAST(JB, 7)
+        int pivots_fast = 0;
+        for (int jb = 0; jb < 8 && fast_ok; ++jb) {
+            // one iteration per column block; inside, the 8 block-local indices are unrolled
+            const int JBv = jb;
+            (void)JBv;
+#define JBX jb
+            M_FAST_ROW(JBX)
+#undef JBX
+        }
+        pivots_init = pivots_fast;
+#undef M_FAST_ROW
+#undef M_FFR
+#undef M_FFC
+#undef M_FFMA
+#undef M_FLDV
+#undef M_FLDU
+#undef M_FXR
+#undef M_FXC
+#undef M_FAST
+    }
+    pivots = pivots_init;
+
     int c = XC;
     double sigma = -1.0, self_lim = 0.0;
     const double slack = 1e-10;
@@ -298,11 +372,11 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
             const double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
             r = -1;
             leave_val = 0.0;
-            // diagonal first (threshold pivoting, u = 0.01): a free variable takes its own
-            // equation row -- no search
-            if (e < N && readlane_i32(rowvar, e) == N + e) {
+            // diagonal first: a free variable whose column is still its own takes its own
+            // equation row when the pivot reaches 1e-4 max(1, max|M|) -- no search
+            if (e < N && c == e && readlane_i32(rowvar, e) == N + e) {
                 const double ad = readlane_f64(av, e);
-                if (ubool(ad > thresh && ad >= 0.01 * colmax)) r = e;
+                if (ubool(ad >= diag_thr)) r = e;
             }
             if (r < 0) {
                 bool ml = false, ord = false;

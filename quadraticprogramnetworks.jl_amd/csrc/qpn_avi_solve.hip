@@ -128,6 +128,10 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
     }
 
     int pivots = 0;
+    double mabs = 0.0;
+    if (act) for (int j = 0; j < N; ++j) mabs = fmax(mabs, fabs(T[j * LD + lane]));
+    const double mscale = wave_max_f64(mabs);
+    const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
 
     // exchange the entering variable (column c, moved by delta) with the basic variable of row r
     auto do_pivot = [&](int r, int c, double delta, double leave_val) {
@@ -197,9 +201,9 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
         double thresh = 1e-9 * (colmax > 1.0 ? colmax : 1.0);
         double best = wave_max_f64(ml ? av : -1.0);
         int rdiag = -1;
-        if (e < N && __shfl(rowvar, e, WAVE) == N + e) {   // diagonal first (threshold pivoting)
+        if (e < N && c == e && __shfl(rowvar, e, WAVE) == N + e) {   // diagonal first
             const double ad = __shfl(av, e, WAVE);
-            if (ad > thresh && ad >= 0.01 * colmax) rdiag = e;
+            if (ad >= diag_thr) rdiag = e;
         }
         if (rdiag >= 0 || best > thresh) {
             int r = rdiag >= 0 ? rdiag : wave_first(ml && av == best);
