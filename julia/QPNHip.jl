@@ -1,0 +1,125 @@
+# QPNHip.jl -- `ccall` shim that puts libqpn_hip.so (include/qpn_hip.h) behind the reference's own
+# functions for the node-AVI hot path.  SOURCE ONLY: this container has no Julia, so this file has
+# never been executed (see INTEGRATION.md); every signature below is checked against the C header
+# by hand.  It replaces exactly two bodies in the reference:
+#
+#   solve_avi(avi::AVI, z0, w)                      src/avi.jl:63-77    (PATHSolver.solve_mcp + check)
+#   solve_qp(Q, q, A, l, u; solver=:PATH)           src/qp_processing.jl:12-33
+#
+# and adds a batched entry (solve_avi_batch) for many independent node-AVIs.
+#
+# Usage from the reference (one line in src/QuadraticProgramNetworks.jl after the includes):
+#     include(joinpath(ENV["QPN_HIP_HOME"], "julia", "QPNHip.jl")); using .QPNHip; QPNHip.install!()
+module QPNHip
+
+using SparseArrays, LinearAlgebra
+
+const LIB = get(ENV, "QPN_HIP_LIB", joinpath(@__DIR__, "..", "quadraticprogramnetworks.jl_amd", "libqpn_hip.so"))
+
+const QPN_MEM_HOST = Cint(0)
+const QPN_SUCCESS = Int32(1)
+
+struct AviOpts                # qpn_avi_opts, include/qpn_hip.h
+    check_tol::Cdouble
+    piv_tol::Cdouble
+    feas_tol::Cdouble
+    comp_tol::Cdouble
+    max_pivots::Int32
+    reserved::Int32
+end
+
+const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+
+function ctx()
+    if CTX[] == C_NULL
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:qpn_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), parse(Cint, get(ENV, "QPN_HIP_DEVICE", "0")), h)
+        rc == 0 || error("qpn_ctx_create failed: " * unsafe_string(ccall((:qpn_strerror, LIB), Cstring, (Cint,), rc)))
+        CTX[] = h[]
+        atexit(() -> ccall((:qpn_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), CTX[]))
+    end
+    CTX[]
+end
+
+function default_opts()
+    o = Ref(AviOpts(0, 0, 0, 0, 0, 0))
+    ccall((:qpn_avi_default_opts, LIB), Cvoid, (Ref{AviOpts},), o)
+    o[]
+end
+
+"""
+    solve_mcp(M, q, l, u, z0) -> (status::Int32, z, info)
+
+Same argument list as `PATHSolver.solve_mcp(M, q, l, u, z0)` at src/avi.jl:64: `M` is the
+reference's own `SparseMatrixCSC{Float64,Int32}`; its `colptr/rowval/nzval` (1-based) go to the
+library as they are.  Julia owns every array; the callee reads them only during the call.
+"""
+function solve_mcp(M::SparseMatrixCSC{Float64,Int32}, q::Vector{Float64}, l::Vector{Float64},
+                   u::Vector{Float64}, z0::Vector{Float64})
+    N = Int32(size(M, 1))
+    z = copy(z0)
+    status = Ref{Int32}(0); resid = Ref{Cdouble}(0); pivots = Ref{Int32}(0)
+    o = Ref(default_opts())
+    rc = ccall((:qpn_solve_mcp_csc, LIB), Cint,
+               (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cdouble}, Ref{Int32}, Ref{Cdouble}, Ref{Int32}, Ref{AviOpts}),
+               ctx(), N, M.colptr, M.rowval, M.nzval, q, l, u, z, status, resid, pivots, o)
+    rc == 0 || error("qpn_solve_mcp_csc: " * unsafe_string(ccall((:qpn_ctx_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx())))
+    (status[], z, (; resid = resid[], pivots = pivots[]))
+end
+
+"""
+    solve_avi_batch(M, q, l, u, z0; kind=nothing) -> (z, status, resid, pivots, active)
+
+`M` is N×N×batch (Julia column-major = the ABI layout) or N×N (shared, strideM = 0); `q,l,u,z0`
+are N×batch.  `kind` (N or N×batch, UInt8) marks GAVI rows (second condition, src/avi.jl:22-24).
+"""
+function solve_avi_batch(M::Array{Float64}, q::Matrix{Float64}, l::Matrix{Float64}, u::Matrix{Float64},
+                         z0::Matrix{Float64}; kind::Union{Nothing,Array{UInt8}} = nothing)
+    N, batch = size(q)
+    strideM = ndims(M) == 3 ? Int64(N * N) : Int64(0)
+    z = copy(z0)
+    status = zeros(Int32, batch); resid = zeros(batch); pivots = zeros(Int32, batch); active = zeros(UInt8, N, batch)
+    kp = kind === nothing ? Ptr{UInt8}(C_NULL) : pointer(kind)
+    sk = kind === nothing ? Int64(0) : (ndims(kind) == 2 ? Int64(N) : Int64(0))
+    o = Ref(default_opts())
+    GC.@preserve kind begin
+        rc = ccall((:qpn_solve_avi_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Int32, Int32, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Int64,
+                    Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{UInt8}, Ref{AviOpts}, Cint),
+                   ctx(), Int32(batch), Int32(N), M, strideM, q, l, u, kp, sk, z, status, resid, pivots, active, o, QPN_MEM_HOST)
+        rc == 0 || error("qpn_solve_avi_batch failed ($rc)")
+    end
+    (z, status, resid, pivots, active)
+end
+
+# ---- drop-in bodies -------------------------------------------------------------------------------
+# src/avi.jl:63-77 with the PATH call replaced; StatusCode / check_avi_solution stay the reference's.
+function solve_avi_hip(QPN, avi, z0, w; convergence_tolerance = 1e-10)
+    (st, z, info) = solve_mcp(avi.M, avi.N * w + avi.o, avi.l, avi.u, collect(Float64, z0))
+    (; sol_bad, degree, r) = QPN.check_avi_solution(avi, z, w)          # kept: src/avi.jl:71
+    sol_bad && return (; z, status = QPN.FAILURE, info = (; path_status = st, info))
+    status = st == QPN_SUCCESS ? QPN.SUCCESS : QPN.FAILURE
+    (; z, status, info = (; path_status = st, info))
+end
+
+# src/qp_processing.jl:12-33 (PATH branch): same MCP, same error convention (:30).
+function solve_qp_hip(Q, q, A, l, u)
+    n = size(Q, 1); m = size(A, 1)
+    M = SparseMatrixCSC{Float64,Int32}([Q -A' spzeros(n, m); A spzeros(m, m) -sparse(1.0I, m, m); spzeros(m, n) sparse(1.0I, m, m) spzeros(m, m)])
+    (st, z, _) = solve_mcp(M, [q; zeros(2m)], [fill(-Inf, n + m); l], [fill(Inf, n + m); u], zeros(2m + n))
+    st == QPN_SUCCESS || error("Solver failure. Status value is $st")
+    z[1:n]
+end
+
+"""
+Overrides `solve_avi` (src/avi.jl:63-77) of the loaded QuadraticProgramNetworks module.  The PATH
+branch of `solve_qp` (src/qp_processing.jl:12-33) shares its function with the OSQP branch, so it is
+rerouted by the three-line source edit shown in INTEGRATION.md (calls `QPNHip.solve_qp_hip`).
+"""
+function install!(QPN = Main.QuadraticProgramNetworks)
+    @eval QPN solve_avi(avi::AVI, z0, w; convergence_tolerance = 1e-10) = $(solve_avi_hip)($QPN, avi, z0, w; convergence_tolerance)
+    nothing
+end
+
+end # module
