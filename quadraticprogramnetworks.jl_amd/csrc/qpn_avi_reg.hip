@@ -159,55 +159,86 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 #define M_DECL(k, l) double E(k, l) = 0.0;
     QPN_FOR_KL(M_DECL)
 #undef M_DECL
-    // Software-pipelined: the (coalesced, 512 B per instruction) loads of column block k+1 are in
-    // flight while block k is transposed through the LDS stage.  Element idx of a block lives at
-    // (col, row) = (idx / N, idx % N); a lane fetches idx = lane + 64 s, s < BS.
-    double pf[BS];
+    // Software-pipelined, two column blocks deep: the coalesced (512 B per instruction) loads of
+    // blocks k+1..k+2 are in flight while block k is transposed through the LDS stage (an HBM
+    // round trip under load is several thousand cycles; one block of transposition is ~2 K).
+    // Element idx of a block lives at (col, row) = (idx / N, idx % N); a lane fetches
+    // idx = lane + 64 s, s < BS.  The two buffers are named scalars (static rotation).
     double mabs = 0.0;                       // running max |M_ij| of the elements this lane moves
-    auto issue_loads = [&](int cbk) {
-        const int col0 = BS * cbk;
-        const int ncols = (N - col0) < BS ? (N - col0) : BS;
-        const int cnt = col0 < N ? ncols * N : 0;
-        const double *base = Mg + (size_t)col0 * N;
-#pragma unroll
-        for (int sidx = 0; sidx < BS; ++sidx) {
-            const int idx = lane + WAVE * sidx;
-            pf[sidx] = idx < cnt ? base[idx] : 0.0;
-        }
-    };
-    issue_loads(0);
-    for (int cbk = 0; cbk < 8; ++cbk) {
-        const int col0 = BS * cbk;
-        if (col0 >= N) break;
-        const int ncols = (N - col0) < BS ? (N - col0) : BS;
-        const int cnt = ncols * N;
-        {
-            int row = lane, col = 0;
-            while (row >= N) { row -= N; col++; }
-#pragma unroll
-            for (int sidx = 0; sidx < BS; ++sidx) {
-                const int idx = lane + WAVE * sidx;
-                if (idx < cnt) { stage[col * NP + G::pidx(row)] = pf[sidx]; mabs = fmax(mabs, fabs(pf[sidx])); }
-                row += WAVE;
-                while (row >= N) { row -= N; col++; }
-            }
-        }
-        if (cbk + 1 < 8) issue_loads(cbk + 1);
-        __syncthreads();
-        // initial basic values  xb = q + M z_nb, columns in ascending order (as the checker)
-        for (int l = 0; l < ncols; ++l) {
-            const double zj = snb[col0 + l];
-            if (zj != 0.0 && act) xb = fma(stage[l * NP + G::pidx(lane)], zj, xb);
-        }
-        if (cb == cbk) {
+#define PF(B, sidx) pf##B##_##sidx
+#define M_PFDECL(sidx) double PF(a, sidx) = 0.0, PF(b, sidx) = 0.0;
+    QPN_FOR_1(M_PFDECL)
+#undef M_PFDECL
+#define QPN_ISSUE(B, cbk)                                                                       \
+    {                                                                                           \
+        const int col0_ = BS * (cbk);                                                           \
+        const int nc_ = (N - col0_) < BS ? (N - col0_) : BS;                                    \
+        const int cnt_ = col0_ < N ? nc_ * N : 0;                                               \
+        const double *base_ = Mg + (size_t)col0_ * N;                                           \
+        if constexpr (0 < BS) PF(B, 0) = (lane + WAVE * 0 < cnt_) ? base_[lane + WAVE * 0] : 0.0; \
+        if constexpr (1 < BS) PF(B, 1) = (lane + WAVE * 1 < cnt_) ? base_[lane + WAVE * 1] : 0.0; \
+        if constexpr (2 < BS) PF(B, 2) = (lane + WAVE * 2 < cnt_) ? base_[lane + WAVE * 2] : 0.0; \
+        if constexpr (3 < BS) PF(B, 3) = (lane + WAVE * 3 < cnt_) ? base_[lane + WAVE * 3] : 0.0; \
+        if constexpr (4 < BS) PF(B, 4) = (lane + WAVE * 4 < cnt_) ? base_[lane + WAVE * 4] : 0.0; \
+        if constexpr (5 < BS) PF(B, 5) = (lane + WAVE * 5 < cnt_) ? base_[lane + WAVE * 5] : 0.0; \
+        if constexpr (6 < BS) PF(B, 6) = (lane + WAVE * 6 < cnt_) ? base_[lane + WAVE * 6] : 0.0; \
+        if constexpr (7 < BS) PF(B, 7) = (lane + WAVE * 7 < cnt_) ? base_[lane + WAVE * 7] : 0.0; \
+    }
+#define QPN_PUT(B, sidx)                                                                        \
+    if constexpr ((sidx) < BS) {                                                                \
+        if (lane + WAVE * (sidx) < cnt) {                                                       \
+            stage[col * NP + G::pidx(row)] = PF(B, sidx);                                       \
+            mabs = fmax(mabs, fabs(PF(B, sidx)));                                               \
+        }                                                                                       \
+        row += WAVE;                                                                            \
+        while (row >= N) { row -= N; col++; }                                                   \
+    }
+#define QPN_PUT_FULL(B, sidx)   /* N == 64: element (col, row) = (sidx, lane) */                 \
+    if constexpr ((sidx) < BS) {                                                                \
+        stage[(sidx) * NP + G::pidx(lane)] = PF(B, sidx);                                       \
+        mabs = fmax(mabs, fabs(PF(B, sidx)));                                                   \
+    }
+#define QPN_ROUND(B, cbk)                                                                       \
+    if (BS * (cbk) < N) {                                                                       \
+        const int col0 = BS * (cbk);                                                            \
+        const int ncols = (N - col0) < BS ? (N - col0) : BS;                                    \
+        const int cnt = ncols * N;                                                              \
+        if (full) {                                                                             \
+            QPN_PUT_FULL(B, 0) QPN_PUT_FULL(B, 1) QPN_PUT_FULL(B, 2) QPN_PUT_FULL(B, 3)         \
+            QPN_PUT_FULL(B, 4) QPN_PUT_FULL(B, 5) QPN_PUT_FULL(B, 6) QPN_PUT_FULL(B, 7)         \
+        } else {                                                                                \
+            int row = lane, col = 0;                                                            \
+            while (row >= N) { row -= N; col++; }                                               \
+            QPN_PUT(B, 0) QPN_PUT(B, 1) QPN_PUT(B, 2) QPN_PUT(B, 3)                             \
+            QPN_PUT(B, 4) QPN_PUT(B, 5) QPN_PUT(B, 6) QPN_PUT(B, 7)                             \
+        }                                                                                       \
+        if ((cbk) + 2 < 8) QPN_ISSUE(B, (cbk) + 2)                                              \
+        __syncthreads();                                                                        \
+        /* initial basic values xb = q + M z_nb, columns in ascending order (as the checker) */ \
+        for (int l = 0; l < ncols; ++l) {                                                       \
+            const double zj = snb[col0 + l];                                                    \
+            if (zj != 0.0 && act) xb = fma(stage[l * NP + G::pidx(lane)], zj, xb);              \
+        }                                                                                       \
+        if (cb == (cbk)) { if (full) { QPN_FOR_KL(M_LOAD_FULL) } else { QPN_FOR_KL(M_LOAD) } }  \
+        __syncthreads();                                                                        \
+    }
 #define M_LOAD(k, l)                                                                            \
     if constexpr ((k) < BS && (l) < BS)                                                         \
         E(k, l) = (BS * ra + (k) < N && (l) < ncols) ? stage[(l) * NP + ra * PB + (k)] : 0.0;
-            QPN_FOR_KL(M_LOAD)
+#define M_LOAD_FULL(k, l)                                                                       \
+    if constexpr ((k) < BS && (l) < BS) E(k, l) = stage[(l) * NP + ra * PB + (k)];
+    const bool full = N == WAVE && BS == 8;
+    QPN_ISSUE(a, 0)
+    QPN_ISSUE(b, 1)
+    QPN_ROUND(a, 0) QPN_ROUND(b, 1) QPN_ROUND(a, 2) QPN_ROUND(b, 3)
+    QPN_ROUND(a, 4) QPN_ROUND(b, 5) QPN_ROUND(a, 6) QPN_ROUND(b, 7)
+#undef M_LOAD_FULL
+#undef QPN_PUT_FULL
 #undef M_LOAD
-        }
-        __syncthreads();
-    }
+#undef QPN_ROUND
+#undef QPN_PUT
+#undef QPN_ISSUE
+#undef PF
     STAMP(0);   // setup + load
     int pivots = 0;
     int pivots_init = 0;
@@ -257,16 +288,19 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                 if (cb == (JB)) { QPN_FOR_K(M_FXC, JJ) }                                            \
                 if (ra == (JB)) { QPN_FOR_L(M_FXR, JJ) }                                            \
                 __syncthreads();                                                                    \
-                const double piv = udbl(ucol[G::pidx(e_)]);                                         \
+                /* one LDS round trip: pivot, this row-lane's column entry, u and raw v blocks */   \
+                const double pivr = ucol[G::pidx(e_)];                                              \
+                const double cmf = lane < NB ? ucol[G::pidx(lane)] : 0.0;                           \
+                QPN_FOR_1(M_FLDU)                                                                   \
+                QPN_FOR_1(M_FLDVR)                                                                  \
+                const double piv = udbl(pivr);                                                      \
                 if (!ubool(fabs(piv) >= diag_thr)) { fast_ok = false; }                             \
                 else {                                                                              \
-                    const double cmf = lane < NB ? ucol[G::pidx(lane)] : 0.0;                       \
                     const double inv = 1.0 / piv;                                                   \
                     const double delta = udbl((0.0 - readlane_f64(xb, e_)) * inv);                  \
                     const double ent = udbl(readlane_f64(nbval, e_) + delta);                       \
                     xb = fma(delta, cmf, xb);                                                       \
                     if (lane == e_) { xb = ent; rowvar = e_; colvar = N + e_; nbval = 0.0; lo = -QINF; hi = QINF; } \
-                    QPN_FOR_1(M_FLDU)                                                               \
                     QPN_FOR_1(M_FLDV)                                                               \
                     if (cb == (JB)) v_##JJ##_f = -inv;                                              \
                     QPN_FOR_KL(M_FFMA)                                                              \
@@ -281,7 +315,8 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 #define M_FXC(k, L) if constexpr ((k) < BS) ucol[ra * PB + (k)] = E(k, L);
 #define M_FXR(K, l) if constexpr ((l) < BS) vrow[cb * PB + (l)] = E(K, l);
 #define M_FLDU(k) double u_##k##_f = 0.0; if constexpr ((k) < BS) u_##k##_f = ucol[ra * PB + (k)];
-#define M_FLDV(l) double v_##l##_f = 0.0; if constexpr ((l) < BS) v_##l##_f = vrow[cb * PB + (l)] * inv;
+#define M_FLDVR(l) double vr_##l##_f = 0.0; if constexpr ((l) < BS) vr_##l##_f = vrow[cb * PB + (l)];
+#define M_FLDV(l) double v_##l##_f = vr_##l##_f * inv;
 #define M_FFMA(k, l) if constexpr ((k) < BS && (l) < BS) E(k, l) = fma(-u_##k##_f, v_##l##_f, E(k, l));
 #define M_FFC(k, L) if constexpr ((k) < BS) E(k, L) = u_##k##_f * inv;
 #define M_FFR(K, l) if constexpr ((l) < BS) E(K, l) = -v_##l##_f;
@@ -296,11 +331,13 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 #undef JBX
         }
         pivots_init = pivots_fast;
+        STAMP(6);   // crash fast path
 #undef M_FAST_ROW
 #undef M_FFR
 #undef M_FFC
 #undef M_FFMA
 #undef M_FLDV
+#undef M_FLDVR
 #undef M_FLDU
 #undef M_FXR
 #undef M_FXC

@@ -31,7 +31,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.float64)
 piv = res["pivots"].cpu().numpy().mean()
-names = ["setup+load", "loop control", "extract column", "pivot selection", "rank-1 update", "readback+check"]
+names = ["setup+load", "loop control", "extract column", "pivot selection", "rank-1 update", "readback+check", "crash fast path"]
 tot = s.sum(axis=1).mean()
 print(f"mean pivots {piv:.1f}, mean cycles per solve {tot:.0f} ({tot/piv:.0f} per pivot)")
 for i, nm in enumerate(names):
