@@ -40,13 +40,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nodes", type=int, default=NODES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -73,27 +75,27 @@ def main():
                                        t(colmajor(B)), t(l), t(u), t(w_host))
     x_all = torch.zeros((args.nodes, n), dtype=torch.float64, device=dev)
     counts = [sharding.node_range(args.nodes, world, r) for r in range(world)]
-    z0 = torch.zeros((cnt, N), dtype=torch.float64, device=dev)
-
     ev_pairs = []
+    bufs = {"asm": None, "sol": None}      # output buffers are allocated once and reused
 
     def step(record):
-        Mc, q, lo, hi, kind = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw)
+        bufs["asm"] = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["asm"])
+        Mc, q, lo, hi, kind = bufs["asm"]
         if record:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        res = eng.solve_avi_batch(Mc, q, lo, hi, z0=z0, kind=kind)
+        res = bufs["sol"] = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind, out=bufs["sol"])   # cold start
         if record:
             e1.record(); ev_pairs.append((e0, e1))
         xloc = res["z"][:, :n].contiguous()
-        if world > 1:
+        if use_dist:
             sharding.all_gather_primal(x_all, xloc, counts, dist)
         else:
             x_all[lo_id:hi_id].copy_(xloc)
         return res
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -109,7 +111,7 @@ def main():
     solved_local = int((res["status"] == 1).sum().item())
     max_resid = float(res["resid"].max().item())
     tt = torch.tensor([dt, float(solved_local), max_resid], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, solved, max_resid = float(mx[0]), int(sm[1]), float(mx[2])
@@ -138,7 +140,7 @@ def main():
             "config": {"workload": f"synthetic {args.nodes}-node x {n}-var two-level QPNet "
                                    f"(n=m={n}, N_red={N}, p={p}; BASELINE.json configs[3]); step = "
                                    "assemble + cold-start AVI solve + check + active sets"
-                                   + (" + RCCL all-gather of primals" if world > 1 else ""),
+                                   + (" + RCCL all-gather of primals" if use_dist else ""),
                        "nodes": args.nodes, "n": n, "m": m, "params": p,
                        "sharding": f"node ranges over {world} GPU(s)",
                        "max_resid": max_resid, "solved": solved},
@@ -150,7 +152,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Q, R, qd, A, B, l, u, w_host)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -46,13 +46,16 @@ enum { QPN_ROW_STD = 0, QPN_ROW_GAVI = 1 };
 
 typedef struct qpn_ctx qpn_ctx;
 
+/* qpn_avi_opts.flags */
+#define QPN_AVI_FLAG_COLD_START 1 /* ignore the z input: every item starts from z0 = 0 (no reset pass) */
+
 typedef struct {
     double check_tol;  /* post-check tolerance, 1e-6       (src/avi.jl:148)                 */
     double piv_tol;    /* smallest admissible pivot, 1e-11                                   */
     double feas_tol;   /* basic infeasibility treated as zero, 1e-12                         */
     double comp_tol;   /* active-set classification tolerance, 1e-2 (src/avi_solutions.jl:511) */
     int32_t max_pivots; /* <= 0: 50*N + 100 (cf. PATH limits at src/avi.jl:67-70)             */
-    int32_t reserved;
+    int32_t flags;      /* QPN_AVI_FLAG_* (0 by default)                                        */
 } qpn_avi_opts;
 
 /* ---- context ------------------------------------------------------------------- */
@@ -81,7 +84,7 @@ void qpn_avi_default_opts(qpn_avi_opts *opts);
  *   status  [batch] int32 (QPN_SUCCESS..QPN_FAILURE), resid [batch] natural-map residual,
  *   pivots  [batch] int32, active [batch][N] uint8: bit (c-1) set for code c of
  *           src/avi_solutions.jl:511-562 on STD rows, bit (c+3) on GAVI rows (codes 5..8).
- *   Any of resid/pivots/active may be NULL.  N <= 64 in ABI version 1. */
+ *   Any of resid/pivots/active may be NULL.  N <= 1024 in ABI version 1 (N <= 64: one wavefront per item; larger: one workgroup). */
 int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, int64_t strideM,
                         const double *q, const double *l, const double *u, const uint8_t *kind,
                         int64_t stride_kind, double *z, int32_t *status, double *resid,

@@ -25,7 +25,7 @@ struct AviOpts                # qpn_avi_opts, include/qpn_hip.h
     feas_tol::Cdouble
     comp_tol::Cdouble
     max_pivots::Int32
-    reserved::Int32
+    flags::Int32
 end
 
 const CTX = Ref{Ptr{Cvoid}}(C_NULL)

@@ -18,6 +18,7 @@ ABI_SYMBOLS = (
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
+AVI_FLAG_COLD_START = 1
 
 
 class LibraryMissing(RuntimeError):
@@ -26,7 +27,7 @@ class LibraryMissing(RuntimeError):
 
 class AviOpts(C.Structure):
     _fields_ = [("check_tol", C.c_double), ("piv_tol", C.c_double), ("feas_tol", C.c_double),
-                ("comp_tol", C.c_double), ("max_pivots", C.c_int32), ("reserved", C.c_int32)]
+                ("comp_tol", C.c_double), ("max_pivots", C.c_int32), ("flags", C.c_int32)]
 
 
 _lib = None

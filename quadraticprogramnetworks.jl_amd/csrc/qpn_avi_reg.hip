@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
     if (act) {
         if (gk) { colvar = N + lane; rowvar = lane; }
         else {
-            double z0 = a.z[vo + lane];
+            double z0 = (a.flags & QPN_AVI_FLAG_COLD_START) ? 0.0 : a.z[vo + lane];
             if (isnan(z0)) z0 = 0.0;
             if (freek) v0 = z0;
             else {
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 
     int c = XC;
     double sigma = -1.0, self_lim = 0.0;
+    double elo = 0.0, ehi = QINF;             // admissible interval of the entering variable (stage 2)
     const double slack = 1e-10;
     const double ptol = a.piv_tol;
     for (;;) {
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
             }
             cNval = theta0;
             c = XC; sigma = -1.0; self_lim = theta0;
+            elo = 0.0; ehi = QINF;            // the artificial: [0, inf)
             status = QPN_MAX_ITERS;
             stage_ = 2;
             continue;
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                 if (c < 0) { status = QPN_FAILURE; break; }
                 sigma = au ? -1.0 : 1.0;
                 self_lim = QINF;
+                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }   // d_k of an ordinary pair
                 __syncthreads();
                 continue;
             }
@@ -531,23 +534,25 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         }
         if (lane == r) vrow[NP] = tcol;
         __syncthreads();
-        // row-vector updates first (cm is dead afterwards): basic values and the extra column
         {
-            const double vx = (c == XC) ? -inv_u : vrow[NP] * inv_u;
-            double xbn = fma(delta_u, cm, xb);
-            double tcn = (c == XC) ? cm * inv_u : fma(-cm, vx, tcol);
-            if (lane == r) { xbn = enter_val; tcn = (c == XC) ? inv_u : -vx; }
-            xb = xbn; tcol = tcn;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            // u = pivot column block, v = scaled pivot row block; the slot of column c carries -inv_u
+            // one LDS round trip: extra-column entry of the pivot row, u = pivot column block,
+            // v = raw pivot row block
+            const double vxr = vrow[NP];
 #define M_LDU(k) double u_##k = 0.0; if constexpr ((k) < BS) u_##k = ucol[ra * PB + (k)];
             QPN_FOR_1(M_LDU)
 #undef M_LDU
 #define M_LDV(l) double v_##l = 0.0; if constexpr ((l) < BS) v_##l = vrow[cb * PB + (l)];
             QPN_FOR_1(M_LDV)
 #undef M_LDV
+            // row-vector updates (cm is dead afterwards): basic values and the extra column
+            {
+                const double vx = (c == XC) ? -inv_u : vxr * inv_u;
+                double xbn = fma(delta_u, cm, xb);
+                double tcn = (c == XC) ? cm * inv_u : fma(-cm, vx, tcol);
+                if (lane == r) { xbn = enter_val; tcn = (c == XC) ? inv_u : -vx; }
+                xb = xbn; tcol = tcn;
+            }
+            // the slot of column c carries -inv_u (row fix-up below)
 #define M_SCV(l) if constexpr ((l) < BS) { const double sc = v_##l * inv_u; v_##l = (BS * cb + (l) == c) ? -inv_u : sc; }
             QPN_FOR_1(M_SCV)
 #undef M_SCV
@@ -580,8 +585,8 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
         __builtin_amdgcn_sched_barrier(0);
         // bookkeeping: row r now holds the entering variable, column c the leaving one
         const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
-        double nlo, nhi;
-        interval_uni(ve, N, sl, su, sat, nlo, nhi);
+        double nlo = elo, nhi = ehi;          // stage 2: known when the entering variable was chosen
+        if (stage_ == 0) interval_uni(ve, N, sl, su, sat, nlo, nhi);
         if (lane == r) { rowvar = ve; lo = nlo; hi = nhi; }
         if (c == XC) { cNvar = vl; cNval = leave_u; }
         else if (lane == c) { colvar = vl; nbval = leave_u; }
@@ -604,6 +609,11 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                 vn = N + k;
                 sigma = au ? -1.0 : 1.0;
                 self_lim = QINF;
+                // interval of the entering multiplier d_k (same rule as interval_uni)
+                if (ubool(Lk == Uk)) { elo = -QINF; ehi = QINF; }
+                else if (ubool(Lk == -QINF && Uk == QINF)) { elo = 0.0; ehi = 0.0; }
+                else if (au) { elo = -QINF; ehi = 0.0; }
+                else { elo = 0.0; ehi = QINF; }
             } else {
                 const int k = vl - N;
                 const double Lk = udbl(sl[k]), Uk = udbl(su[k]);
@@ -611,6 +621,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
                 sigma = uni(sat[k]) ? -1.0 : 1.0;
                 self_lim = Uk - Lk;
                 if (ubool(Lk == -QINF && Uk == QINF)) { self_lim = QINF; sigma = 1.0; }
+                elo = Lk; ehi = Uk;           // the bounded member p_k enters
             }
             c = col_of(vn);
             if (c < 0) { status = QPN_FAILURE; break; }

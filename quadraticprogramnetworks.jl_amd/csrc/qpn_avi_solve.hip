@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
     if (act) {
         if (gk) { colvar = N + lane; rowvar = lane; }
         else {
-            double z0 = a.z[vo + lane];
+            double z0 = (a.flags & QPN_AVI_FLAG_COLD_START) ? 0.0 : a.z[vo + lane];
             if (isnan(z0)) z0 = 0.0;
             if (freek) v0 = z0;
             else {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(WAVE) void avi_solve_lds1(AviBatchArgs a)
 
 } // namespace
 
-int qpn_avi_max_n() { return 64; }
+int qpn_avi_max_n() { return qpn_avi_big_max_n(); }   // N <= 64: one wavefront; larger: qpn_avi_big.hip
 
 // Kernel choice: the register-tableau kernel (qpn_avi_reg.hip) is the production path; the
 // LDS-tableau kernel of this file stays selectable (QPN_AVI_KERNEL=lds1) for A/B measurements.

@@ -93,7 +93,7 @@ void qpn_avi_default_opts(qpn_avi_opts *o)
     o->feas_tol = 1e-12;
     o->comp_tol = 1e-2;    // src/avi_solutions.jl:511
     o->max_pivots = 0;
-    o->reserved = 0;
+    o->flags = 0;
 }
 
 int qpn_ctx_create(int device_id, qpn_ctx **out)
@@ -168,7 +168,8 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
     if (!M || !q || !l || !u || !z || !status) return fail_arg(ctx, "qpn_solve_avi_batch: null pointer");
     if (strideM != 0 && strideM < (int64_t)N * N) return fail_arg(ctx, "qpn_solve_avi_batch: strideM < N*N");
     if (kind && stride_kind != 0 && stride_kind < N) return fail_arg(ctx, "qpn_solve_avi_batch: stride_kind < N");
-    if (N > qpn_avi_max_n()) { ctx->last_error = "qpn_solve_avi_batch: N > 64 not supported by ABI v1"; return QPN_ERR_SIZE; }
+    if (N > qpn_avi_max_n()) { ctx->last_error = "qpn_solve_avi_batch: N > 1024 not supported by ABI v1"; return QPN_ERR_SIZE; }
+    const bool big = N > 64;   // one workgroup per item, dictionary in a workspace (qpn_avi_big.hip)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     qpn_avi_opts o;
     if (opts) o = *opts; else qpn_avi_default_opts(&o);
@@ -177,6 +178,7 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
     a.batch = batch; a.N = N; a.strideM = strideM; a.stride_kind = kind ? stride_kind : 0;
     a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
     a.max_pivots = o.max_pivots;
+    a.flags = o.flags;
 
     if (mem == QPN_MEM_DEVICE) {
         a.M = M; a.q = q; a.l = l; a.u = u; a.kind = kind; a.z = z; a.status = status;
@@ -184,7 +186,16 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
 #ifdef QPN_STAMPS
         a.stamps = g_stamps;
 #endif
-        HIPCHK(ctx, qpn_launch_avi_solve(a, ctx->stream));
+        if (big) {
+            double *wsp;
+            Carver cvb(ctx);
+            cvb.add((void **)&wsp, qpn_avi_big_workspace_bytes(batch, N));
+            int rcb = cvb.commit();
+            if (rcb != QPN_OK) return rcb;
+            HIPCHK(ctx, qpn_launch_avi_solve_big(a, wsp, ctx->stream));
+        } else {
+            HIPCHK(ctx, qpn_launch_avi_solve(a, ctx->stream));
+        }
         return QPN_OK;
     }
     if (mem != QPN_MEM_HOST) return fail_arg(ctx, "qpn_solve_avi_batch: bad mem kind");
@@ -198,6 +209,8 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
     cv.add((void **)&du, bN * 8); cv.add((void **)&dz, bN * 8); cv.add((void **)&dres, (size_t)batch * 8);
     cv.add((void **)&dst, (size_t)batch * 4); cv.add((void **)&dpv, (size_t)batch * 4);
     cv.add((void **)&dact, bN); cv.add((void **)&dk, kBytes ? kBytes : 1);
+    double *wsb = nullptr;
+    if (big) cv.add((void **)&wsb, qpn_avi_big_workspace_bytes(batch, N));
     int rc = cv.commit();
     if (rc != QPN_OK) return rc;
     hipStream_t s = ctx->stream;
@@ -209,7 +222,8 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
     if (kind) HIPCHK(ctx, hipMemcpyAsync(dk, kind, kBytes, hipMemcpyHostToDevice, s));
     a.M = dM; a.q = dq; a.l = dl; a.u = du; a.kind = kind ? dk : nullptr; a.z = dz; a.status = dst;
     a.resid = dres; a.pivots = dpv; a.active = dact;
-    HIPCHK(ctx, qpn_launch_avi_solve(a, s));
+    if (big) HIPCHK(ctx, qpn_launch_avi_solve_big(a, wsb, s));
+    else HIPCHK(ctx, qpn_launch_avi_solve(a, s));
     HIPCHK(ctx, hipMemcpyAsync(z, dz, bN * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(status, dst, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
     if (resid) HIPCHK(ctx, hipMemcpyAsync(resid, dres, (size_t)batch * 8, hipMemcpyDeviceToHost, s));

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/qpn_hip.h"
@@ -23,6 +24,7 @@ struct AviBatchArgs {
     uint8_t *active;
     double check_tol, piv_tol, feas_tol, comp_tol;
     int32_t max_pivots;
+    int32_t flags;   // QPN_AVI_FLAG_*
     // optional gate: item b runs only when only_if[b] == only_if_value (others are left untouched)
     const int32_t *only_if;
     int32_t only_if_value;
@@ -34,6 +36,11 @@ struct AviBatchArgs {
 hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream);      // dispatcher
 hipError_t qpn_launch_avi_solve_lds1(const AviBatchArgs &a, hipStream_t stream); // LDS-tableau kernel
 int qpn_avi_max_n();
+
+// qpn_avi_big.hip: 64 < N <= 1024, one workgroup per item, dictionary in an HBM workspace
+int qpn_avi_big_max_n();
+size_t qpn_avi_big_workspace_bytes(int batch, int N);
+hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hipStream_t stream);
 
 // qpn_avi_reg.hip
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream);  // register-tableau kernel

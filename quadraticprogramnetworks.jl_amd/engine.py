@@ -108,11 +108,13 @@ class Engine:
         return np.empty(shape, dtype=dtype)
 
     # -- (A2+A3+A9) ------------------------------------------------------------------------
-    def solve_avi_batch(self, Mc, q, l, u, z0=None, kind=None, opts=None, want_active=True):
+    def solve_avi_batch(self, Mc, q, l, u, z0=None, kind=None, opts=None, want_active=True, out=None):
         """Batched AVI solve; replaces PATHSolver.solve_mcp (src/avi.jl:64-70) per item.
 
         Mc: (batch, N, N) column-major per item, or (N, N) shared.  q, l, u: (batch, N).
-        kind: None | (N,) shared | (batch, N) uint8.  Returns dict(z, status, resid, pivots, active).
+        kind: None | (N,) shared | (batch, N) uint8.  z0 = None is a cold start (z0 = 0, handled in
+        the kernel: no reset pass).  `out` may carry the dict of a previous call to reuse its
+        buffers.  Returns dict(z, status, resid, pivots, active).
         """
         dev = self._mode(Mc, q, l, u, z0, kind)
         self._bind_stream(dev)
@@ -124,15 +126,26 @@ class Engine:
         batch, N = q.shape
         strideM = 0 if Mc.ndim == 2 else N * N
         sk = 0 if (kind is None or kind.ndim == 1) else N
-        if z0 is None:
-            z = torch.zeros_like(q) if dev else np.zeros_like(q)
-        else:
-            z = z0.clone() if dev else np.array(z0, dtype=np.float64, order="C", copy=True)
-        status = self._alloc(dev, (batch,), np.int32)
-        resid = self._alloc(dev, (batch,), np.float64)
-        pivots = self._alloc(dev, (batch,), np.int32)
-        active = self._alloc(dev, (batch, N), np.uint8) if want_active else None
         o = opts if opts is not None else self.default_opts()
+        if out is not None and out["z"].shape == q.shape:
+            z, status, resid, pivots, active = out["z"], out["status"], out["resid"], out["pivots"], out["active"]
+        else:
+            z = self._alloc(dev, (batch, N), np.float64)
+            status = self._alloc(dev, (batch,), np.int32)
+            resid = self._alloc(dev, (batch,), np.float64)
+            pivots = self._alloc(dev, (batch,), np.int32)
+            active = self._alloc(dev, (batch, N), np.uint8) if want_active else None
+        if z0 is None:
+            if opts is None:
+                o.flags |= _lib.AVI_FLAG_COLD_START
+            elif dev:
+                z.zero_()
+            else:
+                z[...] = 0.0
+        elif dev:
+            z.copy_(z0)
+        else:
+            z[...] = np.asarray(z0, dtype=np.float64)
         rc = self.lib.qpn_solve_avi_batch(self.ctx, batch, N, _ptr(Mc), strideM, _ptr(q), _ptr(l),
                                           _ptr(u), _ptr(kind), sk, _ptr(z), _ptr(status),
                                           _ptr(resid), _ptr(pivots), _ptr(active), C.byref(o),
@@ -189,9 +202,10 @@ class Engine:
         return mask
 
     # -- (A5+A6) ---------------------------------------------------------------------------
-    def assemble_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w):
+    def assemble_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w, out=None):
         """Per-node reduced KKT blocks.  Qc (batch,n,n), Rc (batch,p,n), Ac (batch,n,m),
-        Bc (batch,p,m): all column-major per item (see ``colmajor``); w (p,) shared or (batch,p)."""
+        Bc (batch,p,m): all column-major per item (see ``colmajor``); w (p,) shared or (batch,p).
+        `out` may carry the tuple of a previous call to reuse its buffers."""
         dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, w)
         self._bind_stream(dev)
         if not dev:
@@ -201,11 +215,14 @@ class Engine:
         p = w.shape[-1]
         sw = 0 if w.ndim == 1 else p
         N = n + m
-        Mout = self._alloc(dev, (batch, N, N), np.float64)
-        qout = self._alloc(dev, (batch, N), np.float64)
-        lout = self._alloc(dev, (batch, N), np.float64)
-        uout = self._alloc(dev, (batch, N), np.float64)
-        kind = self._alloc(dev, (batch, N), np.uint8)
+        if out is not None and out[1].shape == (batch, N):
+            Mout, qout, lout, uout, kind = out
+        else:
+            Mout = self._alloc(dev, (batch, N, N), np.float64)
+            qout = self._alloc(dev, (batch, N), np.float64)
+            lout = self._alloc(dev, (batch, N), np.float64)
+            uout = self._alloc(dev, (batch, N), np.float64)
+            kind = self._alloc(dev, (batch, N), np.uint8)
         rc = self.lib.qpn_assemble_nodes(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd),
                                          _ptr(Ac), _ptr(Bc), _ptr(l), _ptr(u), _ptr(w), sw,
                                          _ptr(Mout), _ptr(qout), _ptr(lout), _ptr(uout), _ptr(kind),
