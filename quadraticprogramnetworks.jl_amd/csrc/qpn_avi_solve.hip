@@ -415,7 +415,22 @@ hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream)
         const char *e = getenv("QPN_AVI_KERNEL");
         return (e && strcmp(e, "lds1") == 0) ? 1 : 0;
     }();
-    return use_lds1 ? qpn_launch_avi_solve_lds1(a, stream) : qpn_launch_avi_solve_reg(a, stream);
+    if (use_lds1) return qpn_launch_avi_solve_lds1(a, stream);
+    // Items of shape [free STD x n | GAVI x m] (a node's reduced KKT system) take the MFMA
+    // Schur-complement kernel; it flags everything else (and any item whose H block fails its
+    // no-pivoting test) with status = -1, and the register kernel solves exactly those in a second,
+    // gated launch.  Pure box-MCP batches (kind == NULL) and already gated launches go straight to
+    // the register kernel.  QPN_AVI_KERNEL=reg forces the general kernel for A/B runs.
+    static const int force_reg = [] {
+        const char *e = getenv("QPN_AVI_KERNEL");
+        return (e && strcmp(e, "reg") == 0) ? 1 : 0;
+    }();
+    if (force_reg || a.kind == nullptr || a.only_if != nullptr || a.N < 2) return qpn_launch_avi_solve_reg(a, stream);
+    hipError_t e = qpn_launch_avi_solve_schur(a, nullptr, nullptr, nullptr, nullptr, stream);
+    if (e != hipSuccess) return e;
+    AviBatchArgs g = a;
+    g.only_if = a.status; g.only_if_value = -1;
+    return qpn_launch_avi_solve_reg(g, stream);
 }
 
 hipError_t qpn_launch_avi_solve_lds1(const AviBatchArgs &a, hipStream_t stream)

@@ -150,6 +150,20 @@ int qpn_ctx_synchronize(qpn_ctx *ctx)
 
 const char *qpn_ctx_last_error(qpn_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
+#ifdef QPN_DIAG
+// diagnostic builds only: run Stage A of the MFMA Schur kernel and dump S, c, W, h (device pointers)
+int qpn_debug_schur_stage_a(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M, const double *q,
+                            const double *l, const double *u, const uint8_t *kind, int32_t *status,
+                            double *S, double *c, double *W, double *h)
+{
+    AviBatchArgs a{};
+    a.batch = batch; a.N = N; a.M = M; a.strideM = (int64_t)N * N; a.q = q; a.l = l; a.u = u; a.kind = kind;
+    a.stride_kind = N; a.status = status;
+    if (qpn_launch_avi_solve_schur(a, S, c, W, h, ctx->stream) != hipSuccess) return QPN_ERR_HIP;
+    return hipStreamSynchronize(ctx->stream) == hipSuccess ? QPN_OK : QPN_ERR_HIP;
+}
+#endif
+
 #ifdef QPN_STAMPS
 // diagnostic builds only: where the next device-path solve writes its [batch][8] cycle sums
 static unsigned long long *g_stamps = nullptr;

@@ -42,6 +42,10 @@ int qpn_avi_big_max_n();
 size_t qpn_avi_big_workspace_bytes(int batch, int N);
 hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hipStream_t stream);
 
+// qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
+hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,
+                                      double *dbgh, hipStream_t stream);
+
 // qpn_avi_reg.hip
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream);  // register-tableau kernel
 
