@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nodes", type=int, default=NODES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="assemble M in HBM, then solve (two kernels) instead of the fused pass")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
     args = ap.parse_args()
 
@@ -79,12 +80,16 @@ def main():
     bufs = {"asm": None, "sol": None}      # output buffers are allocated once and reused
 
     def step(record):
-        bufs["asm"] = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["asm"])
-        Mc, q, lo, hi, kind = bufs["asm"]
         if record:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        res = bufs["sol"] = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind, out=bufs["sol"])   # cold start
+        if args.unfused:
+            bufs["asm"] = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["asm"])
+            Mc, q, lo, hi, kind = bufs["asm"]
+            res = bufs["sol"] = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind, out=bufs["sol"])   # cold start
+        else:
+            # (A5+A6+A2+A3+A9) one fused pass: KKT blocks assembled on the fly inside the solve kernel
+            res = bufs["sol"] = eng.solve_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["sol"])
         if record:
             e1.record(); ev_pairs.append((e0, e1))
         xloc = res["z"][:, :n].contiguous()
@@ -139,14 +144,15 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic {args.nodes}-node x {n}-var two-level QPNet "
                                    f"(n=m={n}, N_red={N}, p={p}; BASELINE.json configs[3]); step = "
-                                   "assemble + cold-start AVI solve + check + active sets"
+                                   "KKT assembly + cold-start AVI solve + check + active sets ("
+                                   + ("two kernels" if args.unfused else "one fused kernel") + ")"
                                    + (" + RCCL all-gather of primals" if use_dist else ""),
                        "nodes": args.nodes, "n": n, "m": m, "params": p,
                        "sharding": f"node ranges over {world} GPU(s)",
                        "max_resid": max_resid, "solved": solved},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "avi_solve", "kernel_ms": kern_ms,
+                         "kernel": "avi_solve_schur<nodes> (+ gated fallback launches)" if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt},
         }
         if world == 1 and not args.no_cpu_baseline:

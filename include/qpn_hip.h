@@ -126,6 +126,18 @@ int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_
                        int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
                        uint8_t *kind_out, int mem);
 
+/* ---- (A5+A6+A2+A3+A9) fused: assemble each node's KKT blocks on the fly and solve ----------
+ * Same inputs as qpn_assemble_nodes, same outputs as qpn_solve_avi_batch (N = n+m, z = [x_d; lambda]);
+ * identical results to calling the two in sequence, without materialising M in HBM: one pass of the
+ * hot path per outer sweep (src/algorithm.jl:95 -> solve_qep -> src/avi.jl:399-409 for single-node
+ * pools).  z: in z0 (ignored with QPN_AVI_FLAG_COLD_START), out solution.  n, m <= 32 run on the
+ * matrix-core kernel; other sizes (n+m <= 1024) go through assembly + the general kernels. */
+int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                    const double *R, const double *qd, const double *Ad, const double *B,
+                    const double *l, const double *u, const double *w, int64_t stride_w, double *z,
+                    int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
+                    const qpn_avi_opts *opts, int mem);
+
 /* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
  *   xd [batch][n] current decision values, w as above.
  *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower

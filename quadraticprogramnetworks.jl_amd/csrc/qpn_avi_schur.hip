@@ -28,6 +28,19 @@
 namespace {
 
 constexpr int WAVE = 64;
+
+#ifdef QPN_STAMPS
+#define STAMP(slot)                                                     \
+    do {                                                                \
+        unsigned long long now__ = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        stamp_acc[slot] += now__ - stamp_last;                          \
+        stamp_last = now__;                                             \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
@@ -43,9 +56,10 @@ struct SchurDebug { double *S, *c, *W, *h; };
 // (r = q + 4g + 16Ib) as 8 consecutive doubles
 __device__ __forceinline__ int perm32(int r) { return (r & 3) * 8 + ((r >> 4) << 2) + ((r >> 2) & 3); }
 
+template <bool NODES>
 __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
-    const int N = a.N;
+    const int N = NODES ? a.nd.n + a.nd.m : a.N;
     const int l = threadIdx.x;
     const int b = blockIdx.x;
     const int lc = l & 15, lq = l >> 4;
@@ -57,13 +71,52 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     __shared__ double sl[32], su[32], sval[2 * 32 + 2], sz[64];   // sval: values by variable id
     __shared__ int sat[32];
 
-    const double *Mg = a.M + (size_t)b * (size_t)a.strideM;
+    const double *Mg = NODES ? nullptr : a.M + (size_t)b * (size_t)a.strideM;
     const size_t vo = (size_t)b * (size_t)N;
     const bool act = l < N;
+#ifdef QPN_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    // node records (fused path): M = [[Qd, -Ad'],[Ad, 0]], q = [qd + R w; B w], src/avi.jl:205-251 + :305-377
+    const int nn = a.nd.n, nm = a.nd.m, np_ = a.nd.p;
+    const double *Q_ = NODES ? a.nd.Qd + (size_t)b * nn * nn : nullptr;
+    const double *A_ = NODES ? a.nd.Ad + (size_t)b * nm * nn : nullptr;
+    const double *R_ = NODES ? a.nd.R + (size_t)b * nn * np_ : nullptr;
+    const double *B_ = NODES ? a.nd.B + (size_t)b * nm * np_ : nullptr;
+    const double *w_ = NODES ? a.nd.w + (size_t)b * (size_t)a.nd.stride_w : nullptr;
+    // element (ri, ci) of the item's stacked M, item coordinates
+    auto melem = [&](int ri, int ci) -> double {
+        if constexpr (NODES) {
+            if (ri < nn) return ci < nn ? Q_[(size_t)ci * nn + ri] : -A_[(size_t)ri * nm + (ci - nn)];
+            return ci < nn ? A_[(size_t)ci * nm + (ri - nn)] : 0.0;
+        } else {
+            return Mg[(size_t)ci * N + ri];
+        }
+    };
+    auto qelem = [&](int it) -> double {
+        if constexpr (NODES) {
+            double s;
+            if (it < nn) { s = a.nd.qd[(size_t)b * nn + it]; for (int k = 0; k < np_; ++k) s = fma(R_[(size_t)k * nn + it], w_[k], s); }
+            else { s = 0.0; for (int k = 0; k < np_; ++k) s = fma(B_[(size_t)k * nm + (it - nn)], w_[k], s); }
+            return s;
+        } else {
+            return a.q[vo + it];
+        }
+    };
 
     // ---- structure test: leading free STD rows, then GAVI rows -------------------------------------
-    const double lk = act ? a.l[vo + l] : 0.0, uk = act ? a.u[vo + l] : 0.0;
-    const int gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + l] : 0;
+    double lk = 0.0, uk = 0.0;
+    int gk = 0;
+    if constexpr (NODES) {
+        if (act) {
+            if (l < nn) { lk = -QINF; uk = QINF; }
+            else { lk = a.nd.l[(size_t)b * nm + (l - nn)]; uk = a.nd.u[(size_t)b * nm + (l - nn)]; gk = 1; }
+        }
+    } else {
+        lk = act ? a.l[vo + l] : 0.0; uk = act ? a.u[vo + l] : 0.0;
+        gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + l] : 0;
+    }
     const bool isfree = act && !gk && lk == -QINF && uk == QINF;
     const unsigned long long mfree = __ballot(isfree), mg = __ballot(act && gk);
     const int n = __popcll(mfree), m = __popcll(mg);
@@ -82,13 +135,24 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     double mabs = 0.0;
 #define M_LOAD(I, J)                                                                                \
     {                                                                                               \
-        const int ci = item_of(16 * (J) + lc);                                                      \
+        const int cc = 16 * (J) + lc;                                                               \
+        const int ci = item_of(cc);                                                                 \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
             const int rr = 16 * (I) + 4 * g + lq;                                                   \
             const int ri = item_of(rr);                                                             \
-            double v = 0.0;                                                                         \
-            if (ri >= 0 && ci >= 0) v = Mg[(size_t)ci * N + ri];                                    \
-            else if (rr == 16 * (J) + lc && rr < 32) v = 1.0;   /* padded x rows: identity */        \
+            const bool valid = ri >= 0 && ci >= 0;                                                  \
+            double v;                                                                               \
+            if constexpr (NODES) {                                                                  \
+                /* the tile's quadrant is static; loads are unconditional on a clamped index */     \
+                if constexpr ((I) < 2 && (J) < 2) v = Q_[valid ? (size_t)ci * nn + ri : 0];         \
+                else if constexpr ((I) < 2) v = -A_[valid ? (size_t)ri * nm + (ci - nn) : 0];       \
+                else if constexpr ((J) < 2) v = A_[valid ? (size_t)ci * nm + (ri - nn) : 0];        \
+                else v = 0.0;                                                                       \
+            } else {                                                                                \
+                v = Mg[valid ? (size_t)ci * N + ri : 0];                                            \
+            }                                                                                       \
+            if (!valid) v = (rr == cc && rr < 32) ? 1.0 : 0.0;      /* padded x rows: identity */     \
+            if constexpr (NODES && (I) >= 2 && (J) >= 2) v = 0.0;                                   \
             TL(I, J)[g] = v;                                                                        \
             mabs = fmax(mabs, fabs(v));                                                             \
         }                                                                                           \
@@ -99,11 +163,12 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     double kx;
     {
         const int it = item_of(l);
-        kx = it >= 0 ? a.q[vo + it] : 0.0;
+        kx = it >= 0 ? qelem(it) : 0.0;
     }
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
 
+    STAMP(0);   // setup + load
     // ---- Stage A: 8 rank-4 block pivots on the matrix cores --------------------------------------------
     bool fail = false;
 #define M_GATHER(I, JP)                                                                             \
@@ -190,6 +255,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
 #undef M_UPD
 #undef M_GATHER
     if (fail) { if (l == 0) a.status[b] = -1; return; }
+    STAMP(6);   // crash on the matrix cores
 
     if (dbg.S) {
         // diagnostic builds: dump S (32x32), c, W (32x32), h in row-major
@@ -217,7 +283,10 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     double lo = -QINF, hi = QINF;
     {
         const int it = l < m ? n + l : -1;
-        if (actb && it >= 0) { lo = a.l[vo + it]; hi = a.u[vo + it]; }
+        if (actb && it >= 0) {
+            if constexpr (NODES) { lo = a.nd.l[(size_t)b * nm + l]; hi = a.nd.u[(size_t)b * nm + l]; }
+            else { lo = a.l[vo + it]; hi = a.u[vo + it]; }
+        }
         if (actb) { sl[l] = lo; su[l] = hi; sat[l] = 0; }
     }
     // equality GAVI rows need their multiplier crashed in: left to the general kernel
@@ -422,6 +491,7 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
         __syncthreads();
     }
 
+    STAMP(4);   // Lemke (all phases)
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
     __syncthreads();
     if (actb) { sval[rowvar] = xb; sval[colvar] = nbval; }
@@ -449,8 +519,40 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     __syncthreads();
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
-    double rk = act ? a.q[vo + l] : 0.0;
-    {
+    double rk = act ? qelem(l) : 0.0;
+    if constexpr (NODES) {
+        // r = q + M z from the node records, item columns in ascending order; 8 loads in flight per
+        // step, a zero z_j contributes exactly nothing (finite blocks)
+        const bool isx = l < nn;
+        const int ls = act ? l : 0;
+        const double *colb = isx ? Q_ + ls : A_ + (act ? ls - nn : 0);      // column sweep base of this row
+        const size_t cst = isx ? (size_t)nn : (size_t)nm;
+        const double *rowb = A_ + (size_t)(isx ? ls : 0) * nm;                // row of A' for x rows
+        int j = 0;
+        for (; j + 8 <= nn; j += 8) {                     // columns of x: Q (x rows) or A (constraint rows)
+            double mv[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = colb[(size_t)(j + q8) * cst];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) { const double zj = sz[j + q8]; rk = (zj != 0.0 && act) ? fma(mv[q8], zj, rk) : rk; }
+        }
+        for (; j < nn; ++j) {
+            const double zj = sz[j];
+            if (zj != 0.0 && act) rk = fma(colb[(size_t)j * cst], zj, rk);
+        }
+        int k = 0;
+        for (; k + 8 <= nm; k += 8) {                     // columns of lambda: -A' (x rows only)
+            double mv[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = -rowb[k + q8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) { const double zj = sz[nn + k + q8]; rk = (zj != 0.0 && act && isx) ? fma(mv[q8], zj, rk) : rk; }
+        }
+        for (; k < nm; ++k) {
+            const double zj = sz[nn + k];
+            if (zj != 0.0 && act && isx) rk = fma(-rowb[k], zj, rk);
+        }
+    } else {
         int j = 0;
         for (; j + 8 <= N; j += 8) {
             double mv[8];
@@ -498,6 +600,11 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
         if (a.resid) a.resid[b] = nres;
         if (a.pivots) a.pivots[b] = pivots;
     }
+    STAMP(5);   // read-back + post-check + stores
+#ifdef QPN_STAMPS
+    if (a.stamps && l == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[(size_t)b * 8 + i] = stamp_acc[i];
+#endif
 }
 
 } // namespace
@@ -507,6 +614,14 @@ hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, doubl
 {
     if (a.batch <= 0) return hipSuccess;
     SchurDebug d{dbgS, dbgc, dbgW, dbgh};
-    hipLaunchKernelGGL(avi_solve_schur, dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+    hipLaunchKernelGGL(avi_solve_schur<false>, dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t stream)
+{
+    if (a.batch <= 0) return hipSuccess;
+    SchurDebug d{nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(avi_solve_schur<true>, dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
     return hipGetLastError();
 }

@@ -405,6 +405,99 @@ int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_
     return QPN_OK;
 }
 
+int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                    const double *R, const double *qd, const double *Ad, const double *B,
+                    const double *l, const double *u, const double *w, int64_t stride_w, double *z,
+                    int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
+                    const qpn_avi_opts *opts, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (batch < 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_solve_nodes: bad sizes");
+    if (batch == 0) return QPN_OK;
+    if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || !w || (m > 0 && !B))) || !z || !status)
+        return fail_arg(ctx, "qpn_solve_nodes: null pointer");
+    if (stride_w != 0 && stride_w < p) return fail_arg(ctx, "qpn_solve_nodes: stride_w < p");
+    const int N = n + m;
+    if (N > qpn_avi_max_n()) { ctx->last_error = "qpn_solve_nodes: n+m > 1024 not supported by ABI v1"; return QPN_ERR_SIZE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    qpn_avi_opts o;
+    if (opts) o = *opts; else qpn_avi_default_opts(&o);
+    hipStream_t s = ctx->stream;
+    const size_t bN = (size_t)batch * N;
+    const NodeSizes sz = node_sizes(batch, n, m, p, stride_w);
+
+    // device views of the inputs / outputs
+    const double *dQ = Qd, *dR = R, *dq = qd, *dA = Ad, *dB = B, *dl = l, *du = u, *dw = w;
+    double *dz = z, *dres = resid; int32_t *dst = status, *dpv = pivots; uint8_t *dact = active;
+    // workspace: assembled blocks for the fallback / general path (written only for gated items)
+    double *wM, *wq, *wl, *wu, *wbig = nullptr; uint8_t *wk;
+    double *hQ, *hR, *hq, *hA, *hB, *hl, *hu, *hw, *hz, *hres; int32_t *hst, *hpv; uint8_t *hact;
+    Carver cv(ctx);
+    cv.add((void **)&wM, bN * N * 8); cv.add((void **)&wq, bN * 8); cv.add((void **)&wl, bN * 8);
+    cv.add((void **)&wu, bN * 8); cv.add((void **)&wk, bN);
+    if (N > 64) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, N));
+    if (mem == QPN_MEM_HOST) {
+        cv.add((void **)&hQ, sz.Q); cv.add((void **)&hR, sz.R + 8); cv.add((void **)&hq, sz.q);
+        cv.add((void **)&hA, sz.A + 8); cv.add((void **)&hB, sz.B + 8); cv.add((void **)&hl, sz.lu + 8);
+        cv.add((void **)&hu, sz.lu + 8); cv.add((void **)&hw, sz.w + 8); cv.add((void **)&hz, bN * 8);
+        cv.add((void **)&hres, (size_t)batch * 8); cv.add((void **)&hst, (size_t)batch * 4);
+        cv.add((void **)&hpv, (size_t)batch * 4); cv.add((void **)&hact, bN);
+    } else if (mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_solve_nodes: bad mem kind");
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    if (mem == QPN_MEM_HOST) {
+        HIPCHK(ctx, hipMemcpyAsync(hQ, Qd, sz.Q, hipMemcpyHostToDevice, s));
+        if (sz.R) HIPCHK(ctx, hipMemcpyAsync(hR, R, sz.R, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(hq, qd, sz.q, hipMemcpyHostToDevice, s));
+        if (sz.A) HIPCHK(ctx, hipMemcpyAsync(hA, Ad, sz.A, hipMemcpyHostToDevice, s));
+        if (sz.B) HIPCHK(ctx, hipMemcpyAsync(hB, B, sz.B, hipMemcpyHostToDevice, s));
+        if (sz.lu) {
+            HIPCHK(ctx, hipMemcpyAsync(hl, l, sz.lu, hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipMemcpyAsync(hu, u, sz.lu, hipMemcpyHostToDevice, s));
+        }
+        if (p > 0) HIPCHK(ctx, hipMemcpyAsync(hw, w, sz.w, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(hz, z, bN * 8, hipMemcpyHostToDevice, s));
+        dQ = hQ; dR = hR; dq = hq; dA = hA; dB = hB; dl = hl; du = hu; dw = hw;
+        dz = hz; dres = hres; dst = hst; dpv = hpv; dact = hact;
+    }
+
+    AviBatchArgs a{};
+    a.batch = batch; a.N = N; a.z = dz; a.status = dst; a.resid = dres; a.pivots = dpv; a.active = dact;
+    a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
+    a.max_pivots = o.max_pivots; a.flags = o.flags;
+    a.nd = NodeSrc{n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w};
+#ifdef QPN_STAMPS
+    a.stamps = g_stamps;
+#endif
+    const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
+    if (mfma_shape) {
+        // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
+        HIPCHK(ctx, qpn_launch_avi_solve_schur_nodes(a, s));
+        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, wM, wq, wl,
+                                              wu, wk, s, dst, -1));
+        AviBatchArgs g = a;
+        g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
+        g.only_if = dst; g.only_if_value = -1;
+        HIPCHK(ctx, qpn_launch_avi_solve_reg(g, s));
+    } else {
+        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, wM, wq, wl,
+                                              wu, wk, s));
+        AviBatchArgs g = a;
+        g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
+        if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
+        else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
+    }
+    if (mem == QPN_MEM_HOST) {
+        HIPCHK(ctx, hipMemcpyAsync(z, dz, bN * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(status, dst, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+        if (resid) HIPCHK(ctx, hipMemcpyAsync(resid, dres, (size_t)batch * 8, hipMemcpyDeviceToHost, s));
+        if (pivots) HIPCHK(ctx, hipMemcpyAsync(pivots, dpv, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+        if (active) HIPCHK(ctx, hipMemcpyAsync(active, dact, bN, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+    }
+    return QPN_OK;
+}
+
 int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p,
                      const double *Qd, const double *R, const double *qd, const double *Ad,
                      const double *B, const double *l, const double *u, const double *xd,

@@ -7,6 +7,13 @@
 
 #include "../../include/qpn_hip.h"
 
+// per-node records (qpn_solve_nodes): the solve kernel assembles the KKT blocks on the fly
+struct NodeSrc {
+    int32_t n, m, p;
+    const double *Qd, *R, *qd, *Ad, *B, *l, *u, *w;
+    int64_t stride_w;
+};
+
 struct AviBatchArgs {
     int32_t batch;
     int32_t N;
@@ -30,6 +37,7 @@ struct AviBatchArgs {
     int32_t only_if_value;
     // diagnostic builds only (-DQPN_STAMPS): per-item cycle sums per phase, [batch][8] uint64
     unsigned long long *stamps;
+    NodeSrc nd;      // used by the fused node path only
 };
 
 // qpn_avi_solve.hip
@@ -45,6 +53,7 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
 // qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
 hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,
                                       double *dbgh, hipStream_t stream);
+hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t stream);   // a.nd set, a.M unused
 
 // qpn_avi_reg.hip
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream);  // register-tableau kernel
@@ -62,7 +71,8 @@ hipError_t qpn_launch_assemble_nodes(int32_t batch, int32_t n, int32_t m, int32_
                                      const double *Ad, const double *B, const double *l,
                                      const double *u, const double *w, int64_t stride_w,
                                      double *Mout, double *qout, double *lout, double *uout,
-                                     uint8_t *kind_out, hipStream_t stream);
+                                     uint8_t *kind_out, hipStream_t stream,
+                                     const int32_t *only_if = nullptr, int32_t only_if_value = 0);
 hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t p,
                                    const double *Qd, const double *R, const double *qd,
                                    const double *Ad, const double *B, const double *l,

@@ -76,11 +76,12 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(
     int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
     const double *qd, const double *Ad, const double *B, const double *l, const double *u,
     const double *w, int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
-    uint8_t *kind_out)
+    uint8_t *kind_out, const int32_t *only_if, int32_t only_if_value)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int b = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (b >= batch) return;
+    if (only_if && only_if[b] != only_if_value) return;   // gated (fallback of the fused node path)
     const int N = n + m;
     const double *Q_ = Qd + (size_t)b * n * n;
     const double *A_ = Ad + (size_t)b * m * n;
@@ -147,12 +148,13 @@ hipError_t qpn_launch_assemble_nodes(int32_t batch, int32_t n, int32_t m, int32_
                                      const double *Ad, const double *B, const double *l,
                                      const double *u, const double *w, int64_t stride_w,
                                      double *Mout, double *qout, double *lout, double *uout,
-                                     uint8_t *kind_out, hipStream_t stream)
+                                     uint8_t *kind_out, hipStream_t stream, const int32_t *only_if,
+                                     int32_t only_if_value)
 {
     if (batch <= 0) return hipSuccess;
     const int wpb = 4;
     hipLaunchKernelGGL(assemble_nodes_kernel, dim3((batch + wpb - 1) / wpb), dim3(wpb * WAVE), 0,
                        stream, batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, Mout, qout,
-                       lout, uout, kind_out);
+                       lout, uout, kind_out, only_if, only_if_value);
     return hipGetLastError();
 }

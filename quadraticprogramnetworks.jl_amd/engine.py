@@ -230,6 +230,46 @@ class Engine:
         self._chk(rc, "qpn_assemble_nodes")
         return Mout, qout, lout, uout, kind
 
+    # -- (A5+A6+A2+A3+A9 fused) --------------------------------------------------------------
+    def solve_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w, z0=None, opts=None, want_active=True, out=None):
+        """Assemble every node's KKT blocks on the fly and solve (one kernel for n, m <= 32); same
+        results as assemble_nodes + solve_avi_batch without materialising M.  z = [x_d; lambda]."""
+        dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, w, z0)
+        self._bind_stream(dev)
+        if not dev:
+            Qc, Rc, qd, Ac, Bc, l, u, w = (self._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u, w))
+        batch, n = qd.shape
+        m = l.shape[1]
+        p = w.shape[-1]
+        sw = 0 if w.ndim == 1 else p
+        N = n + m
+        o = opts if opts is not None else self.default_opts()
+        if out is not None and out["z"].shape == (batch, N):
+            z, status, resid, pivots, active = out["z"], out["status"], out["resid"], out["pivots"], out["active"]
+        else:
+            z = self._alloc(dev, (batch, N), np.float64)
+            status = self._alloc(dev, (batch,), np.int32)
+            resid = self._alloc(dev, (batch,), np.float64)
+            pivots = self._alloc(dev, (batch,), np.int32)
+            active = self._alloc(dev, (batch, N), np.uint8) if want_active else None
+        if z0 is None:
+            if opts is None:
+                o.flags |= _lib.AVI_FLAG_COLD_START
+            elif dev:
+                z.zero_()
+            else:
+                z[...] = 0.0
+        elif dev:
+            z.copy_(z0)
+        else:
+            z[...] = np.asarray(z0, dtype=np.float64)
+        rc = self.lib.qpn_solve_nodes(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac),
+                                      _ptr(Bc), _ptr(l), _ptr(u), _ptr(w), sw, _ptr(z), _ptr(status),
+                                      _ptr(resid), _ptr(pivots), _ptr(active), C.byref(o),
+                                      MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_solve_nodes")
+        return dict(z=z, status=status, resid=resid, pivots=pivots, active=active)
+
     # -- (A8) ------------------------------------------------------------------------------
     def verify_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, xd, w, tol=1e-4):
         """Batched verify_solution (src/qp_processing.jl:57-149) -> (solution, lambda, path)."""

@@ -140,3 +140,36 @@ def test_verify_unconstrained_and_degenerate(engine, oracle):
     M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
     z = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)["z"]
     _verify_case(engine, oracle, Q, R, qd, A, B, l, u, z[:, :n].copy(), w, "duplicate rows")
+
+
+def test_solve_nodes_fused_equals_assemble_then_solve(engine, oracle):
+    """qpn_solve_nodes (assembly fused into the solve, M never materialised) against the oracle and
+    against the two-call path, host and device buffers, matrix-core sizes and general sizes."""
+    import torch
+    from qpn_amd.engine import colmajor
+    for n, m, p, cnt in [(32, 32, 8, 300), (7, 19, 3, 40), (32, 5, 8, 20), (3, 32, 1, 20), (40, 50, 4, 3), (6, 0, 2, 4)]:
+        Q, R, qd, A, B, l, u = P.synth_nodes(4000 + n, cnt, n, m, p)
+        B = 0.3 * np.random.default_rng(n).standard_normal((cnt, m, p))
+        w = P.shared_params(p)
+        M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+        rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+        args = (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+        rh = engine.solve_nodes(*args)
+        assert np.array_equal(rh["status"], rc["status"]) and np.all(rc["status"] == 1)
+        assert np.array_equal(rh["active"], rc["active"]) and np.array_equal(rh["pivots"], rc["pivots"])
+        assert np.max(np.abs(rh["z"] - rc["z"])) <= 1e-9 and np.max(rh["resid"]) <= 1e-8
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+        rd = engine.solve_nodes(*[t(x) for x in args])
+        torch.cuda.synchronize()
+        assert np.array_equal(rd["z"].cpu().numpy(), rh["z"]) and np.array_equal(rd["active"].cpu().numpy(), rh["active"])
+    # an LP-like batch (Q = 0) is declined by the matrix-core kernel and solved by the gated fallback
+    n, m, cnt = 6, 14, 10
+    rng = np.random.default_rng(3)
+    Q = np.zeros((cnt, n, n)); R = np.zeros((cnt, n, 1)); B = np.zeros((cnt, m, 1)); qd = rng.standard_normal((cnt, n))
+    A = np.stack([np.vstack([np.eye(n), rng.standard_normal((m - n, n))]) for _ in range(cnt)])
+    l = np.tile(np.concatenate([-2 * np.ones(n), -1.5 * np.ones(m - n)]), (cnt, 1)); u = -l
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, np.zeros(1))
+    rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+    rh = engine.solve_nodes(colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, np.zeros(1))
+    assert np.array_equal(rh["status"], rc["status"]) and np.all(rc["status"] == 1)
+    assert np.array_equal(rh["active"], rc["active"]) and np.max(np.abs(rh["z"] - rc["z"])) <= 1e-9

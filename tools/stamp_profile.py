@@ -11,7 +11,7 @@ csrc = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc")
 out = "/tmp/libqpn_hip_stamps.so"
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQPN_STAMPS", "-ffp-contract=off",
                        "-o", out] + [os.path.join(csrc, f) for f in
-                       ("qpn_capi.hip", "qpn_avi_solve.hip", "qpn_avi_reg.hip", "qpn_avi_big.hip", "qpn_kkt.hip", "qpn_verify.hip")])
+                       ("qpn_capi.hip", "qpn_avi_solve.hip", "qpn_avi_reg.hip", "qpn_avi_big.hip", "qpn_avi_schur.hip", "qpn_kkt.hip", "qpn_verify.hip")])
 import numpy as np, torch
 import qpn_amd
 from qpn_amd import _lib, synthetic
@@ -26,8 +26,12 @@ t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=
 Mc, q, lo, hi, kind = eng.assemble_nodes(t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(w))
 st = torch.zeros((cnt, 8), dtype=torch.int64, device="cuda:0")
 eng.lib.qpn_debug_set_stamps(C.c_void_p(st.data_ptr()))
+fused = os.environ.get("FUSED", "0") == "1"
 for _ in range(2):
-    res = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind)
+    if fused:
+        res = eng.solve_nodes(t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(w))
+    else:
+        res = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind)
 torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.float64)
 piv = res["pivots"].cpu().numpy().mean()
