@@ -64,12 +64,20 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     const int b = blockIdx.x;
     const int lc = l & 15, lq = l >> 4;
 
-    __shared__ __attribute__((aligned(16))) double sU[64 * 4];      // pivot columns, [row][k]
+    // Stage A scratch (sU: pivot columns, [row][k]) and Stage B / read-back scratch never live at the
+    // same time: one buffer, so that the fused node path (which also keeps the node's Q and A blocks in
+    // LDS for the whole solve) still fits 8 waves per CU.
+    __shared__ __attribute__((aligned(16))) double sbuf[64 * 4];
+    double *const sU = sbuf;                    // Stage A: pivot columns, [row][k]
+    double *const sucol = sbuf;                 // Stage B: pivot column (permuted) + extra   [40]
+    double *const svrow = sbuf + 40;            // Stage B: pivot row                         [40]
+    double *const sval = sbuf + 80;             // values by variable id                      [66]
+    double *const sz = sbuf + 160;              // solution in item order                     [64]
     __shared__ __attribute__((aligned(16))) double sP[16];          // P^-1, [i][k]
-    __shared__ __attribute__((aligned(16))) double sucol[40];       // Stage B: pivot column (permuted) + extra
-    __shared__ __attribute__((aligned(16))) double svrow[40];       // Stage B: pivot row
-    __shared__ double sl[32], su[32], sval[2 * 32 + 2], sz[64];   // sval: values by variable id
-    __shared__ int sat[32];
+    // fused node path: Qd (column stride SQS) and Ad (column stride SAS), read ONCE from HBM
+    constexpr int SQS = 34, SAS = 33;
+    __shared__ double sQ[NODES ? 32 * SQS : 1];
+    __shared__ double sA[NODES ? 32 * SAS : 1];
 
     const double *Mg = NODES ? nullptr : a.M + (size_t)b * (size_t)a.strideM;
     const size_t vo = (size_t)b * (size_t)N;
@@ -85,15 +93,6 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     const double *R_ = NODES ? a.nd.R + (size_t)b * nn * np_ : nullptr;
     const double *B_ = NODES ? a.nd.B + (size_t)b * nm * np_ : nullptr;
     const double *w_ = NODES ? a.nd.w + (size_t)b * (size_t)a.nd.stride_w : nullptr;
-    // element (ri, ci) of the item's stacked M, item coordinates
-    auto melem = [&](int ri, int ci) -> double {
-        if constexpr (NODES) {
-            if (ri < nn) return ci < nn ? Q_[(size_t)ci * nn + ri] : -A_[(size_t)ri * nm + (ci - nn)];
-            return ci < nn ? A_[(size_t)ci * nm + (ri - nn)] : 0.0;
-        } else {
-            return Mg[(size_t)ci * N + ri];
-        }
-    };
     auto qelem = [&](int it) -> double {
         if constexpr (NODES) {
             double s;
@@ -128,33 +127,61 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     // internal index (0..63) -> item index or -1 (padding): x block 0..31, lambda block 32..63
     auto item_of = [&](int r) -> int { return r < 32 ? (r < n ? r : -1) : (r - 32 < m ? n + (r - 32) : -1); };
 
-    // ---- load straight into the MFMA tile layout: all 64 loads in flight at once ----------------------
+    // ---- load straight into the MFMA tile layout ------------------------------------------------------
 #define M_DECL(I, J) d4 TL(I, J);
     FOR_IJ(M_DECL)
 #undef M_DECL
     double mabs = 0.0;
+    double qit = 0.0;                     // q of item row l (kept for the post-check)
+    if constexpr (NODES) {
+        // Stage the node's Qd and Ad blocks in LDS with fully coalesced loads (two columns of 32 rows
+        // per instruction = 512 contiguous bytes when n = m = 32): 32 loads per lane instead of the 64
+        // strided ones of a direct tile load, and the post-check re-reads LDS, not HBM.
+        const int r5 = l & 31, ch = l >> 5;
+        double vq[16], va[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            const bool okq = cj < nn && r5 < nn, oka = cj < nn && r5 < nm;
+            vq[t] = Q_[okq ? (size_t)cj * nn + r5 : 0];
+            va[t] = A_[oka ? (size_t)cj * nm + r5 : 0];
+        }
+        if (act) qit = qelem(l);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            const bool okq = cj < nn && r5 < nn, oka = cj < nn && r5 < nm;
+            const double q_ = okq ? vq[t] : 0.0, a_ = oka ? va[t] : 0.0;
+            sQ[cj * SQS + r5] = q_;
+            sA[cj * SAS + r5] = a_;
+            mabs = fmax(mabs, fmax(fabs(q_), fabs(a_)));
+        }
+        __syncthreads();
+    }
 #define M_LOAD(I, J)                                                                                \
     {                                                                                               \
         const int cc = 16 * (J) + lc;                                                               \
-        const int ci = item_of(cc);                                                                 \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
             const int rr = 16 * (I) + 4 * g + lq;                                                   \
-            const int ri = item_of(rr);                                                             \
-            const bool valid = ri >= 0 && ci >= 0;                                                  \
             double v;                                                                               \
             if constexpr (NODES) {                                                                  \
-                /* the tile's quadrant is static; loads are unconditional on a clamped index */     \
-                if constexpr ((I) < 2 && (J) < 2) v = Q_[valid ? (size_t)ci * nn + ri : 0];         \
-                else if constexpr ((I) < 2) v = -A_[valid ? (size_t)ri * nm + (ci - nn) : 0];       \
-                else if constexpr ((J) < 2) v = A_[valid ? (size_t)ci * nm + (ri - nn) : 0];        \
+                /* the tile's quadrant is static; LDS holds zeros outside the n x n / m x n blocks */ \
+                if constexpr ((I) < 2 && (J) < 2) {                                                 \
+                    v = sQ[cc * SQS + rr];                                                          \
+                    if (rr == cc && rr >= n) v = 1.0;               /* padded x rows: identity */     \
+                } else if constexpr ((I) < 2) {                                                     \
+                    const double t_ = sA[rr * SAS + (cc - 32)];                                     \
+                    v = (rr < n && cc - 32 < m) ? -t_ : 0.0;                                        \
+                } else if constexpr ((J) < 2) v = sA[cc * SAS + (rr - 32)];                         \
                 else v = 0.0;                                                                       \
             } else {                                                                                \
+                const int ci = item_of(cc), ri = item_of(rr);                                       \
+                const bool valid = ri >= 0 && ci >= 0;                                              \
                 v = Mg[valid ? (size_t)ci * N + ri : 0];                                            \
+                if (!valid) v = (rr == cc && rr < 32) ? 1.0 : 0.0;  /* padded x rows: identity */     \
+                mabs = fmax(mabs, fabs(v));                                                         \
             }                                                                                       \
-            if (!valid) v = (rr == cc && rr < 32) ? 1.0 : 0.0;      /* padded x rows: identity */     \
-            if constexpr (NODES && (I) >= 2 && (J) >= 2) v = 0.0;                                   \
             TL(I, J)[g] = v;                                                                        \
-            mabs = fmax(mabs, fabs(v));                                                             \
         }                                                                                           \
     }
     FOR_IJ(M_LOAD)
@@ -163,7 +190,8 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     double kx;
     {
         const int it = item_of(l);
-        kx = it >= 0 ? qelem(it) : 0.0;
+        if constexpr (NODES) { const double t_ = __shfl(qit, it >= 0 ? it : 0, WAVE); kx = it >= 0 ? t_ : 0.0; }
+        else kx = it >= 0 ? qelem(it) : 0.0;
     }
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
@@ -277,6 +305,18 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     // ================= Stage B: Lemke on the Schur dictionary (32 pairs, tile layout) =================
     // pair k (k < 32) <-> item row n + k:  p_k = s_k = (S lambda + c)_k in [l_k, u_k],  d_k = lambda_k.
     // ids: p_k -> k, d_k -> 32 + k, artificial -> 64; column index 32 = the extra (covering) column.
+    // The loop is bound by instruction issue, not by flops, so the whole Gauss-Jordan exchange of a pivot
+    // (rank-1 update, new pivot row, new pivot column, new pivot element) is folded into ONE
+    // v_mfma_f64_16x16x4 per tile, using all four K slots in the order the matrix core accumulates them
+    // (k = 0, 1, 2, 3; bitwise an fma chain, tools/mfma_f64_probe.hip):
+    //     k=0:  A = -e_r            B = pivot row (raw)          row r := 0              (exactly)
+    //     k=1:  A = -u  (u_r := 1)  B = v = row*inv (v_c := 1)   T -= u v'; row r := -v; column c := 0; (r,c) = -1
+    //     k=2:  A = u*inv (r: 1)    B = e_c                      column c := u*inv;      (r,c) = 0
+    //     k=3:  A = e_r             B = inv * e_c                (r,c) := inv
+    // Every entry gets exactly the value the scalar exchange gives it; there is no lane- or
+    // register-dependent fix-up code and the dictionary never leaves the accumulator registers.
+    // Pair bounds / bound flags sit in lane k and are fetched with v_readlane; the only LDS traffic per
+    // pivot is the entering column and the pivot row.
     constexpr int NBP = 32, XC = 32, VTH = 64;
     const bool actb = l < NBP;
     double xb = __shfl(kx, (l + 32) & 63, WAVE);            // c_k sits in lane 32 + k
@@ -287,32 +327,45 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
             if constexpr (NODES) { lo = a.nd.l[(size_t)b * nm + l]; hi = a.nd.u[(size_t)b * nm + l]; }
             else { lo = a.l[vo + it]; hi = a.u[vo + it]; }
         }
-        if (actb) { sl[l] = lo; su[l] = hi; sat[l] = 0; }
     }
     // equality GAVI rows need their multiplier crashed in: left to the general kernel
     if (__ballot(actb && lo == hi)) { if (l == 0) a.status[b] = -1; return; }
+    const double lo0 = lo, hi0 = hi;      // bounds of pair l (fixed); lo/hi follow the row's basic variable
+    int satv = 0;                         // pair l: 1 = bounded variable rests at its upper bound
     int rowvar = actb ? l : -1, colvar = actb ? NBP + l : -1;
     double nbval = 0.0, tcol = 0.0;
     int cNvar = VTH;
     double cNval = 0.0;
-    __syncthreads();
+    __syncthreads();                      // Stage A is done with sbuf
 
 #define SB(Ib, Jb) TL_S_##Ib##_##Jb
 #define TL_S_0_0 TL(2, 2)
 #define TL_S_0_1 TL(2, 3)
 #define TL_S_1_0 TL(3, 2)
 #define TL_S_1_1 TL(3, 3)
+    // loop-invariant operand roles of this lane (K slot = lq)
+    const double kA = lq < 2 ? -1.0 : 1.0;            // A operand on the pivot row
+    const double cA0 = lq == 1 ? -1.0 : 0.0;          // A = u * coefA elsewhere (coefA = inv on slot 2)
+    const double cB0 = lq == 0 ? 1.0 : 0.0;           // B = row * coefB (coefB = inv on slot 1) off the pivot column
     auto col_of = [&](int v) -> int {
         int cc = wave_first(actb && colvar == v);
         if (cc < 0 && cNvar == v) cc = XC;
         return cc;
+    };
+    // 1/x to ~1 ulp (|x| > piv_tol on every lane whose result is used)
+    auto rcp64 = [](double x) -> double {
+        double r = __builtin_amdgcn_rcp(x);
+        double e = fma(-x, r, 1.0); r = fma(r, e, r);
+        e = fma(-x, r, 1.0); r = fma(r, e, r);
+        return r;
     };
 
     int pivots = n;                       // the crash brought n free variables in (Stage A)
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
     int status = QPN_FAILURE;
     int c = XC;
-    double sigma = -1.0, self_lim = 0.0, elo = 0.0, ehi = QINF;
+    bool sneg = true;                     // direction of the entering variable: sigma = sneg ? -1 : +1
+    double self_lim = 0.0, elo = 0.0, ehi = QINF;
     const double slack = 1e-10, ptol = a.piv_tol;
     {
         double viol = 0.0;
@@ -340,36 +393,37 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     while (status == QPN_MAX_ITERS) {
         if (pivots >= max_piv) break;
         c = uni(c);
-        // ---- entering column -> sucol (permuted so a lane group reads its 8 rows contiguously)
-        if (c == XC) { if (actb) sucol[perm32(l)] = tcol; }
+        // ---- entering column -> sucol, plain row order
+        if (c == XC) { if (actb) sucol[l] = tcol; }
         else if (lc == (c & 15)) {
-            if ((c >> 4) == 0) {
+            if (c < 16) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) { sucol[lq * 8 + g] = SB(0, 0)[g]; sucol[lq * 8 + 4 + g] = SB(1, 0)[g]; }
+                for (int g = 0; g < 4; ++g) { sucol[4 * g + lq] = SB(0, 0)[g]; sucol[16 + 4 * g + lq] = SB(1, 0)[g]; }
             } else {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) { sucol[lq * 8 + g] = SB(0, 1)[g]; sucol[lq * 8 + 4 + g] = SB(1, 1)[g]; }
+                for (int g = 0; g < 4; ++g) { sucol[4 * g + lq] = SB(0, 1)[g]; sucol[16 + 4 * g + lq] = SB(1, 1)[g]; }
             }
         }
         __syncthreads();
-        const double cm = actb ? sucol[perm32(l)] : 0.0;
-        // ---- ratio test (same rule and arithmetic as the general kernel)
-        const double gdir = sigma * cm;
-        const double rc = 1.0 / gdir;
+        const double cm = actb ? sucol[l] : 0.0;
+        STAMP(1);   // entering column through LDS
+        // ---- ratio test (same rule as the general kernel; reciprocal by Newton instead of a division)
+        const double gdir = sneg ? -cm : cm;
+        const double rc = rcp64(gdir);
         const bool cndlo = actb && gdir < -ptol && lo > -QINF;
         const bool cndhi = actb && gdir > ptol && hi < QINF;
         const bool cnd = cndlo || cndhi;
         const double arc = cndlo ? -rc : rc;
         const double dd = (cndlo ? xb - lo : hi - xb) * arc;
-        const double d1 = dd + slack * arc;
-        double dmax = wave_min_f64(cnd ? d1 : QINF);
+        const double d1 = fma(slack, arc, dd);
+        double dmax = wave_min32_f64(cnd ? d1 : QINF);
         if (self_lim < dmax) dmax = self_lim;
-        dmax = udbl(dmax);
         if (ubool(dmax == QINF)) { status = QPN_RAY_TERM; break; }
         const bool cand = cnd && dd <= dmax;
         const unsigned long long bal = __ballot(cand);
         if (bal == 0ull) {
-            const double dl = sigma * self_lim;
+            // the entering variable reaches its own opposite bound first: no basis change
+            const double dl = sneg ? -self_lim : self_lim;
             if (actb) xb = fma(dl, cm, xb);
             const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
             if (ve == VTH) {
@@ -377,14 +431,14 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
                 status = QPN_SUCCESS; break;
             }
             const int k = ve;
-            const int au = ubool(sigma > 0.0) ? 1 : 0;
-            const double nv = udbl(au ? su[k] : sl[k]);
-            if (l == 0) sat[k] = au;
+            const int au = sneg ? 0 : 1;
+            const double nv = au ? readlane_f64(hi0, k) : readlane_f64(lo0, k);
+            if (l == k) satv = au;
             if (c == XC) cNval = nv; else if (l == c) nbval = nv;
             pivots++;
             c = col_of(NBP + k);
             if (c < 0) { status = QPN_FAILURE; break; }
-            sigma = au ? -1.0 : 1.0;
+            sneg = au != 0;
             self_lim = QINF;
             if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
             __syncthreads();
@@ -399,14 +453,8 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
             r = wave_first(cand && ag == bestg);
         }
         r = uni(r);
-        double step = readlane_f64(dd, r);
-        if (ubool(step < 0.0)) step = 0.0;
-        const double leave_val = udbl(readlane_f64(cndlo ? lo : hi, r));
-        const double inv = udbl(sigma * readlane_f64(rc, r));
-        const double delta = udbl(sigma * step);
-        const int vl = readlane_i32(rowvar, r);
-        // ---- pivot: row r -> svrow (raw), then the rank-1 update on the four S tiles
-        const double enter_val = udbl(((c == XC) ? cNval : readlane_f64(nbval, c)) + delta);
+        STAMP(2);   // ratio test + row choice
+        // ---- pivot row r -> svrow (raw): the 16 lanes that hold it pick the register under a uniform tree
         const int rq = r & 3, rsel = ((r >> 4) << 2) | ((r >> 2) & 3);      // leaf = Ib*4 + g
         if (lq == rq) {
 #define M_XROW(Ib, g) { svrow[lc] = SB(Ib, 0)[g]; svrow[16 + lc] = SB(Ib, 1)[g]; }
@@ -414,48 +462,36 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
             else { if (rsel < 6) { if (rsel < 5) M_XROW(1, 0) else M_XROW(1, 1) } else { if (rsel < 7) M_XROW(1, 2) else M_XROW(1, 3) } }
 #undef M_XROW
         }
-        if (l == r) svrow[32] = tcol;
+        double step = readlane_f64(dd, r);
+        if (step < 0.0) step = 0.0;
+        const double leave_val = readlane_f64(cndlo ? lo : hi, r);
+        const double rcr = readlane_f64(rc, r);
+        const double inv = sneg ? -rcr : rcr;
+        const double delta = sneg ? -step : step;
+        const int vl = readlane_i32(rowvar, r);
+        const double vxr = readlane_f64(tcol, r);
+        const double enter_val = ((c == XC) ? cNval : readlane_f64(nbval, c)) + delta;
         __syncthreads();
         {
-            const double vxr = svrow[32];
-            double u0 = sucol[lq * 8 + 0], u1 = sucol[lq * 8 + 1], u2 = sucol[lq * 8 + 2], u3 = sucol[lq * 8 + 3];
-            double u4 = sucol[lq * 8 + 4], u5 = sucol[lq * 8 + 5], u6 = sucol[lq * 8 + 6], u7 = sucol[lq * 8 + 7];
-            double v0 = svrow[lc] * inv, v1 = svrow[16 + lc] * inv;
-            if (lc == c) v0 = -inv;
-            if (16 + lc == c) v1 = -inv;
-            {
-                const double vx = (c == XC) ? -inv : vxr * inv;
-                double xbn = fma(delta, cm, xb);
-                double tcn = (c == XC) ? cm * inv : fma(-cm, vx, tcol);
-                if (l == r) { xbn = enter_val; tcn = (c == XC) ? inv : -vx; }
-                xb = xbn; tcol = tcn;
-            }
-            SB(0, 0)[0] = fma(-u0, v0, SB(0, 0)[0]); SB(0, 0)[1] = fma(-u1, v0, SB(0, 0)[1]);
-            SB(0, 0)[2] = fma(-u2, v0, SB(0, 0)[2]); SB(0, 0)[3] = fma(-u3, v0, SB(0, 0)[3]);
-            SB(0, 1)[0] = fma(-u0, v1, SB(0, 1)[0]); SB(0, 1)[1] = fma(-u1, v1, SB(0, 1)[1]);
-            SB(0, 1)[2] = fma(-u2, v1, SB(0, 1)[2]); SB(0, 1)[3] = fma(-u3, v1, SB(0, 1)[3]);
-            SB(1, 0)[0] = fma(-u4, v0, SB(1, 0)[0]); SB(1, 0)[1] = fma(-u5, v0, SB(1, 0)[1]);
-            SB(1, 0)[2] = fma(-u6, v0, SB(1, 0)[2]); SB(1, 0)[3] = fma(-u7, v0, SB(1, 0)[3]);
-            SB(1, 1)[0] = fma(-u4, v1, SB(1, 1)[0]); SB(1, 1)[1] = fma(-u5, v1, SB(1, 1)[1]);
-            SB(1, 1)[2] = fma(-u6, v1, SB(1, 1)[2]); SB(1, 1)[3] = fma(-u7, v1, SB(1, 1)[3]);
-            // column c: T[i][c] = cm_i * inv   (the 4 lanes that own that column)
-            if (c != XC && lc == (c & 15)) {
-                if ((c >> 4) == 0) {
-                    SB(0, 0)[0] = u0 * inv; SB(0, 0)[1] = u1 * inv; SB(0, 0)[2] = u2 * inv; SB(0, 0)[3] = u3 * inv;
-                    SB(1, 0)[0] = u4 * inv; SB(1, 0)[1] = u5 * inv; SB(1, 0)[2] = u6 * inv; SB(1, 0)[3] = u7 * inv;
-                } else {
-                    SB(0, 1)[0] = u0 * inv; SB(0, 1)[1] = u1 * inv; SB(0, 1)[2] = u2 * inv; SB(0, 1)[3] = u3 * inv;
-                    SB(1, 1)[0] = u4 * inv; SB(1, 1)[1] = u5 * inv; SB(1, 1)[2] = u6 * inv; SB(1, 1)[3] = u7 * inv;
-                }
-            }
-            // row r: T[r][j] = -prow_j, T[r][c] = inv (v carries -inv there)
-            if (lq == rq) {
-#define M_FROW(Ib, g) { SB(Ib, 0)[g] = -v0; SB(Ib, 1)[g] = -v1; }
-                if (rsel < 4) { if (rsel < 2) { if (rsel < 1) M_FROW(0, 0) else M_FROW(0, 1) } else { if (rsel < 3) M_FROW(0, 2) else M_FROW(0, 3) } }
-                else { if (rsel < 6) { if (rsel < 5) M_FROW(1, 0) else M_FROW(1, 1) } else { if (rsel < 7) M_FROW(1, 2) else M_FROW(1, 3) } }
-#undef M_FROW
-            }
+            // extra column and values (lane l <-> row l)
+            const double ninv = -inv;
+            const double vx = (c == XC) ? ninv : vxr * inv;
+            double xbn = fma(delta, cm, xb);
+            double tcn = (c == XC) ? cm * inv : fma(-cm, vx, tcol);
+            if (l == r) { xbn = enter_val; tcn = (c == XC) ? inv : -vx; }
+            xb = xbn; tcol = tcn;
+            // the exchange on the four S tiles: one MFMA each (see the header of this stage)
+            const double coefA = lq == 2 ? inv : cA0, coefB = lq == 1 ? inv : cB0, kB = lq == 3 ? inv : 1.0;
+            const double a0 = (lc == r) ? kA : sucol[lc] * coefA;
+            const double a1 = (16 + lc == r) ? kA : sucol[16 + lc] * coefA;
+            const double b0 = (lc == c && lq != 0) ? kB : svrow[lc] * coefB;
+            const double b1 = (16 + lc == c && lq != 0) ? kB : svrow[16 + lc] * coefB;
+            SB(0, 0) = MFMA(a0, b0, SB(0, 0));
+            SB(0, 1) = MFMA(a0, b1, SB(0, 1));
+            SB(1, 0) = MFMA(a1, b0, SB(1, 0));
+            SB(1, 1) = MFMA(a1, b1, SB(1, 1));
         }
+        STAMP(3);   // pivot row through LDS + exchange issue
         {
             const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
             if (l == r) { rowvar = ve; lo = elo; hi = ehi; }
@@ -465,33 +501,37 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
         pivots++;
         if (vl == VTH) { status = QPN_SUCCESS; break; }
         int vn;
-        if (vl < NBP) {
-            const int k = vl;
-            const double Lk = udbl(sl[k]), Uk = udbl(su[k]);
-            int au = uni(sat[k]);
-            if (ubool(Lk != Uk)) { au = (leave_val == Uk) ? 1 : 0; if (l == 0) sat[k] = au; }
-            vn = NBP + k;
-            sigma = au ? -1.0 : 1.0;
-            self_lim = QINF;
-            if (ubool(Lk == Uk)) { elo = -QINF; ehi = QINF; }
-            else if (ubool(Lk == -QINF && Uk == QINF)) { elo = 0.0; ehi = 0.0; }
-            else if (au) { elo = -QINF; ehi = 0.0; }
-            else { elo = 0.0; ehi = QINF; }
-        } else {
-            const int k = vl - NBP;
-            const double Lk = udbl(sl[k]), Uk = udbl(su[k]);
-            vn = k;
-            sigma = uni(sat[k]) ? -1.0 : 1.0;
-            self_lim = Uk - Lk;
-            if (ubool(Lk == -QINF && Uk == QINF)) { self_lim = QINF; sigma = 1.0; }
-            elo = Lk; ehi = Uk;
+        {
+            const int k = vl < NBP ? vl : vl - NBP;
+            const double Lk = readlane_f64(lo0, k), Uk = readlane_f64(hi0, k);
+            int au = readlane_i32(satv, k);
+            const bool isfreek = Lk == -QINF && Uk == QINF;
+            if (vl < NBP) {
+                // the bounded variable p_k left at a bound: its multiplier d_k enters from 0
+                if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); if (l == k) satv = au; }
+                vn = NBP + k;
+                sneg = au != 0;
+                self_lim = QINF;
+                if (Lk == Uk) { elo = -QINF; ehi = QINF; }
+                else if (isfreek) { elo = 0.0; ehi = 0.0; }
+                else if (au) { elo = -QINF; ehi = 0.0; }
+                else { elo = 0.0; ehi = QINF; }
+            } else {
+                // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                vn = k;
+                sneg = au != 0;
+                self_lim = Uk - Lk;
+                if (isfreek) { self_lim = QINF; sneg = false; }
+                elo = Lk; ehi = Uk;
+            }
         }
         c = col_of(vn);
         if (c < 0) { status = QPN_FAILURE; break; }
         __syncthreads();
+        STAMP(4);
     }
 
-    STAMP(4);   // Lemke (all phases)
+    STAMP(4);   // Lemke: bookkeeping + flips
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
     __syncthreads();
     if (actb) { sval[rowvar] = xb; sval[colvar] = nbval; }
@@ -519,38 +559,25 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     __syncthreads();
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
-    double rk = act ? qelem(l) : 0.0;
+    double rk;
+    if constexpr (NODES) rk = qit; else rk = act ? qelem(l) : 0.0;
     if constexpr (NODES) {
-        // r = q + M z from the node records, item columns in ascending order; 8 loads in flight per
-        // step, a zero z_j contributes exactly nothing (finite blocks)
+        // r = q + M z from the LDS copies of the node blocks, item columns in ascending order; a zero
+        // z_j contributes exactly nothing (finite blocks)
         const bool isx = l < nn;
-        const int ls = act ? l : 0;
-        const double *colb = isx ? Q_ + ls : A_ + (act ? ls - nn : 0);      // column sweep base of this row
-        const size_t cst = isx ? (size_t)nn : (size_t)nm;
-        const double *rowb = A_ + (size_t)(isx ? ls : 0) * nm;                // row of A' for x rows
-        int j = 0;
-        for (; j + 8 <= nn; j += 8) {                     // columns of x: Q (x rows) or A (constraint rows)
-            double mv[8];
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = colb[(size_t)(j + q8) * cst];
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) { const double zj = sz[j + q8]; rk = (zj != 0.0 && act) ? fma(mv[q8], zj, rk) : rk; }
+        const int ls = act ? (isx ? l : l - nn) : 0;
+        const double *colb = isx ? sQ + ls : sA + ls;          // column sweep base of this row
+        const int cst = isx ? SQS : SAS;
+        const double *rowb = sA + (isx ? ls : 0) * SAS;        // row of A' for x rows
+#pragma unroll 8
+        for (int j = 0; j < nn; ++j) {                         // columns of x: Q (x rows) or A (constraint rows)
+            const double mv = colb[j * cst], zj = sz[j];
+            rk = (zj != 0.0) ? fma(mv, zj, rk) : rk;
         }
-        for (; j < nn; ++j) {
-            const double zj = sz[j];
-            if (zj != 0.0 && act) rk = fma(colb[(size_t)j * cst], zj, rk);
-        }
-        int k = 0;
-        for (; k + 8 <= nm; k += 8) {                     // columns of lambda: -A' (x rows only)
-            double mv[8];
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = -rowb[k + q8];
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) { const double zj = sz[nn + k + q8]; rk = (zj != 0.0 && act && isx) ? fma(mv[q8], zj, rk) : rk; }
-        }
-        for (; k < nm; ++k) {
-            const double zj = sz[nn + k];
-            if (zj != 0.0 && act && isx) rk = fma(-rowb[k], zj, rk);
+#pragma unroll 8
+        for (int k = 0; k < nm; ++k) {                         // columns of lambda: -A' (x rows only)
+            const double mv = -rowb[k], zj = sz[nn + k];
+            rk = (zj != 0.0 && isx) ? fma(mv, zj, rk) : rk;
         }
     } else {
         int j = 0;

@@ -89,8 +89,10 @@ __device__ __forceinline__ double udbl(double v);
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // every source lane of the row patterns used here is valid, so `old` is irrelevant: mov_dpp
+    // (old = undef) saves the two register copies update_dpp(old = v) costs
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // value of `v` in lane `l`; l must be wave-uniform (it is turned into an SGPR)
@@ -127,6 +129,13 @@ __device__ __forceinline__ double wave_min_f64(double v)
     QPN_ROW_REDUCE(v, qpn_min2);
     double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
     return udbl(qpn_min2(qpn_min2(r0, r1), qpn_min2(r2, r3)));
+}
+// min over lanes 0..31 only (two DPP rows); lanes 32..63 are ignored
+__device__ __forceinline__ double wave_min32_f64(double v)
+{
+    QPN_ROW_REDUCE(v, qpn_min2);
+    double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
+    return qpn_min2(r0, r1);
 }
 __device__ __forceinline__ double wave_sum_f64(double v)
 {

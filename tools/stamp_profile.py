@@ -36,7 +36,9 @@ torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.float64)
 piv = res["pivots"].cpu().numpy().mean()
 names = ["setup+load", "loop control", "extract column", "pivot selection", "rank-1 update", "readback+check", "crash fast path"]
+if fused or os.environ.get("SCHUR_NAMES"):
+    names = ["setup+load", "B: column via LDS", "B: ratio test+row", "B: row via LDS+exchange", "B: bookkeeping/flips", "readback+check", "A: MFMA crash"]
 tot = s.sum(axis=1).mean()
-print(f"mean pivots {piv:.1f}, mean cycles per solve {tot:.0f} ({tot/piv:.0f} per pivot)")
+print(f"mean pivots {piv:.1f} (Stage B: {piv - n:.1f}), mean cycles per solve {tot:.0f} ({tot/piv:.0f} per pivot)")
 for i, nm in enumerate(names):
     print(f"  {nm:18s} {s[:, i].mean():10.0f} cycles  {100*s[:, i].mean()/tot:5.1f} %")

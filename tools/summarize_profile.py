@@ -28,7 +28,7 @@ for k, known in (("calib_read8", 1 << 30), ("calib_read16", 1 << 30)):
 v = pmc("calib_write/runc/*counter_collection.csv", "WRITE_SIZE", "calib_write8")
 if v: cal["calib_write8"] = (64 << 20) / 1024.0 / v[0]
 summ = {"calibration_factor_known_over_reported": cal}
-for kern in ("avi_solve_reg", "assemble_nodes"):
+for kern in ("avi_solve_schur", "avi_solve_reg", "assemble_nodes"):
     f = pmc("pmc_fetch/runc/*counter_collection.csv", "FETCH_SIZE", kern)
     wv = pmc("pmc_write/runc/*counter_collection.csv", "WRITE_SIZE", kern)
     if f and wv:
@@ -36,14 +36,16 @@ for kern in ("avi_solve_reg", "assemble_nodes"):
         fcorr = fk * cal.get("calib_read8", 2.0)
         summ[kern] = {"launches": len(f), "FETCH_SIZE_KiB_raw": fk, "FETCH_KiB_corrected": fcorr, "WRITE_SIZE_KiB": wk,
                       "hbm_bytes_per_launch": (fcorr + wk * cal.get("calib_write8", 1.0)) * 1024.0}
+DOM = "avi_solve_schur"      # the dominant kernel of the bench step (fused node path)
 sq = collections.defaultdict(list)
-for r in rows("pmc_sq/runc/*counter_collection.csv"):
-    if "avi_solve_reg" in r["Kernel_Name"]: sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ["avi_solve_reg_sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
+for sub in ("pmc_sq", "pmc_sq_b", "pmc_sq_c"):
+    for r in rows(sub + "/runc/*counter_collection.csv"):
+        if DOM in r["Kernel_Name"]: sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+summ[DOM + "_sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
 json.dump(summ, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
-if "avi_solve_reg" in summ:
-    json.dump({"avi_solve_hbm_bytes_per_launch": summ["avi_solve_reg"]["hbm_bytes_per_launch"],
+if DOM in summ:
+    json.dump({"avi_solve_hbm_bytes_per_launch": summ[DOM]["hbm_bytes_per_launch"], "kernel": DOM,
                "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                          "FETCH_SIZE x calibrated factor)", "solves_per_launch": 10000},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(json.dumps(summ, indent=1)[:1500])
+print(json.dumps(summ, indent=1)[:3000])
