@@ -2,26 +2,37 @@
 //
 // For the item shape the hot path is made of -- a node's reduced KKT system
 //     kinds = [STD free x n | GAVI x m],  n, m <= 32      (M = [[H, C],[A, D]], q = [g; b])
-// -- the crash (Stage A of DESIGN.md section 3: all n free variables enter) is block Gaussian
-// elimination of the H block.  Here it runs as 8 rank-4 block pivots on fp64 matrix cores:
-//   * the 64 x 64 (padded) matrix lives in registers as 4 x 4 tiles of 16 x 16 in the C/D layout of
-//     v_mfma_f64_16x16x4_f64 (lane l, reg g  <->  row (l>>4) + 4g, col l&15); an aligned group of 4
-//     rows IS a B operand, so the pivot rows need no data movement at all;
-//   * per block pivot: the 4 pivot columns go through LDS once (-> A operands), the 4 x 4 pivot block is
-//     inverted redundantly by every lane (uniform), V' = P^-1 V is one MFMA per column tile, and the
-//     rank-4 update of a tile is ONE instruction (1024 multiply-adds) instead of 4 x 16 v_fma_f64
-//     plus their LDS traffic: ~140 MFMAs replace ~8000 VALU/LDS/SALU instructions of the scalar crash.
-// Result: S = D - A H^-1 C (m x m), c = b - A H^-1 g, W = H^-1 C, h = H^-1 g.  Stage B (Lemke) then
-// runs on the 32 x 33 dictionary of S in the same tile layout with v_fma_f64 (a pivot touches 16
-// registers per lane), and x = -(W lambda + h) is recovered at the end.  Post-check, residual and
-// active-set masks are computed on the ORIGINAL blocks exactly as in qpn_avi_reg.hip.
+// -- the crash (Stage A of DESIGN.md section 3: all n free variables enter) is block Gauss-Jordan
+// elimination of the H block.  It runs on fp64 matrix cores:
+//   * only the TOP half [H | C] (32 x 64, padded) is eliminated, as 2 x 4 tiles of 16 x 16 in the C/D
+//     layout of v_mfma_f64_16x16x4_f64 (lane l, reg g  <->  row (l>>4) + 4g, col l&15); an aligned group
+//     of 4 rows IS a B operand, so the pivot rows need no data movement at all;
+//   * per block pivot (8 of them): the 4 pivot columns go through LDS once (-> A operands), the 4 x 4
+//     pivot block is inverted in registers (lane group k computes column k of the inverse, every lane
+//     carries the uniform part), V' = P^-1 V is one MFMA per column tile, and the rank-4 update of a
+//     tile is ONE instruction (1024 multiply-adds);
+//   * the bottom half is never eliminated: with W = H^-1 C and h = H^-1 g in hand,
+//         S = D - A W   (32 MFMAs, A operands straight from the staged A block)   and   c = b - A h.
+//     This is 25 % fewer flops than eliminating all four quadrants and -- the point -- needs 8 live tiles
+//     instead of 16, so THREE waves fit a SIMD (<= 168 VGPRs) instead of two.  The solve is a chain of
+//     dependent LDS / cross-lane / MFMA latencies, and resident waves are what hides them.
+// Stage B (Lemke) then runs on the 32 x 33 dictionary of S in the same tile layout, one MFMA per tile per
+// pivot, and x = -(W lambda + h) is recovered at the end.  Post-check, residual and active-set masks
+// are computed on the ORIGINAL blocks exactly as in qpn_avi_reg.hip.
+//
+// Fused node path (NODES = true, qpn_solve_nodes): M is never materialised.  Qd and Ad are read from HBM
+// ONCE with fully coalesced loads into one 8.5 KB LDS buffer (Qd first, to build the H tiles; then Ad,
+// which stays for the C tiles, the S = -A W operands and the post-check); the post-check re-reads Qd
+// column-wise (lane <-> row: coalesced, served by L2 / Infinity Cache).
 //
 // Items that do not have this shape, or whose H block fails the no-pivoting test
 // (|pivot| >= 1e-4 max(1, max|M|) inside a 4 x 4 block), are flagged (status = -1) and solved by the
 // register kernel in a second, gated launch -- results identical to the general path.
-// Arithmetic differs from the scalar crash only by summation order (block elimination), so primals
-// agree to ~1e-13 and active sets are identical on well-posed items; parity bar: DESIGN.md section 2.
+// Arithmetic differs from the scalar crash only by summation order (block elimination) and Newton
+// reciprocals, so primals agree to ~1e-13 and active sets are identical on well-posed items; parity bar:
+// DESIGN.md section 2.
 #include "qpn_internal.h"
+#include <cstdlib>
 
 #define QINF __builtin_huge_val()
 
@@ -45,19 +56,24 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
 
-// 16 tiles, named (no arrays: see qpn_avi_reg.hip)
+// 8 tiles of the top half, named (no arrays: see qpn_avi_reg.hip)
 #define TL(I, J) tl_##I##_##J
 #define FOR_J(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3)
-#define FOR_IJ(M) FOR_J(M, 0) FOR_J(M, 1) FOR_J(M, 2) FOR_J(M, 3)
+#define FOR_IJ(M) FOR_J(M, 0) FOR_J(M, 1)
 
 struct SchurDebug { double *S, *c, *W, *h; };
 
-// permuted position of row r (0..31) in the Stage-B column vector: lane group q = r&3 reads its 8 rows
-// (r = q + 4g + 16Ib) as 8 consecutive doubles
-__device__ __forceinline__ int perm32(int r) { return (r & 3) * 8 + ((r >> 4) << 2) + ((r >> 2) & 3); }
+// 1/x to ~1 ulp (callers guarantee |x| is well away from 0 on every lane whose result is used)
+__device__ __forceinline__ double rcp64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
 
 template <bool NODES>
-__global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
+__global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
     const int N = NODES ? a.nd.n + a.nd.m : a.N;
     const int l = threadIdx.x;
@@ -65,19 +81,18 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     const int lc = l & 15, lq = l >> 4;
 
     // Stage A scratch (sU: pivot columns, [row][k]) and Stage B / read-back scratch never live at the
-    // same time: one buffer, so that the fused node path (which also keeps the node's Q and A blocks in
-    // LDS for the whole solve) still fits 8 waves per CU.
-    __shared__ __attribute__((aligned(16))) double sbuf[64 * 4];
-    double *const sU = sbuf;                    // Stage A: pivot columns, [row][k]
-    double *const sucol = sbuf;                 // Stage B: pivot column (permuted) + extra   [40]
+    // same time: one buffer.
+    __shared__ __attribute__((aligned(32))) double sbuf[224];
+    double *const sU = sbuf;                    // Stage A: pivot columns of the top half, [32][4]
+    double *const sucol = sbuf;                 // Stage B: entering column + extra          [40]
     double *const svrow = sbuf + 40;            // Stage B: pivot row                         [40]
     double *const sval = sbuf + 80;             // values by variable id                      [66]
-    double *const sz = sbuf + 160;              // solution in item order                     [64]
-    __shared__ __attribute__((aligned(16))) double sP[16];          // P^-1, [i][k]
-    // fused node path: Qd (column stride SQS) and Ad (column stride SAS), read ONCE from HBM
+    double *const sz = sbuf + 160;              // h, then the solution in item order         [64]
+    __shared__ double sq[64];                   // q in item order (fused path; g and b of the header)
+    // fused node path: one block buffer -- Qd (column stride SQS) while the H tiles are built, then Ad
+    // (column stride SAS) for the rest of the solve
     constexpr int SQS = 34, SAS = 33;
-    __shared__ double sQ[NODES ? 32 * SQS : 1];
-    __shared__ double sA[NODES ? 32 * SAS : 1];
+    __shared__ double sA[NODES ? 32 * SQS : 1];
 
     const double *Mg = NODES ? nullptr : a.M + (size_t)b * (size_t)a.strideM;
     const size_t vo = (size_t)b * (size_t)N;
@@ -103,40 +118,42 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
             return a.q[vo + it];
         }
     };
+    // bounds / kind of item row l (re-read where needed rather than kept in registers)
+    auto row_bounds = [&](double &lk_, double &uk_, int &gk_) {
+        lk_ = 0.0; uk_ = 0.0; gk_ = 0;
+        if constexpr (NODES) {
+            if (act) {
+                if (l < nn) { lk_ = -QINF; uk_ = QINF; }
+                else { lk_ = a.nd.l[(size_t)b * nm + (l - nn)]; uk_ = a.nd.u[(size_t)b * nm + (l - nn)]; gk_ = 1; }
+            }
+        } else {
+            lk_ = act ? a.l[vo + l] : 0.0; uk_ = act ? a.u[vo + l] : 0.0;
+            gk_ = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + l] : 0;
+        }
+    };
 
     // ---- structure test: leading free STD rows, then GAVI rows -------------------------------------
-    double lk = 0.0, uk = 0.0;
-    int gk = 0;
-    if constexpr (NODES) {
-        if (act) {
-            if (l < nn) { lk = -QINF; uk = QINF; }
-            else { lk = a.nd.l[(size_t)b * nm + (l - nn)]; uk = a.nd.u[(size_t)b * nm + (l - nn)]; gk = 1; }
-        }
-    } else {
-        lk = act ? a.l[vo + l] : 0.0; uk = act ? a.u[vo + l] : 0.0;
-        gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + l] : 0;
+    int n, m;
+    {
+        double lk, uk; int gk;
+        row_bounds(lk, uk, gk);
+        const bool isfree = act && !gk && lk == -QINF && uk == QINF;
+        const unsigned long long mfree = __ballot(isfree), mg = __ballot(act && gk);
+        n = __popcll(mfree); m = __popcll(mg);
+        const bool shape_ok = n + m == N && n <= 32 && m <= 32 && n >= 1 &&
+                              mfree == ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) &&
+                              mg == ((((m + n) >= 64) ? ~0ull : ((1ull << (m + n)) - 1ull)) & ~((1ull << n) - 1ull));
+        if (!shape_ok) { if (l == 0) a.status[b] = -1; return; }
     }
-    const bool isfree = act && !gk && lk == -QINF && uk == QINF;
-    const unsigned long long mfree = __ballot(isfree), mg = __ballot(act && gk);
-    const int n = __popcll(mfree), m = __popcll(mg);
-    const bool shape_ok = n + m == N && n <= 32 && m <= 32 && n >= 1 &&
-                          mfree == ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) &&
-                          mg == ((((m + n) >= 64) ? ~0ull : ((1ull << (m + n)) - 1ull)) & ~((1ull << n) - 1ull));
-    if (!shape_ok) { if (l == 0) a.status[b] = -1; return; }
 
-    // internal index (0..63) -> item index or -1 (padding): x block 0..31, lambda block 32..63
-    auto item_of = [&](int r) -> int { return r < 32 ? (r < n ? r : -1) : (r - 32 < m ? n + (r - 32) : -1); };
-
-    // ---- load straight into the MFMA tile layout ------------------------------------------------------
+    // ---- load: the top half [H | C] straight into the MFMA tile layout ----------------------------------
 #define M_DECL(I, J) d4 TL(I, J);
     FOR_IJ(M_DECL)
 #undef M_DECL
     double mabs = 0.0;
-    double qit = 0.0;                     // q of item row l (kept for the post-check)
     if constexpr (NODES) {
-        // Stage the node's Qd and Ad blocks in LDS with fully coalesced loads (two columns of 32 rows
-        // per instruction = 512 contiguous bytes when n = m = 32): 32 loads per lane instead of the 64
-        // strided ones of a direct tile load, and the post-check re-reads LDS, not HBM.
+        // Qd and Ad with fully coalesced loads (two columns of 32 rows per instruction = 512 contiguous
+        // bytes when n = m = 32), all 32 + the q loads in flight at once
         const int r5 = l & 31, ch = l >> 5;
         double vq[16], va[16];
 #pragma unroll
@@ -146,129 +163,137 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
             vq[t] = Q_[okq ? (size_t)cj * nn + r5 : 0];
             va[t] = A_[oka ? (size_t)cj * nm + r5 : 0];
         }
-        if (act) qit = qelem(l);
+        sq[l] = act ? qelem(l) : 0.0;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int cj = 2 * t + ch;
-            const bool okq = cj < nn && r5 < nn, oka = cj < nn && r5 < nm;
-            const double q_ = okq ? vq[t] : 0.0, a_ = oka ? va[t] : 0.0;
-            sQ[cj * SQS + r5] = q_;
-            sA[cj * SAS + r5] = a_;
-            mabs = fmax(mabs, fmax(fabs(q_), fabs(a_)));
+            const double q_ = (cj < nn && r5 < nn) ? vq[t] : 0.0;
+            sA[cj * SQS + r5] = q_;
+            mabs = fmax(mabs, fabs(q_));
         }
         __syncthreads();
+#define M_LOADH(I, J)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * (I) + 4 * g + lq, cc = 16 * (J) + lc;                                   \
+        double v = sA[cc * SQS + rr];                                                               \
+        if (rr == cc && rr >= n) v = 1.0;                           /* padded x rows: identity */     \
+        TL(I, J)[g] = v;                                                                            \
     }
+        M_LOADH(0, 0) M_LOADH(0, 1) M_LOADH(1, 0) M_LOADH(1, 1)
+#undef M_LOADH
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            const double a_ = (cj < nn && r5 < nm) ? va[t] : 0.0;
+            sA[cj * SAS + r5] = a_;
+            mabs = fmax(mabs, fabs(a_));
+        }
+        __syncthreads();
+#define M_LOADC(I, J)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * (I) + 4 * g + lq, ck = 16 * ((J) - 2) + lc;                             \
+        const double t_ = sA[rr * SAS + ck];                        /* C = -Ad' */                   \
+        TL(I, J)[g] = (rr < n && ck < m) ? -t_ : 0.0;                                               \
+    }
+        M_LOADC(0, 2) M_LOADC(0, 3) M_LOADC(1, 2) M_LOADC(1, 3)
+#undef M_LOADC
+    } else {
+        // internal index (0..63) -> item index or -1 (padding): x block 0..31, lambda block 32..63
+        auto item_of = [&](int r) -> int { return r < 32 ? (r < n ? r : -1) : (r - 32 < m ? n + (r - 32) : -1); };
 #define M_LOAD(I, J)                                                                                \
     {                                                                                               \
         const int cc = 16 * (J) + lc;                                                               \
+        const int ci = item_of(cc);                                                                 \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
             const int rr = 16 * (I) + 4 * g + lq;                                                   \
-            double v;                                                                               \
-            if constexpr (NODES) {                                                                  \
-                /* the tile's quadrant is static; LDS holds zeros outside the n x n / m x n blocks */ \
-                if constexpr ((I) < 2 && (J) < 2) {                                                 \
-                    v = sQ[cc * SQS + rr];                                                          \
-                    if (rr == cc && rr >= n) v = 1.0;               /* padded x rows: identity */     \
-                } else if constexpr ((I) < 2) {                                                     \
-                    const double t_ = sA[rr * SAS + (cc - 32)];                                     \
-                    v = (rr < n && cc - 32 < m) ? -t_ : 0.0;                                        \
-                } else if constexpr ((J) < 2) v = sA[cc * SAS + (rr - 32)];                         \
-                else v = 0.0;                                                                       \
-            } else {                                                                                \
-                const int ci = item_of(cc), ri = item_of(rr);                                       \
-                const bool valid = ri >= 0 && ci >= 0;                                              \
-                v = Mg[valid ? (size_t)ci * N + ri : 0];                                            \
-                if (!valid) v = (rr == cc && rr < 32) ? 1.0 : 0.0;  /* padded x rows: identity */     \
-                mabs = fmax(mabs, fabs(v));                                                         \
-            }                                                                                       \
+            const bool valid = rr < n && ci >= 0;                                                   \
+            double v = Mg[valid ? (size_t)ci * N + rr : 0];                                         \
+            if (!valid) v = (rr == cc) ? 1.0 : 0.0;                 /* padded x rows: identity */     \
             TL(I, J)[g] = v;                                                                        \
+            mabs = fmax(mabs, fabs(v));                                                             \
         }                                                                                           \
     }
-    FOR_IJ(M_LOAD)
+        FOR_IJ(M_LOAD)
 #undef M_LOAD
-    // extra column: q in internal order, one entry per internal row (lane l <-> internal row l)
-    double kx;
-    {
-        const int it = item_of(l);
-        if constexpr (NODES) { const double t_ = __shfl(qit, it >= 0 ? it : 0, WAVE); kx = it >= 0 ? t_ : 0.0; }
-        else kx = it >= 0 ? qelem(it) : 0.0;
+        // the pivot threshold is relative to max |M| over the WHOLE item: sweep the bottom half too
+        // (rows n.., lane <-> row: coalesced; also warms L2 for the operand loads after the crash)
+        {
+            const bool lowr = l < m;
+            const double *base = Mg + n + (lowr ? l : 0);
+            for (int j = 0; j < N; j += 8) {
+                double mv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = (lowr && j + q8 < N) ? base[(size_t)(j + q8 < N ? j + q8 : 0) * N] : 0.0;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mabs = fmax(mabs, fabs(mv[q8]));
+            }
+        }
     }
+    // extra column: g = q of the x rows, lane l <-> row l of the top half (lanes >= 32 idle)
+    double kx;
+    if constexpr (NODES) kx = (l < n) ? sq[l] : 0.0; else kx = (l < n) ? qelem(l) : 0.0;
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
 
     STAMP(0);   // setup + load
-    // ---- Stage A: 8 rank-4 block pivots on the matrix cores --------------------------------------------
+    // ---- Stage A: 8 rank-4 block pivots of the top half on the matrix cores ------------------------------
+    // Pivot rows carry P - I in sU so that the update T -= U (P^-1 V) turns them into P^-1 V themselves.
     bool fail = false;
 #define M_GATHER(I, JP)                                                                             \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq;                                                       \
         double v = TL(I, JP)[g];                                                                    \
-        if (rr == p0 + kcol) v -= 1.0;              /* pivot rows carry P - I (see header) */        \
+        if (rr == p0 + kcol) v -= 1.0;                                                              \
         sU[rr * 4 + kcol] = v;                                                                      \
     }
-#define M_UPD(I, J) TL(I, J) = MFMA(au##I, vn, TL(I, J));
 #define M_COLTILE(J, IP, GP)                                                                        \
     {                                                                                               \
         const double vraw = TL(IP, J)[GP];                                                          \
         d4 z4 = {0.0, 0.0, 0.0, 0.0};                                                               \
         const d4 vn4 = MFMA(ap, vraw, z4);                                                          \
         const double vn = vn4[0];                                                                   \
-        M_UPD(0, J) M_UPD(1, J) M_UPD(2, J) M_UPD(3, J)                                             \
+        TL(0, J) = MFMA(au0, vn, TL(0, J));                                                         \
+        TL(1, J) = MFMA(au1, vn, TL(1, J));                                                         \
     }
 #define M_STEP(KB, JP, GP)                                                                          \
     if (!fail) {                                                                                    \
         constexpr int p0 = 4 * (KB);                                                                \
         constexpr int cq = p0 & 15;                                                                 \
         const int kcol = lc - cq;                                                                   \
-        if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP) M_GATHER(1, JP) M_GATHER(2, JP) M_GATHER(3, JP) } \
+        if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP) M_GATHER(1, JP) }                              \
         __syncthreads();                                                                            \
-        /* P = pivot block (+I back), inverted by every lane (uniform values) */                    \
-        double p00 = sU[(p0 + 0) * 4 + 0] + 1.0, p01 = sU[(p0 + 0) * 4 + 1], p02 = sU[(p0 + 0) * 4 + 2], p03 = sU[(p0 + 0) * 4 + 3]; \
-        double p10 = sU[(p0 + 1) * 4 + 0], p11 = sU[(p0 + 1) * 4 + 1] + 1.0, p12 = sU[(p0 + 1) * 4 + 2], p13 = sU[(p0 + 1) * 4 + 3]; \
-        double p20 = sU[(p0 + 2) * 4 + 0], p21 = sU[(p0 + 2) * 4 + 1], p22 = sU[(p0 + 2) * 4 + 2] + 1.0, p23 = sU[(p0 + 2) * 4 + 3]; \
-        double p30 = sU[(p0 + 3) * 4 + 0], p31 = sU[(p0 + 3) * 4 + 1], p32 = sU[(p0 + 3) * 4 + 2], p33 = sU[(p0 + 3) * 4 + 3] + 1.0; \
-        double q00 = 1, q01 = 0, q02 = 0, q03 = 0, q10 = 0, q11 = 1, q12 = 0, q13 = 0;              \
-        double q20 = 0, q21 = 0, q22 = 1, q23 = 0, q30 = 0, q31 = 0, q32 = 0, q33 = 1;              \
-        bool okp = fabs(p00) >= diag_thr;                                                           \
-        { const double iv = 1.0 / p00; p01 *= iv; p02 *= iv; p03 *= iv; q00 *= iv;                  \
-          { const double f = p10; p11 -= f * p01; p12 -= f * p02; p13 -= f * p03; q10 -= f * q00; } \
-          { const double f = p20; p21 -= f * p01; p22 -= f * p02; p23 -= f * p03; q20 -= f * q00; } \
-          { const double f = p30; p31 -= f * p01; p32 -= f * p02; p33 -= f * p03; q30 -= f * q00; } } \
-        okp = okp && fabs(p11) >= diag_thr;                                                         \
-        { const double iv = 1.0 / p11; p12 *= iv; p13 *= iv; q10 *= iv; q11 *= iv;                  \
-          { const double f = p01; p02 -= f * p12; p03 -= f * p13; q00 -= f * q10; q01 -= f * q11; } \
-          { const double f = p21; p22 -= f * p12; p23 -= f * p13; q20 -= f * q10; q21 -= f * q11; } \
-          { const double f = p31; p32 -= f * p12; p33 -= f * p13; q30 -= f * q10; q31 -= f * q11; } } \
-        okp = okp && fabs(p22) >= diag_thr;                                                         \
-        { const double iv = 1.0 / p22; p23 *= iv; q20 *= iv; q21 *= iv; q22 *= iv;                  \
-          { const double f = p02; p03 -= f * p23; q00 -= f * q20; q01 -= f * q21; q02 -= f * q22; } \
-          { const double f = p12; p13 -= f * p23; q10 -= f * q20; q11 -= f * q21; q12 -= f * q22; } \
-          { const double f = p32; p33 -= f * p23; q30 -= f * q20; q31 -= f * q21; q32 -= f * q22; } } \
-        okp = okp && fabs(p33) >= diag_thr;                                                         \
-        { const double iv = 1.0 / p33; q30 *= iv; q31 *= iv; q32 *= iv; q33 *= iv;                  \
-          { const double f = p03; q00 -= f * q30; q01 -= f * q31; q02 -= f * q32; q03 -= f * q33; } \
-          { const double f = p13; q10 -= f * q30; q11 -= f * q31; q12 -= f * q32; q13 -= f * q33; } \
-          { const double f = p23; q20 -= f * q30; q21 -= f * q31; q22 -= f * q32; q23 -= f * q33; } } \
+        /* [P | e_lq | x_piv] -> [I | column lq of P^-1 | y = P^-1 x_piv] by Gauss-Jordan */        \
+        double pm[4][4], qv[4], xv[4];                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+            const d4 row = *reinterpret_cast<const d4 *>(sU + (p0 + i) * 4);                        \
+            pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];             \
+            pm[i][i] += 1.0;                                                                        \
+            qv[i] = (lq == i) ? 1.0 : 0.0;                                                          \
+            xv[i] = readlane_f64(kx, p0 + i);                                                       \
+        }                                                                                           \
+        bool okp = true;                                                                            \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
+            okp = okp && fabs(pm[s][s]) >= diag_thr;                                                \
+            const double iv = rcp64(pm[s][s]);                                                      \
+            _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[s][j] *= iv;                       \
+            qv[s] *= iv; xv[s] *= iv;                                                               \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i != s) {                             \
+                const double f = pm[i][s];                                                          \
+                _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]); \
+                qv[i] = fma(-f, qv[s], qv[i]); xv[i] = fma(-f, xv[s], xv[i]);                       \
+            }                                                                                       \
+        }                                                                                           \
         if (!ubool(okp)) { fail = true; }                                                           \
         else {                                                                                      \
-            if (l == 0) {                                                                           \
-                sP[0] = q00; sP[1] = q01; sP[2] = q02; sP[3] = q03; sP[4] = q10; sP[5] = q11; sP[6] = q12; sP[7] = q13; \
-                sP[8] = q20; sP[9] = q21; sP[10] = q22; sP[11] = q23; sP[12] = q30; sP[13] = q31; sP[14] = q32; sP[15] = q33; \
+            /* A operand of V' = P^-1 V: element (i = lc, k = lq) of P^-1, padded to 16 x 4 */      \
+            const double ap = lc == 0 ? qv[0] : lc == 1 ? qv[1] : lc == 2 ? qv[2] : lc == 3 ? qv[3] : 0.0; \
+            /* extra column: kx_i -= sum_k U[i][k] y_k   (lane l <-> row l) */                       \
+            if (l < 32) {                                                                           \
+                const d4 ur = *reinterpret_cast<const d4 *>(sU + l * 4);                            \
+                kx -= ur[0] * xv[0] + ur[1] * xv[1] + ur[2] * xv[2] + ur[3] * xv[3];                \
             }                                                                                       \
-            /* extra column: kx_i -= sum_k U[i][k] (P^-1 kx_piv)[k]   (lane l <-> internal row l) */  \
-            {                                                                                       \
-                const double x0 = readlane_f64(kx, p0 + 0), x1 = readlane_f64(kx, p0 + 1);          \
-                const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);          \
-                const double y0 = q00 * x0 + q01 * x1 + q02 * x2 + q03 * x3;                        \
-                const double y1 = q10 * x0 + q11 * x1 + q12 * x2 + q13 * x3;                        \
-                const double y2 = q20 * x0 + q21 * x1 + q22 * x2 + q23 * x3;                        \
-                const double y3 = q30 * x0 + q31 * x1 + q32 * x2 + q33 * x3;                        \
-                kx -= sU[l * 4 + 0] * y0 + sU[l * 4 + 1] * y1 + sU[l * 4 + 2] * y2 + sU[l * 4 + 3] * y3; \
-            }                                                                                       \
-            __syncthreads();                                                                        \
-            const double ap = lc < 4 ? sP[lc * 4 + lq] : 0.0;       /* A operand: P^-1 padded to 16 x 4 */ \
             const double au0 = -sU[(0 + lc) * 4 + lq], au1 = -sU[(16 + lc) * 4 + lq];               \
-            const double au2 = -sU[(32 + lc) * 4 + lq], au3 = -sU[(48 + lc) * 4 + lq];              \
             if ((JP) <= 0) M_COLTILE(0, JP, GP)                                                     \
             if ((JP) <= 1) M_COLTILE(1, JP, GP)                                                     \
             M_COLTILE(2, JP, GP)                                                                    \
@@ -280,24 +305,87 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     M_STEP(4, 1, 0) M_STEP(5, 1, 1) M_STEP(6, 1, 2) M_STEP(7, 1, 3)
 #undef M_STEP
 #undef M_COLTILE
-#undef M_UPD
 #undef M_GATHER
     if (fail) { if (l == 0) a.status[b] = -1; return; }
+
+    // ---- S = D - A W on the matrix cores, c = b - A h -----------------------------------------------------
+    // W = TL(0..1, 2..3) (rows = x, an aligned group of 4 rows is a B operand), h = kx (lanes 0..31).
+#define SB(Ib, Jb) sb_##Ib##_##Jb
+    d4 SB(0, 0), SB(0, 1), SB(1, 0), SB(1, 1);
+    if (l < 32) sz[l] = kx;
+    if constexpr (NODES) {
+        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+        SB(0, 0) = z4; SB(0, 1) = z4; SB(1, 0) = z4; SB(1, 1) = z4;
+    } else {
+#define M_LOADD(Ib, Jb)                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rk_ = 16 * (Ib) + 4 * g + lq, ck = 16 * (Jb) + lc;                                \
+        const bool valid = rk_ < m && ck < m;                                                       \
+        const double v = Mg[valid ? (size_t)(n + ck) * N + n + rk_ : 0];                            \
+        SB(Ib, Jb)[g] = valid ? v : 0.0;                                                            \
+    }
+        M_LOADD(0, 0) M_LOADD(0, 1) M_LOADD(1, 0) M_LOADD(1, 1)
+#undef M_LOADD
+    }
+    // A operand (16 x 4) of row tile Ib, k-block kk: element (i = lc, k = lq) = -A[16 Ib + lc][4 kk + lq]
+    auto aop = [&](int Ib, int kk) -> double {
+        const int rk_ = 16 * Ib + lc, cj = 4 * kk + lq;
+        if constexpr (NODES) return -sA[cj * SAS + rk_];           // zeros outside m x n already
+        else {
+            const bool valid = rk_ < m && cj < n;
+            const double v = Mg[valid ? (size_t)cj * N + n + rk_ : 0];
+            return valid ? -v : 0.0;
+        }
+    };
+#define M_SK(I, g, kk)                                                                              \
+    {                                                                                               \
+        const double a0_ = aop(0, kk), a1_ = aop(1, kk);                                            \
+        SB(0, 0) = MFMA(a0_, TL(I, 2)[g], SB(0, 0)); SB(0, 1) = MFMA(a0_, TL(I, 3)[g], SB(0, 1));   \
+        SB(1, 0) = MFMA(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = MFMA(a1_, TL(I, 3)[g], SB(1, 1));   \
+    }
+    M_SK(0, 0, 0) M_SK(0, 1, 1) M_SK(0, 2, 2) M_SK(0, 3, 3) M_SK(1, 0, 4) M_SK(1, 1, 5) M_SK(1, 2, 6) M_SK(1, 3, 7)
+#undef M_SK
+    __syncthreads();
+    // c_k = b_k - sum_j A[k][j] h_j, lane k <-> pair k (k < m)
+    double xb = 0.0;
+    {
+        const bool lowr = l < m;
+        const int ls = lowr ? l : 0;
+        double acc;
+        if constexpr (NODES) acc = lowr ? sq[n + ls] : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
+        if constexpr (NODES) {
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) acc = fma(-sA[j * SAS + ls], sz[j], acc);      // zero columns beyond n
+        } else {
+            for (int j = 0; j < n; j += 8) {
+                double mv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = (j + q8 < n) ? Mg[(size_t)(j + q8) * N + n + ls] : 0.0;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) acc = fma(-mv[q8], sz[(j + q8) & 31], acc);
+            }
+        }
+        xb = lowr ? acc : 0.0;
+    }
     STAMP(6);   // crash on the matrix cores
 
     if (dbg.S) {
         // diagnostic builds: dump S (32x32), c, W (32x32), h in row-major
-#define M_DUMP(I, J)                                                                                \
-    if ((J) >= 2) {                                                                                 \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-            const int rr = 16 * (I) + 4 * g + lq, cc = 16 * ((J) - 2) + lc;                         \
-            double *dst = (I) >= 2 ? dbg.S : dbg.W;                                                 \
-            dst[(size_t)b * 1024 + (size_t)(rr & 31) * 32 + cc] = TL(I, J)[g];                      \
-        }                                                                                           \
+#define M_DUMPW(I, J)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * (I) + 4 * g + lq, cc = 16 * ((J) - 2) + lc;                             \
+        dbg.W[(size_t)b * 1024 + (size_t)rr * 32 + cc] = TL(I, J)[g];                               \
     }
-        FOR_IJ(M_DUMP)
-#undef M_DUMP
-        if (l < 32) dbg.h[(size_t)b * 32 + l] = kx; else dbg.c[(size_t)b * 32 + (l - 32)] = kx;
+#define M_DUMPS(Ib, Jb)                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * (Ib) + 4 * g + lq, cc = 16 * (Jb) + lc;                                 \
+        dbg.S[(size_t)b * 1024 + (size_t)rr * 32 + cc] = SB(Ib, Jb)[g];                             \
+    }
+        M_DUMPW(0, 2) M_DUMPW(0, 3) M_DUMPW(1, 2) M_DUMPW(1, 3)
+        M_DUMPS(0, 0) M_DUMPS(0, 1) M_DUMPS(1, 0) M_DUMPS(1, 1)
+#undef M_DUMPW
+#undef M_DUMPS
+        if (l < 32) { dbg.h[(size_t)b * 32 + l] = kx; dbg.c[(size_t)b * 32 + l] = xb; }
         if (l == 0) a.status[b] = -2;
         return;
     }
@@ -319,7 +407,6 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     // pivot is the entering column and the pivot row.
     constexpr int NBP = 32, XC = 32, VTH = 64;
     const bool actb = l < NBP;
-    double xb = __shfl(kx, (l + 32) & 63, WAVE);            // c_k sits in lane 32 + k
     double lo = -QINF, hi = QINF;
     {
         const int it = l < m ? n + l : -1;
@@ -336,13 +423,8 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     double nbval = 0.0, tcol = 0.0;
     int cNvar = VTH;
     double cNval = 0.0;
-    __syncthreads();                      // Stage A is done with sbuf
+    __syncthreads();                      // Stage A and the c sweep are done with sbuf
 
-#define SB(Ib, Jb) TL_S_##Ib##_##Jb
-#define TL_S_0_0 TL(2, 2)
-#define TL_S_0_1 TL(2, 3)
-#define TL_S_1_0 TL(3, 2)
-#define TL_S_1_1 TL(3, 3)
     // loop-invariant operand roles of this lane (K slot = lq)
     const double kA = lq < 2 ? -1.0 : 1.0;            // A operand on the pivot row
     const double cA0 = lq == 1 ? -1.0 : 0.0;          // A = u * coefA elsewhere (coefA = inv on slot 2)
@@ -352,14 +434,6 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
         if (cc < 0 && cNvar == v) cc = XC;
         return cc;
     };
-    // 1/x to ~1 ulp (|x| > piv_tol on every lane whose result is used)
-    auto rcp64 = [](double x) -> double {
-        double r = __builtin_amdgcn_rcp(x);
-        double e = fma(-x, r, 1.0); r = fma(r, e, r);
-        e = fma(-x, r, 1.0); r = fma(r, e, r);
-        return r;
-    };
-
     int pivots = n;                       // the crash brought n free variables in (Stage A)
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
     int status = QPN_FAILURE;
@@ -559,27 +633,46 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_schur(AviBatchArgs a, Schur
     __syncthreads();
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
+    double lk, uk; int gk;
+    row_bounds(lk, uk, gk);
     double rk;
-    if constexpr (NODES) rk = qit; else rk = act ? qelem(l) : 0.0;
     if constexpr (NODES) {
-        // r = q + M z from the LDS copies of the node blocks, item columns in ascending order; a zero
-        // z_j contributes exactly nothing (finite blocks)
+        // r = q + M z, item columns in ascending order; a zero z_j contributes exactly nothing (finite
+        // blocks).  x rows read Qd column-wise from global memory (lane <-> row: coalesced, L2 / Infinity
+        // Cache hits) and their -Ad' part from LDS; constraint rows read Ad from LDS.
+        rk = sq[l];
         const bool isx = l < nn;
         const int ls = act ? (isx ? l : l - nn) : 0;
-        const double *colb = isx ? sQ + ls : sA + ls;          // column sweep base of this row
-        const int cst = isx ? SQS : SAS;
-        const double *rowb = sA + (isx ? ls : 0) * SAS;        // row of A' for x rows
-#pragma unroll 8
-        for (int j = 0; j < nn; ++j) {                         // columns of x: Q (x rows) or A (constraint rows)
-            const double mv = colb[j * cst], zj = sz[j];
+        const double *qcol = Q_ + (isx ? ls : 0);
+        const int aoff = isx ? 0 : ls, roff = (isx ? ls : 0) * SAS;   // column of Ad (constraint rows) / row of Ad' (x rows)
+        int j = 0;
+        for (; j + 8 <= nn; j += 8) {
+            double mq[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) mq[q8] = qcol[(size_t)(j + q8) * nn];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) {
+                double ma = sA[(j + q8) * SAS + aoff];
+                asm volatile("" : "+v"(ma));        // keep the LDS read a read (no select of pointers)
+                const double zj = sz[j + q8];
+                const double mv = isx ? mq[q8] : ma;
+                rk = (zj != 0.0) ? fma(mv, zj, rk) : rk;
+            }
+        }
+        for (; j < nn; ++j) {
+            double ma = sA[j * SAS + aoff];
+            asm volatile("" : "+v"(ma));
+            const double zj = sz[j], mq1 = qcol[(size_t)j * nn];
+            const double mv = isx ? mq1 : ma;
             rk = (zj != 0.0) ? fma(mv, zj, rk) : rk;
         }
 #pragma unroll 8
         for (int k = 0; k < nm; ++k) {                         // columns of lambda: -A' (x rows only)
-            const double mv = -rowb[k], zj = sz[nn + k];
+            const double mv = -sA[roff + k], zj = sz[nn + k];
             rk = (zj != 0.0 && isx) ? fma(mv, zj, rk) : rk;
         }
     } else {
+        rk = act ? qelem(l) : 0.0;
         int j = 0;
         for (; j + 8 <= N; j += 8) {
             double mv[8];
@@ -649,6 +742,7 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
 {
     if (a.batch <= 0) return hipSuccess;
     SchurDebug d{nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(avi_solve_schur<true>, dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+    static const unsigned pad = [] { const char *e = getenv("QPN_DEBUG_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    hipLaunchKernelGGL(avi_solve_schur<true>, dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
     return hipGetLastError();
 }
