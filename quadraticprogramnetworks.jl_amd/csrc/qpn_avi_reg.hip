@@ -82,16 +82,15 @@ __device__ __forceinline__ void interval_uni(int v, int N, const double *sl, con
     else { lo = 0.0; hi = QINF; }
 }
 
+// One item, one wavefront (the whole kernel body; see avi_solve_reg below for how items are picked).
 template <int BS>
-__global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
+__device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const int b)
 {
     using G = Geo<BS>;
     constexpr int NB = G::NB, PB = G::PB, NP = G::NP;
     constexpr int XC = NB;                 // index of the extra (covering) column
     const int N = a.N;
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    if (a.only_if && a.only_if[b] != a.only_if_value) return;   // wave-uniform gate
     const int ra = lane >> 3, cb = lane & 7;
     const bool act = lane < N;             // this lane carries row `lane` / column `lane`
 
@@ -810,12 +809,69 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 #endif
 }
 
+// Item selection.  Plain kernel: block b solves item b (optionally gated on only_if[b]).
+template <int BS>
+__global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
+{
+    const int b = blockIdx.x;
+    if (a.only_if && a.only_if[b] != a.only_if_value) return;   // wave-uniform gate
+    avi_solve_reg_item<BS>(a, b);
+}
+
+// Scan kernel (a.scan): the grid is small and fixed; block g looks at items g, g + G, g + 2G, ... (64 at
+// a time, one per lane) and solves the ones whose only_if entry matches, one after the other -- the
+// fallback pass behind the MFMA kernel costs one near-empty launch instead of `batch` blocks that exit
+// at once (and, for qpn_solve_nodes, no separate gated assembly launch).
+template <int BS>
+__global__ __launch_bounds__(WAVE, 2) void avi_solve_reg_scan(AviBatchArgs a)
+{
+    const int lane = threadIdx.x;
+    const long G = gridDim.x;
+    {
+        // the common case first: nothing in this block's share is flagged -> leave before any of the
+        // solver's set-up code runs
+        bool any = false;
+        for (long t0 = 0; blockIdx.x + G * t0 < a.batch; t0 += WAVE) {
+            const long bb = blockIdx.x + G * (t0 + lane);
+            any = any || (bb < a.batch && a.only_if[bb < a.batch ? bb : 0] == a.only_if_value);
+        }
+        if (__ballot(any) == 0ull) return;
+    }
+    for (long t0 = 0; blockIdx.x + G * t0 < a.batch; t0 += WAVE) {
+        const long bb = blockIdx.x + G * (t0 + lane);
+        unsigned long long pick = __ballot(bb < a.batch && a.only_if[bb < a.batch ? bb : 0] == a.only_if_value);
+        while (pick) {
+            const int i = __ffsll((long long)pick) - 1;
+            pick &= pick - 1ull;
+            const int b = (int)(blockIdx.x + G * (t0 + i));
+            if (a.assemble_first) {
+                qpn_assemble_item(a.nd, b, lane, const_cast<double *>(a.M), const_cast<double *>(a.q),
+                                  const_cast<double *>(a.l), const_cast<double *>(a.u),
+                                  const_cast<uint8_t *>(a.kind));
+                __threadfence();
+                __syncthreads();
+            }
+            avi_solve_reg_item<BS>(a, b);
+            __syncthreads();
+        }
+    }
+}
+
 } // namespace
 
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream)
 {
     if (a.batch <= 0) return hipSuccess;
-    const dim3 grid((unsigned)a.batch), block(WAVE);
+    const dim3 block(WAVE);
+    if (a.scan) {
+        const dim3 grid((unsigned)(a.batch < 2048 ? a.batch : 2048));
+        if (a.N <= 8) hipLaunchKernelGGL(avi_solve_reg_scan<1>, grid, block, 0, stream, a);
+        else if (a.N <= 16) hipLaunchKernelGGL(avi_solve_reg_scan<2>, grid, block, 0, stream, a);
+        else if (a.N <= 32) hipLaunchKernelGGL(avi_solve_reg_scan<4>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(avi_solve_reg_scan<8>, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    const dim3 grid((unsigned)a.batch);
     if (a.N <= 8) hipLaunchKernelGGL(avi_solve_reg<1>, grid, block, 0, stream, a);
     else if (a.N <= 16) hipLaunchKernelGGL(avi_solve_reg<2>, grid, block, 0, stream, a);
     else if (a.N <= 32) hipLaunchKernelGGL(avi_solve_reg<4>, grid, block, 0, stream, a);

@@ -63,6 +63,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct SchurDebug { double *S, *c, *W, *h; };
 
+// The workgroup IS one wavefront: LDS operations of a wave execute in issue order, so ordering between
+// a lane's store and another lane's load needs no s_barrier and no drain of the memory counters -- only
+// that the compiler keeps the program order of the LDS accesses (it must: they may alias) and does not
+// move them across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // 1/x to ~1 ulp (callers guarantee |x| is well away from 0 on every lane whose result is used)
 __device__ __forceinline__ double rcp64(double x)
 {
@@ -110,9 +121,23 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     const double *w_ = NODES ? a.nd.w + (size_t)b * (size_t)a.nd.stride_w : nullptr;
     auto qelem = [&](int it) -> double {
         if constexpr (NODES) {
-            double s;
-            if (it < nn) { s = a.nd.qd[(size_t)b * nn + it]; for (int k = 0; k < np_; ++k) s = fma(R_[(size_t)k * nn + it], w_[k], s); }
-            else { s = 0.0; for (int k = 0; k < np_; ++k) s = fma(B_[(size_t)k * nm + (it - nn)], w_[k], s); }
+            // q = [qd + R w; B w]; the p terms are added in ascending order (same fma chain as the
+            // assemble kernel), but loaded eight at a time so that the loads are in flight together
+            const bool isx = it < nn;
+            const double *col = isx ? R_ + it : B_ + (it - nn);
+            const size_t cs = isx ? (size_t)nn : (size_t)nm;
+            double s = isx ? a.nd.qd[(size_t)b * nn + it] : 0.0;
+            for (int k0 = 0; k0 < np_; k0 += 8) {
+                double rv[8], wv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool ok = k0 + k < np_;
+                    rv[k] = col[ok ? (size_t)(k0 + k) * cs : 0];
+                    wv[k] = w_[ok ? k0 + k : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s = (k0 + k < np_) ? fma(rv[k], wv[k], s) : s;
+            }
             return s;
         } else {
             return a.q[vo + it];
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             sA[cj * SQS + r5] = q_;
             mabs = fmax(mabs, fabs(q_));
         }
-        __syncthreads();
+        wave_sync();
 #define M_LOADH(I, J)                                                                               \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq, cc = 16 * (J) + lc;                                   \
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     }
         M_LOADH(0, 0) M_LOADH(0, 1) M_LOADH(1, 0) M_LOADH(1, 1)
 #undef M_LOADH
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int cj = 2 * t + ch;
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             sA[cj * SAS + r5] = a_;
             mabs = fmax(mabs, fabs(a_));
         }
-        __syncthreads();
+        wave_sync();
 #define M_LOADC(I, J)                                                                               \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq, ck = 16 * ((J) - 2) + lc;                             \
@@ -262,7 +287,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         constexpr int cq = p0 & 15;                                                                 \
         const int kcol = lc - cq;                                                                   \
         if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP) M_GATHER(1, JP) }                              \
-        __syncthreads();                                                                            \
+        wave_sync();                                                                            \
         /* [P | e_lq | x_piv] -> [I | column lq of P^-1 | y = P^-1 x_piv] by Gauss-Jordan */        \
         double pm[4][4], qv[4], xv[4];                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             if ((JP) <= 1) M_COLTILE(1, JP, GP)                                                     \
             M_COLTILE(2, JP, GP)                                                                    \
             M_COLTILE(3, JP, GP)                                                                    \
-            __syncthreads();                                                                        \
+            wave_sync();                                                                        \
         }                                                                                           \
     }
     M_STEP(0, 0, 0) M_STEP(1, 0, 1) M_STEP(2, 0, 2) M_STEP(3, 0, 3)
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     }
     M_SK(0, 0, 0) M_SK(0, 1, 1) M_SK(0, 2, 2) M_SK(0, 3, 3) M_SK(1, 0, 4) M_SK(1, 1, 5) M_SK(1, 2, 6) M_SK(1, 3, 7)
 #undef M_SK
-    __syncthreads();
+    wave_sync();
     // c_k = b_k - sum_j A[k][j] h_j, lane k <-> pair k (k < m)
     double xb = 0.0;
     {
@@ -423,7 +448,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     double nbval = 0.0, tcol = 0.0;
     int cNvar = VTH;
     double cNval = 0.0;
-    __syncthreads();                      // Stage A and the c sweep are done with sbuf
+    wave_sync();                      // Stage A and the c sweep are done with sbuf
 
     // loop-invariant operand roles of this lane (K slot = lq)
     const double kA = lq < 2 ? -1.0 : 1.0;            // A operand on the pivot row
@@ -478,7 +503,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
                 for (int g = 0; g < 4; ++g) { sucol[4 * g + lq] = SB(0, 1)[g]; sucol[16 + 4 * g + lq] = SB(1, 1)[g]; }
             }
         }
-        __syncthreads();
+        wave_sync();
         const double cm = actb ? sucol[l] : 0.0;
         STAMP(1);   // entering column through LDS
         // ---- ratio test (same rule as the general kernel; reciprocal by Newton instead of a division)
@@ -515,7 +540,14 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             sneg = au != 0;
             self_lim = QINF;
             if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
-            __syncthreads();
+            wave_sync();
+            {
+                // a null exchange (A = 0): keeps every path through the loop body writing the tiles with
+                // an MFMA in place, so the accumulators are never copied at the loop edge
+                const double z0 = 0.0;
+                SB(0, 0) = MFMA(z0, z0, SB(0, 0)); SB(0, 1) = MFMA(z0, z0, SB(0, 1));
+                SB(1, 0) = MFMA(z0, z0, SB(1, 0)); SB(1, 1) = MFMA(z0, z0, SB(1, 1));
+            }
             continue;
         }
         int r;
@@ -545,7 +577,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         const int vl = readlane_i32(rowvar, r);
         const double vxr = readlane_f64(tcol, r);
         const double enter_val = ((c == XC) ? cNval : readlane_f64(nbval, c)) + delta;
-        __syncthreads();
+        wave_sync();
         {
             // extra column and values (lane l <-> row l)
             const double ninv = -inv;
@@ -556,10 +588,12 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             xb = xbn; tcol = tcn;
             // the exchange on the four S tiles: one MFMA each (see the header of this stage)
             const double coefA = lq == 2 ? inv : cA0, coefB = lq == 1 ? inv : cB0, kB = lq == 3 ? inv : 1.0;
-            const double a0 = (lc == r) ? kA : sucol[lc] * coefA;
-            const double a1 = (16 + lc == r) ? kA : sucol[16 + lc] * coefA;
-            const double b0 = (lc == c && lq != 0) ? kB : svrow[lc] * coefB;
-            const double b1 = (16 + lc == c && lq != 0) ? kB : svrow[16 + lc] * coefB;
+            double ua = sucol[lc], ub = sucol[16 + lc], pa = svrow[lc], pb = svrow[16 + lc];
+            asm volatile("" : "+v"(ua), "+v"(ub), "+v"(pa), "+v"(pb));     // four reads in flight, no branches
+            const double a0 = (lc == r) ? kA : ua * coefA;
+            const double a1 = (16 + lc == r) ? kA : ub * coefA;
+            const double b0 = (lc == c && lq != 0) ? kB : pa * coefB;
+            const double b1 = (16 + lc == c && lq != 0) ? kB : pb * coefB;
             SB(0, 0) = MFMA(a0, b0, SB(0, 0));
             SB(0, 1) = MFMA(a0, b1, SB(0, 1));
             SB(1, 0) = MFMA(a1, b0, SB(1, 0));
@@ -601,16 +635,16 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         }
         c = col_of(vn);
         if (c < 0) { status = QPN_FAILURE; break; }
-        __syncthreads();
+        wave_sync();
         STAMP(4);
     }
 
     STAMP(4);   // Lemke: bookkeeping + flips
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
-    __syncthreads();
+    wave_sync();
     if (actb) { sval[rowvar] = xb; sval[colvar] = nbval; }
     if (l == 0) sval[cNvar] = cNval;
-    __syncthreads();
+    wave_sync();
     const double lam0 = sval[NBP + lc], lam1 = sval[NBP + 16 + lc];     // lambda of this lane's two columns
     {
         // partial row sums of W lambda over this lane's columns, reduced across the 16 lanes of a DPP row
@@ -624,13 +658,13 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         M_WROW(1, 0, 4) M_WROW(1, 1, 5) M_WROW(1, 2, 6) M_WROW(1, 3, 7)
 #undef M_WROW
     }
-    __syncthreads();
+    wave_sync();
     // item order: rows < n are x, rows n.. are lambda
     double zk = 0.0;
     if (act) zk = l < n ? -(sz[l] + kx) : sval[NBP + (l - n)];
-    __syncthreads();
+    wave_sync();
     if (act) sz[l] = zk;
-    __syncthreads();
+    wave_sync();
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
     double lk, uk; int gk;

@@ -429,7 +429,7 @@ hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream)
     hipError_t e = qpn_launch_avi_solve_schur(a, nullptr, nullptr, nullptr, nullptr, stream);
     if (e != hipSuccess) return e;
     AviBatchArgs g = a;
-    g.only_if = a.status; g.only_if_value = -1;
+    g.only_if = a.status; g.only_if_value = -1; g.scan = 1;
     return qpn_launch_avi_solve_reg(g, stream);
 }
 

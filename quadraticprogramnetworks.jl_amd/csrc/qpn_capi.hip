@@ -472,12 +472,12 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
     if (mfma_shape) {
         // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
+        // (one small scan-mode launch: its waves pick the flagged items, assemble their blocks into the
+        // workspace and solve them)
         HIPCHK(ctx, qpn_launch_avi_solve_schur_nodes(a, s));
-        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, wM, wq, wl,
-                                              wu, wk, s, dst, -1));
         AviBatchArgs g = a;
         g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
-        g.only_if = dst; g.only_if_value = -1;
+        g.only_if = dst; g.only_if_value = -1; g.scan = 1; g.assemble_first = 1;
         HIPCHK(ctx, qpn_launch_avi_solve_reg(g, s));
     } else {
         HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, wM, wq, wl,

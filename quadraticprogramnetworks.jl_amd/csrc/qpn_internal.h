@@ -35,6 +35,11 @@ struct AviBatchArgs {
     // optional gate: item b runs only when only_if[b] == only_if_value (others are left untouched)
     const int32_t *only_if;
     int32_t only_if_value;
+    // compact form of the gate (register kernel only): scan != 0 launches a SMALL grid whose waves scan
+    // only_if[] and solve just the matching items, one after the other; with assemble_first != 0 the
+    // item's blocks are first assembled from `nd` into M/q/l/u/kind (the fallback of qpn_solve_nodes).
+    int32_t scan;
+    int32_t assemble_first;
     // diagnostic builds only (-DQPN_STAMPS): per-item cycle sums per phase, [batch][8] uint64
     unsigned long long *stamps;
     NodeSrc nd;      // used by the fused node path only
@@ -83,6 +88,46 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
 
 // ---- wave64 helpers (CDNA4: one wavefront = 64 lanes) --------------------------------
 #ifdef __HIPCC__
+// (A5+A6) reduced single-node KKT assembly of item b by ONE wavefront (src/avi.jl:205-251 + :305-377):
+// M = [[Qd, -Ad'],[Ad, 0]] column-major, q = [qd + R w; B w], bounds [free; l..u], kinds [STD; GAVI].
+// Column j of M (length N = n+m) is written by lanes striding the rows: coalesced.
+__device__ __forceinline__ void qpn_assemble_item(const NodeSrc &nd, int b, int lane, double *Mout,
+                                                  double *qout, double *lout, double *uout,
+                                                  uint8_t *kind_out)
+{
+    const int n = nd.n, m = nd.m, p = nd.p, N = n + m;
+    const double *Q_ = nd.Qd + (size_t)b * n * n;
+    const double *A_ = nd.Ad + (size_t)b * m * n;
+    const double *R_ = nd.R + (size_t)b * n * p;
+    const double *B_ = nd.B + (size_t)b * m * p;
+    const double *w_ = nd.w + (size_t)b * (size_t)nd.stride_w;
+    double *Mo = Mout + (size_t)b * N * N;
+    const size_t vo = (size_t)b * (size_t)N;
+    // columns 0..n-1: [Qd(:,j) ; Ad(:,j)]
+    for (int j = 0; j < n; ++j)
+        for (int i = lane; i < N; i += 64)
+            Mo[(size_t)j * N + i] = i < n ? Q_[(size_t)j * n + i] : A_[(size_t)j * m + (i - n)];
+    // columns n..N-1: [-Ad(c,:)' ; 0]
+    for (int c = 0; c < m; ++c)
+        for (int i = lane; i < N; i += 64)
+            Mo[(size_t)(n + c) * N + i] = i < n ? -A_[(size_t)i * m + c] : 0.0;
+    for (int i = lane; i < N; i += 64) {
+        double s;
+        if (i < n) {
+            s = nd.qd[(size_t)b * n + i];
+            for (int k = 0; k < p; ++k) s = fma(R_[(size_t)k * n + i], w_[k], s);
+            lout[vo + i] = -__builtin_huge_val(); uout[vo + i] = __builtin_huge_val(); kind_out[vo + i] = QPN_ROW_STD;
+        } else {
+            const int r = i - n;
+            s = 0.0;
+            for (int k = 0; k < p; ++k) s = fma(B_[(size_t)k * m + r], w_[k], s);
+            lout[vo + i] = nd.l[(size_t)b * m + r]; uout[vo + i] = nd.u[(size_t)b * m + r];
+            kind_out[vo + i] = QPN_ROW_GAVI;
+        }
+        qout[vo + i] = s;
+    }
+}
+
 __device__ __forceinline__ double udbl(double v);
 // ---- DPP / readlane based wave64 primitives (no LDS round trips) -------------------------
 // dpp_ctrl encodings (GFX9): quad_perm = 0x00..0xFF, row_half_mirror = 0x141, row_mirror = 0x140

@@ -82,39 +82,8 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(
     const int b = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (b >= batch) return;
     if (only_if && only_if[b] != only_if_value) return;   // gated (fallback of the fused node path)
-    const int N = n + m;
-    const double *Q_ = Qd + (size_t)b * n * n;
-    const double *A_ = Ad + (size_t)b * m * n;
-    const double *R_ = R + (size_t)b * n * p;
-    const double *B_ = B + (size_t)b * m * p;
-    const double *w_ = w + (size_t)b * (size_t)stride_w;
-    double *Mo = Mout + (size_t)b * N * N;
-    const size_t vo = (size_t)b * (size_t)N;
-    // columns 0..n-1: [Qd(:,j) ; Ad(:,j)]
-    for (int j = 0; j < n; ++j) {
-        for (int i = lane; i < N; i += WAVE)
-            Mo[(size_t)j * N + i] = i < n ? Q_[(size_t)j * n + i] : A_[(size_t)j * m + (i - n)];
-    }
-    // columns n..N-1: [-Ad(c,:)' ; 0]
-    for (int c = 0; c < m; ++c) {
-        for (int i = lane; i < N; i += WAVE)
-            Mo[(size_t)(n + c) * N + i] = i < n ? -A_[(size_t)i * m + c] : 0.0;
-    }
-    for (int i = lane; i < N; i += WAVE) {
-        double s;
-        if (i < n) {
-            s = qd[(size_t)b * n + i];
-            for (int k = 0; k < p; ++k) s = fma(R_[(size_t)k * n + i], w_[k], s);
-            lout[vo + i] = -QINF; uout[vo + i] = QINF; kind_out[vo + i] = QPN_ROW_STD;
-        } else {
-            const int r = i - n;
-            s = 0.0;
-            for (int k = 0; k < p; ++k) s = fma(B_[(size_t)k * m + r], w_[k], s);
-            lout[vo + i] = l[(size_t)b * m + r]; uout[vo + i] = u[(size_t)b * m + r];
-            kind_out[vo + i] = QPN_ROW_GAVI;
-        }
-        qout[vo + i] = s;
-    }
+    const NodeSrc nd{n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w};
+    qpn_assemble_item(nd, b, lane, Mout, qout, lout, uout, kind_out);
 }
 
 } // namespace
