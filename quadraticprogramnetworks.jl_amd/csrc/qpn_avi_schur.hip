@@ -418,16 +418,14 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     // ================= Stage B: Lemke on the Schur dictionary (32 pairs, tile layout) =================
     // pair k (k < 32) <-> item row n + k:  p_k = s_k = (S lambda + c)_k in [l_k, u_k],  d_k = lambda_k.
     // ids: p_k -> k, d_k -> 32 + k, artificial -> 64; column index 32 = the extra (covering) column.
-    // The loop is bound by instruction issue, not by flops, so the whole Gauss-Jordan exchange of a pivot
-    // (rank-1 update, new pivot row, new pivot column, new pivot element) is folded into ONE
-    // v_mfma_f64_16x16x4 per tile, using all four K slots in the order the matrix core accumulates them
-    // (k = 0, 1, 2, 3; bitwise an fma chain, tools/mfma_f64_probe.hip):
-    //     k=0:  A = -e_r            B = pivot row (raw)          row r := 0              (exactly)
-    //     k=1:  A = -u  (u_r := 1)  B = v = row*inv (v_c := 1)   T -= u v'; row r := -v; column c := 0; (r,c) = -1
-    //     k=2:  A = u*inv (r: 1)    B = e_c                      column c := u*inv;      (r,c) = 0
-    //     k=3:  A = e_r             B = inv * e_c                (r,c) := inv
-    // Every entry gets exactly the value the scalar exchange gives it; there is no lane- or
-    // register-dependent fix-up code and the dictionary never leaves the accumulator registers.
+    // The loop is bound by instruction issue.  On gfx950 an fp64 MFMA occupies the SIMD's fp64 pipe for as
+    // long as the 16 v_fma_f64 it replaces and does not overlap with other VALU work
+    // (tools/mfma_valu_overlap.hip), so a RANK-1 exchange -- which would waste 3 of the 4 K slots -- is done
+    // with v_fma_f64: 16 per lane, in place, plus lane-masked fix-ups of the pivot column (8 v_mul_f64 on
+    // the 4 owner lanes) and the pivot row (2 v_mov_b64 on the 16 owner lanes).  The whole exchange is ONE
+    // asm block: the compiler sees 16 read-modify-write registers, so the dictionary is never copied,
+    // selected or spilled whatever the control flow around it; EXEC narrowing and the uniform
+    // column-tile / row-register dispatch live inside the block.
     // Pair bounds / bound flags sit in lane k and are fetched with v_readlane; the only LDS traffic per
     // pivot is the entering column and the pivot row.
     constexpr int NBP = 32, XC = 32, VTH = 64;
@@ -450,10 +448,13 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     double cNval = 0.0;
     wave_sync();                      // Stage A and the c sweep are done with sbuf
 
-    // loop-invariant operand roles of this lane (K slot = lq)
-    const double kA = lq < 2 ? -1.0 : 1.0;            // A operand on the pivot row
-    const double cA0 = lq == 1 ? -1.0 : 0.0;          // A = u * coefA elsewhere (coefA = inv on slot 2)
-    const double cB0 = lq == 0 ? 1.0 : 0.0;           // B = row * coefB (coefB = inv on slot 1) off the pivot column
+    // the dictionary as 16 named doubles: element g of tile (Ib, Jb) = row 16 Ib + 4 g + lq, column 16 Jb + lc
+#define SD(Ib, Jb, g) s##Ib##Jb##_##g
+#define M_SDECL(Ib, Jb)                                                                             \
+    double SD(Ib, Jb, 0) = SB(Ib, Jb)[0], SD(Ib, Jb, 1) = SB(Ib, Jb)[1], SD(Ib, Jb, 2) = SB(Ib, Jb)[2],     \
+           SD(Ib, Jb, 3) = SB(Ib, Jb)[3];
+    M_SDECL(0, 0) M_SDECL(0, 1) M_SDECL(1, 0) M_SDECL(1, 1)
+#undef M_SDECL
     auto col_of = [&](int v) -> int {
         int cc = wave_first(actb && colvar == v);
         if (cc < 0 && cNvar == v) cc = XC;
@@ -492,19 +493,16 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     while (status == QPN_MAX_ITERS) {
         if (pivots >= max_piv) break;
         c = uni(c);
-        // ---- entering column -> sucol, plain row order
-        if (c == XC) { if (actb) sucol[l] = tcol; }
+        // ---- entering column -> sucol, permuted so that a lane group reads its 8 rows as 8 consecutive doubles
+        // (row r = q + 4 g + 16 Ib sits at q*8 + 4 Ib + g)
+        if (c == XC) { if (actb) sucol[(l & 3) * 8 + ((l >> 4) << 2) + ((l >> 2) & 3)] = tcol; }
         else if (lc == (c & 15)) {
-            if (c < 16) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { sucol[4 * g + lq] = SB(0, 0)[g]; sucol[16 + 4 * g + lq] = SB(1, 0)[g]; }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { sucol[4 * g + lq] = SB(0, 1)[g]; sucol[16 + 4 * g + lq] = SB(1, 1)[g]; }
-            }
+            d4 *const dst = reinterpret_cast<d4 *>(sucol + lq * 8);
+            if (c < 16) { dst[0] = d4{SD(0, 0, 0), SD(0, 0, 1), SD(0, 0, 2), SD(0, 0, 3)}; dst[1] = d4{SD(1, 0, 0), SD(1, 0, 1), SD(1, 0, 2), SD(1, 0, 3)}; }
+            else { dst[0] = d4{SD(0, 1, 0), SD(0, 1, 1), SD(0, 1, 2), SD(0, 1, 3)}; dst[1] = d4{SD(1, 1, 0), SD(1, 1, 1), SD(1, 1, 2), SD(1, 1, 3)}; }
         }
         wave_sync();
-        const double cm = actb ? sucol[l] : 0.0;
+        const double cm = actb ? sucol[(l & 3) * 8 + ((l >> 4) << 2) + ((l >> 2) & 3)] : 0.0;
         STAMP(1);   // entering column through LDS
         // ---- ratio test (same rule as the general kernel; reciprocal by Newton instead of a division)
         const double gdir = sneg ? -cm : cm;
@@ -520,6 +518,11 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         if (ubool(dmax == QINF)) { status = QPN_RAY_TERM; break; }
         const bool cand = cnd && dd <= dmax;
         const unsigned long long bal = __ballot(cand);
+        // Both outcomes below end in the SAME exchange block (a bound flip runs it with v = 0 and empty lane
+        // masks: a no-op), so the dictionary registers have one definition per iteration.
+        double v0 = 0.0, v1 = 0.0, inv = 0.0;
+        unsigned long long mcol = 0ull, mrow = 0ull;
+        int cx = XC, rsel = 0, cnext;
         if (bal == 0ull) {
             // the entering variable reaches its own opposite bound first: no basis change
             const double dl = sneg ? -self_lim : self_lim;
@@ -535,111 +538,159 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             if (l == k) satv = au;
             if (c == XC) cNval = nv; else if (l == c) nbval = nv;
             pivots++;
-            c = col_of(NBP + k);
-            if (c < 0) { status = QPN_FAILURE; break; }
+            cnext = col_of(NBP + k);
+            if (cnext < 0) { status = QPN_FAILURE; break; }
             sneg = au != 0;
             self_lim = QINF;
             if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+            STAMP(4);
+        } else {
+            int r;
+            if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
+            else {
+                double ag = cand ? fabs(gdir) : -1.0;
+                if (cand && rowvar == VTH) ag = QINF;
+                const double bestg = wave_max_f64(ag);
+                r = wave_first(cand && ag == bestg);
+            }
+            r = uni(r);
+            STAMP(2);   // ratio test + row choice
+            // ---- pivot row r -> svrow (raw): the 16 lanes that hold it pick the register under a uniform tree
+            const int rq = r & 3;
+            rsel = ((r >> 4) << 2) | ((r >> 2) & 3);      // leaf = Ib*4 + g
+            if (lq == rq) {
+#define M_XROW(Ib, g) { svrow[lc] = SD(Ib, 0, g); svrow[16 + lc] = SD(Ib, 1, g); }
+                if (rsel < 4) { if (rsel < 2) { if (rsel < 1) M_XROW(0, 0) else M_XROW(0, 1) } else { if (rsel < 3) M_XROW(0, 2) else M_XROW(0, 3) } }
+                else { if (rsel < 6) { if (rsel < 5) M_XROW(1, 0) else M_XROW(1, 1) } else { if (rsel < 7) M_XROW(1, 2) else M_XROW(1, 3) } }
+#undef M_XROW
+            }
+            double step = readlane_f64(dd, r);
+            if (step < 0.0) step = 0.0;
+            const double leave_val = readlane_f64(cndlo ? lo : hi, r);
+            const double rcr = readlane_f64(rc, r);
+            inv = sneg ? -rcr : rcr;
+            const double delta = sneg ? -step : step;
+            const int vl = readlane_i32(rowvar, r);
+            const double vxr = readlane_f64(tcol, r);
+            const double enter_val = ((c == XC) ? cNval : readlane_f64(nbval, c)) + delta;
             wave_sync();
             {
-                // a null exchange (A = 0): keeps every path through the loop body writing the tiles with
-                // an MFMA in place, so the accumulators are never copied at the loop edge
-                const double z0 = 0.0;
-                SB(0, 0) = MFMA(z0, z0, SB(0, 0)); SB(0, 1) = MFMA(z0, z0, SB(0, 1));
-                SB(1, 0) = MFMA(z0, z0, SB(1, 0)); SB(1, 1) = MFMA(z0, z0, SB(1, 1));
+                // extra column and values (lane l <-> row l)
+                const double ninv = -inv;
+                const double vx = (c == XC) ? ninv : vxr * inv;
+                double xbn = fma(delta, cm, xb);
+                double tcn = (c == XC) ? cm * inv : fma(-cm, vx, tcol);
+                if (l == r) { xbn = enter_val; tcn = (c == XC) ? inv : -vx; }
+                xb = xbn; tcol = tcn;
+                double pa = svrow[lc], pb = svrow[16 + lc];
+                asm volatile("" : "+v"(pa), "+v"(pb));
+                v0 = pa * inv; v1 = pb * inv;
+                if (lc == c) v0 = ninv;
+                if (16 + lc == c) v1 = ninv;
+                mcol = __ballot(lc == (c & 15)); mrow = __ballot(lq == rq);
+                cx = c;
             }
-            continue;
-        }
-        int r;
-        if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
-        else {
-            double ag = cand ? fabs(gdir) : -1.0;
-            if (cand && rowvar == VTH) ag = QINF;
-            const double bestg = wave_max_f64(ag);
-            r = wave_first(cand && ag == bestg);
-        }
-        r = uni(r);
-        STAMP(2);   // ratio test + row choice
-        // ---- pivot row r -> svrow (raw): the 16 lanes that hold it pick the register under a uniform tree
-        const int rq = r & 3, rsel = ((r >> 4) << 2) | ((r >> 2) & 3);      // leaf = Ib*4 + g
-        if (lq == rq) {
-#define M_XROW(Ib, g) { svrow[lc] = SB(Ib, 0)[g]; svrow[16 + lc] = SB(Ib, 1)[g]; }
-            if (rsel < 4) { if (rsel < 2) { if (rsel < 1) M_XROW(0, 0) else M_XROW(0, 1) } else { if (rsel < 3) M_XROW(0, 2) else M_XROW(0, 3) } }
-            else { if (rsel < 6) { if (rsel < 5) M_XROW(1, 0) else M_XROW(1, 1) } else { if (rsel < 7) M_XROW(1, 2) else M_XROW(1, 3) } }
-#undef M_XROW
-        }
-        double step = readlane_f64(dd, r);
-        if (step < 0.0) step = 0.0;
-        const double leave_val = readlane_f64(cndlo ? lo : hi, r);
-        const double rcr = readlane_f64(rc, r);
-        const double inv = sneg ? -rcr : rcr;
-        const double delta = sneg ? -step : step;
-        const int vl = readlane_i32(rowvar, r);
-        const double vxr = readlane_f64(tcol, r);
-        const double enter_val = ((c == XC) ? cNval : readlane_f64(nbval, c)) + delta;
-        wave_sync();
-        {
-            // extra column and values (lane l <-> row l)
-            const double ninv = -inv;
-            const double vx = (c == XC) ? ninv : vxr * inv;
-            double xbn = fma(delta, cm, xb);
-            double tcn = (c == XC) ? cm * inv : fma(-cm, vx, tcol);
-            if (l == r) { xbn = enter_val; tcn = (c == XC) ? inv : -vx; }
-            xb = xbn; tcol = tcn;
-            // the exchange on the four S tiles: one MFMA each (see the header of this stage)
-            const double coefA = lq == 2 ? inv : cA0, coefB = lq == 1 ? inv : cB0, kB = lq == 3 ? inv : 1.0;
-            double ua = sucol[lc], ub = sucol[16 + lc], pa = svrow[lc], pb = svrow[16 + lc];
-            asm volatile("" : "+v"(ua), "+v"(ub), "+v"(pa), "+v"(pb));     // four reads in flight, no branches
-            const double a0 = (lc == r) ? kA : ua * coefA;
-            const double a1 = (16 + lc == r) ? kA : ub * coefA;
-            const double b0 = (lc == c && lq != 0) ? kB : pa * coefB;
-            const double b1 = (16 + lc == c && lq != 0) ? kB : pb * coefB;
-            SB(0, 0) = MFMA(a0, b0, SB(0, 0));
-            SB(0, 1) = MFMA(a0, b1, SB(0, 1));
-            SB(1, 0) = MFMA(a1, b0, SB(1, 0));
-            SB(1, 1) = MFMA(a1, b1, SB(1, 1));
-        }
-        STAMP(3);   // pivot row through LDS + exchange issue
-        {
-            const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
-            if (l == r) { rowvar = ve; lo = elo; hi = ehi; }
-            if (c == XC) { cNvar = vl; cNval = leave_val; }
-            else if (l == c) { colvar = vl; nbval = leave_val; }
-        }
-        pivots++;
-        if (vl == VTH) { status = QPN_SUCCESS; break; }
-        int vn;
-        {
-            const int k = vl < NBP ? vl : vl - NBP;
-            const double Lk = readlane_f64(lo0, k), Uk = readlane_f64(hi0, k);
-            int au = readlane_i32(satv, k);
-            const bool isfreek = Lk == -QINF && Uk == QINF;
-            if (vl < NBP) {
-                // the bounded variable p_k left at a bound: its multiplier d_k enters from 0
-                if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); if (l == k) satv = au; }
-                vn = NBP + k;
-                sneg = au != 0;
-                self_lim = QINF;
-                if (Lk == Uk) { elo = -QINF; ehi = QINF; }
-                else if (isfreek) { elo = 0.0; ehi = 0.0; }
-                else if (au) { elo = -QINF; ehi = 0.0; }
-                else { elo = 0.0; ehi = QINF; }
-            } else {
-                // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
-                vn = k;
-                sneg = au != 0;
-                self_lim = Uk - Lk;
-                if (isfreek) { self_lim = QINF; sneg = false; }
-                elo = Lk; ehi = Uk;
+            STAMP(3);   // pivot row through LDS
+            {
+                const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
+                if (l == r) { rowvar = ve; lo = elo; hi = ehi; }
+                if (c == XC) { cNvar = vl; cNval = leave_val; }
+                else if (l == c) { colvar = vl; nbval = leave_val; }
             }
+            pivots++;
+            if (vl == VTH) { status = QPN_SUCCESS; break; }
+            int vn;
+            {
+                const int k = vl < NBP ? vl : vl - NBP;
+                const double Lk = readlane_f64(lo0, k), Uk = readlane_f64(hi0, k);
+                int au = readlane_i32(satv, k);
+                const bool isfreek = Lk == -QINF && Uk == QINF;
+                if (vl < NBP) {
+                    // the bounded variable p_k left at a bound: its multiplier d_k enters from 0
+                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); if (l == k) satv = au; }
+                    vn = NBP + k;
+                    sneg = au != 0;
+                    self_lim = QINF;
+                    if (Lk == Uk) { elo = -QINF; ehi = QINF; }
+                    else if (isfreek) { elo = 0.0; ehi = 0.0; }
+                    else if (au) { elo = -QINF; ehi = 0.0; }
+                    else { elo = 0.0; ehi = QINF; }
+                } else {
+                    // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                    vn = k;
+                    sneg = au != 0;
+                    self_lim = Uk - Lk;
+                    if (isfreek) { self_lim = QINF; sneg = false; }
+                    elo = Lk; ehi = Uk;
+                }
+            }
+            cnext = col_of(vn);
+            if (cnext < 0) { status = QPN_FAILURE; break; }
+            STAMP(4);
         }
-        c = col_of(vn);
-        if (c < 0) { status = QPN_FAILURE; break; }
+        // ---- the exchange on the 32 x 32 dictionary (see the header of this stage)
+        {
+            const d4 ua = *reinterpret_cast<const d4 *>(sucol + lq * 8);
+            const d4 ub = *reinterpret_cast<const d4 *>(sucol + lq * 8 + 4);
+            const double nv0 = -v0, nv1 = -v1;
+            cx = uni(cx); rsel = uni(rsel);
+            asm volatile(
+                "v_fma_f64 %[s000], -%[u0], %[v0], %[s000]\n\tv_fma_f64 %[s001], -%[u1], %[v0], %[s001]\n\t"
+                "v_fma_f64 %[s002], -%[u2], %[v0], %[s002]\n\tv_fma_f64 %[s003], -%[u3], %[v0], %[s003]\n\t"
+                "v_fma_f64 %[s010], -%[u0], %[v1], %[s010]\n\tv_fma_f64 %[s011], -%[u1], %[v1], %[s011]\n\t"
+                "v_fma_f64 %[s012], -%[u2], %[v1], %[s012]\n\tv_fma_f64 %[s013], -%[u3], %[v1], %[s013]\n\t"
+                "v_fma_f64 %[s100], -%[u4], %[v0], %[s100]\n\tv_fma_f64 %[s101], -%[u5], %[v0], %[s101]\n\t"
+                "v_fma_f64 %[s102], -%[u6], %[v0], %[s102]\n\tv_fma_f64 %[s103], -%[u7], %[v0], %[s103]\n\t"
+                "v_fma_f64 %[s110], -%[u4], %[v1], %[s110]\n\tv_fma_f64 %[s111], -%[u5], %[v1], %[s111]\n\t"
+                "v_fma_f64 %[s112], -%[u6], %[v1], %[s112]\n\tv_fma_f64 %[s113], -%[u7], %[v1], %[s113]\n\t"
+                // column c: T[i][c] = u_i * inv on the 4 lanes that own it (none when c is the extra column)
+                "s_cmp_gt_i32 %[c], 31\n\ts_cbranch_scc1 .Lqx_row%=\n\t"
+                "s_mov_b64 exec, %[mcol]\n\t"
+                "s_cmp_gt_i32 %[c], 15\n\ts_cbranch_scc1 .Lqx_col1%=\n\t"
+                "v_mul_f64 %[s000], %[u0], %[iv]\n\tv_mul_f64 %[s001], %[u1], %[iv]\n\t"
+                "v_mul_f64 %[s002], %[u2], %[iv]\n\tv_mul_f64 %[s003], %[u3], %[iv]\n\t"
+                "v_mul_f64 %[s100], %[u4], %[iv]\n\tv_mul_f64 %[s101], %[u5], %[iv]\n\t"
+                "v_mul_f64 %[s102], %[u6], %[iv]\n\tv_mul_f64 %[s103], %[u7], %[iv]\n\t"
+                "s_branch .Lqx_row%=\n"
+                ".Lqx_col1%=:\n\t"
+                "v_mul_f64 %[s010], %[u0], %[iv]\n\tv_mul_f64 %[s011], %[u1], %[iv]\n\t"
+                "v_mul_f64 %[s012], %[u2], %[iv]\n\tv_mul_f64 %[s013], %[u3], %[iv]\n\t"
+                "v_mul_f64 %[s110], %[u4], %[iv]\n\tv_mul_f64 %[s111], %[u5], %[iv]\n\t"
+                "v_mul_f64 %[s112], %[u6], %[iv]\n\tv_mul_f64 %[s113], %[u7], %[iv]\n"
+                // row r: T[r][j] = -v_j on the 16 lanes that own it (v carries -inv at column c)
+                ".Lqx_row%=:\n\t"
+                "s_mov_b64 exec, %[mrow]\n\t"
+                "s_cmp_gt_i32 %[rs], 3\n\ts_cbranch_scc1 .Lqx_r4%=\n\t"
+                "s_cmp_gt_i32 %[rs], 1\n\ts_cbranch_scc1 .Lqx_r2%=\n\t"
+                "s_cmp_eq_u32 %[rs], 0\n\ts_cbranch_scc0 .Lqx_r1%=\n\t"
+                "v_mov_b64 %[s000], %[n0]\n\tv_mov_b64 %[s010], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r1%=:\n\tv_mov_b64 %[s001], %[n0]\n\tv_mov_b64 %[s011], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r2%=:\n\ts_cmp_eq_u32 %[rs], 2\n\ts_cbranch_scc0 .Lqx_r3%=\n\t"
+                "v_mov_b64 %[s002], %[n0]\n\tv_mov_b64 %[s012], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r3%=:\n\tv_mov_b64 %[s003], %[n0]\n\tv_mov_b64 %[s013], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r4%=:\n\ts_cmp_gt_i32 %[rs], 5\n\ts_cbranch_scc1 .Lqx_r6%=\n\t"
+                "s_cmp_eq_u32 %[rs], 4\n\ts_cbranch_scc0 .Lqx_r5%=\n\t"
+                "v_mov_b64 %[s100], %[n0]\n\tv_mov_b64 %[s110], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r5%=:\n\tv_mov_b64 %[s101], %[n0]\n\tv_mov_b64 %[s111], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r6%=:\n\ts_cmp_eq_u32 %[rs], 6\n\ts_cbranch_scc0 .Lqx_r7%=\n\t"
+                "v_mov_b64 %[s102], %[n0]\n\tv_mov_b64 %[s112], %[n1]\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r7%=:\n\tv_mov_b64 %[s103], %[n0]\n\tv_mov_b64 %[s113], %[n1]\n"
+                ".Lqx_end%=:\n\t"
+                "s_mov_b64 exec, -1"
+                : [s000] "+v"(SD(0, 0, 0)), [s001] "+v"(SD(0, 0, 1)), [s002] "+v"(SD(0, 0, 2)), [s003] "+v"(SD(0, 0, 3)),
+                  [s010] "+v"(SD(0, 1, 0)), [s011] "+v"(SD(0, 1, 1)), [s012] "+v"(SD(0, 1, 2)), [s013] "+v"(SD(0, 1, 3)),
+                  [s100] "+v"(SD(1, 0, 0)), [s101] "+v"(SD(1, 0, 1)), [s102] "+v"(SD(1, 0, 2)), [s103] "+v"(SD(1, 0, 3)),
+                  [s110] "+v"(SD(1, 1, 0)), [s111] "+v"(SD(1, 1, 1)), [s112] "+v"(SD(1, 1, 2)), [s113] "+v"(SD(1, 1, 3))
+                : [u0] "v"(ua[0]), [u1] "v"(ua[1]), [u2] "v"(ua[2]), [u3] "v"(ua[3]), [u4] "v"(ub[0]), [u5] "v"(ub[1]),
+                  [u6] "v"(ub[2]), [u7] "v"(ub[3]), [v0] "v"(v0), [v1] "v"(v1), [n0] "v"(nv0), [n1] "v"(nv1), [iv] "v"(inv),
+                  [mcol] "s"(mcol), [mrow] "s"(mrow), [c] "s"(cx), [rs] "s"(rsel)
+                : "scc");
+        }
+        c = cnext;
         wave_sync();
-        STAMP(4);
+        STAMP(3);
     }
-
-    STAMP(4);   // Lemke: bookkeeping + flips
+    STAMP(4);   // Lemke: exit paths
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
     wave_sync();
     if (actb) { sval[rowvar] = xb; sval[colvar] = nbval; }
