@@ -691,6 +691,34 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         STAMP(3);
     }
     STAMP(4);   // Lemke: exit paths
+    // ---- everything below reads its kernel arguments AFRESH from the kernarg segment (through an opaque
+    // pointer), so that output pointers, tolerances and record bases are not kept in SGPRs -- and spilled to
+    // VGPR lanes -- across the pivot loops above
+    typedef const AviBatchArgs __attribute__((address_space(4))) *kargs_t;
+    kargs_t kp = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    AviBatchArgs ae{};
+    ae.z = kp->z; ae.status = kp->status; ae.resid = kp->resid; ae.pivots = kp->pivots; ae.active = kp->active;
+    ae.check_tol = kp->check_tol; ae.comp_tol = kp->comp_tol;
+#ifdef QPN_STAMPS
+    ae.stamps = kp->stamps;
+#endif
+    if constexpr (NODES) { ae.nd.Qd = kp->nd.Qd; ae.nd.l = kp->nd.l; ae.nd.u = kp->nd.u; }
+    else { ae.M = kp->M; ae.strideM = kp->strideM; ae.q = kp->q; ae.l = kp->l; ae.u = kp->u; ae.kind = kp->kind; ae.stride_kind = kp->stride_kind; }
+    const double *Qe_ = NODES ? ae.nd.Qd + (size_t)b * nn * nn : nullptr;
+    const double *Mge = NODES ? nullptr : ae.M + (size_t)b * (size_t)ae.strideM;
+    auto row_bounds_e = [&](double &lk_, double &uk_, int &gk_) {
+        lk_ = 0.0; uk_ = 0.0; gk_ = 0;
+        if constexpr (NODES) {
+            if (act) {
+                if (l < nn) { lk_ = -QINF; uk_ = QINF; }
+                else { lk_ = ae.nd.l[(size_t)b * nm + (l - nn)]; uk_ = ae.nd.u[(size_t)b * nm + (l - nn)]; gk_ = 1; }
+            }
+        } else {
+            lk_ = act ? ae.l[vo + l] : 0.0; uk_ = act ? ae.u[vo + l] : 0.0;
+            gk_ = (act && ae.kind) ? (int)ae.kind[(size_t)b * (size_t)ae.stride_kind + l] : 0;
+        }
+    };
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
     wave_sync();
     if (actb) { sval[rowvar] = xb; sval[colvar] = nbval; }
@@ -719,7 +747,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
     double lk, uk; int gk;
-    row_bounds(lk, uk, gk);
+    row_bounds_e(lk, uk, gk);
     double rk;
     if constexpr (NODES) {
         // r = q + M z, item columns in ascending order; a zero z_j contributes exactly nothing (finite
@@ -728,7 +756,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         rk = sq[l];
         const bool isx = l < nn;
         const int ls = act ? (isx ? l : l - nn) : 0;
-        const double *qcol = Q_ + (isx ? ls : 0);
+        const double *qcol = Qe_ + (isx ? ls : 0);
         const int aoff = isx ? 0 : ls, roff = (isx ? ls : 0) * SAS;   // column of Ad (constraint rows) / row of Ad' (x rows)
         int j = 0;
         for (; j + 8 <= nn; j += 8) {
@@ -757,23 +785,23 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             rk = (zj != 0.0 && isx) ? fma(mv, zj, rk) : rk;
         }
     } else {
-        rk = act ? qelem(l) : 0.0;
+        rk = act ? ae.q[vo + l] : 0.0;
         int j = 0;
         for (; j + 8 <= N; j += 8) {
             double mv[8];
 #pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = act ? Mg[(size_t)(j + q8) * N + l] : 0.0;
+            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = act ? Mge[(size_t)(j + q8) * N + l] : 0.0;
 #pragma unroll
             for (int q8 = 0; q8 < 8; ++q8) { const double zj = sz[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
         }
-        for (; j < N; ++j) { const double zj = sz[j]; if (zj != 0.0 && act) rk = fma(Mg[(size_t)j * N + l], zj, rk); }
+        for (; j < N; ++j) { const double zj = sz[j]; if (zj != 0.0 && act) rk = fma(Mge[(size_t)j * N + l], zj, rk); }
     }
     const double pp = gk ? rk : zk, dv = gk ? zk : rk;
     int bad = 0;
     double nres = 0.0;
     unsigned mask = 0;
     if (act) {
-        const double tol = a.check_tol;
+        const double tol = ae.check_tol;
         if (dv > tol && fabs(pp - lk) > tol) bad++;
         if (dv < -tol && fabs(pp - uk) > tol) bad++;
         if (pp - lk < -tol) bad++;
@@ -784,7 +812,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         if (tt > uk) tt = uk;
         nres = fabs(pp - tt);
         if (isnan(nres)) nres = QINF;
-        const double ct = a.comp_tol;
+        const double ct = ae.comp_tol;
         auto approx = [&](double x, double y) { return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= ct); };
         if (!approx(lk, uk)) {
             if (approx(pp, lk) && dv >= -ct) mask |= 1u;
@@ -797,18 +825,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     nres = wave_max_f64(nres);
     if (bad > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
     if (act) {
-        a.z[vo + l] = zk;
-        if (a.active) a.active[vo + l] = (uint8_t)mask;
+        ae.z[vo + l] = zk;
+        if (ae.active) ae.active[vo + l] = (uint8_t)mask;
     }
     if (l == 0) {
-        a.status[b] = status;
-        if (a.resid) a.resid[b] = nres;
-        if (a.pivots) a.pivots[b] = pivots;
+        ae.status[b] = status;
+        if (ae.resid) ae.resid[b] = nres;
+        if (ae.pivots) ae.pivots[b] = pivots;
     }
     STAMP(5);   // read-back + post-check + stores
 #ifdef QPN_STAMPS
-    if (a.stamps && l == 0)
-        for (int i = 0; i < 8; ++i) a.stamps[(size_t)b * 8 + i] = stamp_acc[i];
+    if (ae.stamps && l == 0)
+        for (int i = 0; i < 8; ++i) ae.stamps[(size_t)b * 8 + i] = stamp_acc[i];
 #endif
 }
 
