@@ -178,50 +178,53 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     double mabs = 0.0;
     if constexpr (NODES) {
         // Qd and Ad with fully coalesced loads (two columns of 32 rows per instruction = 512 contiguous
-        // bytes when n = m = 32), all 32 + the q loads in flight at once
+        // bytes when n = m = 32), all 32 + the q loads in flight at once.  FULL (n = m = 32, the hot shape)
+        // drops every bounds predicate, clamp and padding select.
         const int r5 = l & 31, ch = l >> 5;
-        double vq[16], va[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int cj = 2 * t + ch;
-            const bool okq = cj < nn && r5 < nn, oka = cj < nn && r5 < nm;
-            vq[t] = Q_[okq ? (size_t)cj * nn + r5 : 0];
-            va[t] = A_[oka ? (size_t)cj * nm + r5 : 0];
-        }
-        sq[l] = act ? qelem(l) : 0.0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int cj = 2 * t + ch;
-            const double q_ = (cj < nn && r5 < nn) ? vq[t] : 0.0;
-            sA[cj * SQS + r5] = q_;
-            mabs = fmax(mabs, fabs(q_));
-        }
-        wave_sync();
-#define M_LOADH(I, J)                                                                               \
+#define M_LOADH(I, J, FULL)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq, cc = 16 * (J) + lc;                                   \
         double v = sA[cc * SQS + rr];                                                               \
-        if (rr == cc && rr >= n) v = 1.0;                           /* padded x rows: identity */     \
+        if (!(FULL) && rr == cc && rr >= n) v = 1.0;                /* padded x rows: identity */     \
         TL(I, J)[g] = v;                                                                            \
     }
-        M_LOADH(0, 0) M_LOADH(0, 1) M_LOADH(1, 0) M_LOADH(1, 1)
-#undef M_LOADH
-        wave_sync();
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int cj = 2 * t + ch;
-            const double a_ = (cj < nn && r5 < nm) ? va[t] : 0.0;
-            sA[cj * SAS + r5] = a_;
-            mabs = fmax(mabs, fabs(a_));
-        }
-        wave_sync();
-#define M_LOADC(I, J)                                                                               \
+#define M_LOADC(I, J, FULL)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq, ck = 16 * ((J) - 2) + lc;                             \
         const double t_ = sA[rr * SAS + ck];                        /* C = -Ad' */                   \
-        TL(I, J)[g] = (rr < n && ck < m) ? -t_ : 0.0;                                               \
+        TL(I, J)[g] = ((FULL) || (rr < n && ck < m)) ? -t_ : 0.0;                                   \
     }
-        M_LOADC(0, 2) M_LOADC(0, 3) M_LOADC(1, 2) M_LOADC(1, 3)
+#define M_NODE_LOAD(FULL)                                                                           \
+    {                                                                                               \
+        double vq[16], va[16];                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
+            const int cj = 2 * t + ch;                                                              \
+            const bool okq = (FULL) || (cj < nn && r5 < nn), oka = (FULL) || (cj < nn && r5 < nm);  \
+            vq[t] = Q_[okq ? (size_t)cj * ((FULL) ? 32 : nn) + r5 : 0];                             \
+            va[t] = A_[oka ? (size_t)cj * ((FULL) ? 32 : nm) + r5 : 0];                             \
+        }                                                                                           \
+        sq[l] = act ? qelem(l) : 0.0;                                                               \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
+            const int cj = 2 * t + ch;                                                              \
+            const double q_ = ((FULL) || (cj < nn && r5 < nn)) ? vq[t] : 0.0;                       \
+            sA[cj * SQS + r5] = q_;                                                                 \
+            mabs = fmax(mabs, fabs(q_));                                                            \
+        }                                                                                           \
+        wave_sync();                                                                                \
+        M_LOADH(0, 0, FULL) M_LOADH(0, 1, FULL) M_LOADH(1, 0, FULL) M_LOADH(1, 1, FULL)             \
+        wave_sync();                                                                                \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
+            const int cj = 2 * t + ch;                                                              \
+            const double a_ = ((FULL) || (cj < nn && r5 < nm)) ? va[t] : 0.0;                       \
+            sA[cj * SAS + r5] = a_;                                                                 \
+            mabs = fmax(mabs, fabs(a_));                                                            \
+        }                                                                                           \
+        wave_sync();                                                                                \
+        M_LOADC(0, 2, FULL) M_LOADC(0, 3, FULL) M_LOADC(1, 2, FULL) M_LOADC(1, 3, FULL)             \
+    }
+        if (nn == 32 && nm == 32) M_NODE_LOAD(true) else M_NODE_LOAD(false)
+#undef M_NODE_LOAD
+#undef M_LOADH
 #undef M_LOADC
     } else {
         // internal index (0..63) -> item index or -1 (padding): x block 0..31, lambda block 32..63
@@ -750,14 +753,16 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     row_bounds_e(lk, uk, gk);
     double rk;
     if constexpr (NODES) {
-        // r = q + M z, item columns in ascending order; a zero z_j contributes exactly nothing (finite
-        // blocks).  x rows read Qd column-wise from global memory (lane <-> row: coalesced, L2 / Infinity
-        // Cache hits) and their -Ad' part from LDS; constraint rows read Ad from LDS.
-        rk = sq[l];
+        // r = q + M z, item columns in ascending order (finite blocks: a zero z_j contributes exactly
+        // nothing).  x rows read Qd column-wise from global memory (lane <-> row: coalesced, L2 / Infinity
+        // Cache hits) and their -Ad' part from LDS; constraint rows read Ad from LDS.  Every lane runs BOTH
+        // fma chains (one is garbage, on in-range addresses) and keeps its own at the end: two v_fma_f64
+        // per column instead of a compare and four selects.
         const bool isx = l < nn;
         const int ls = act ? (isx ? l : l - nn) : 0;
         const double *qcol = Qe_ + (isx ? ls : 0);
         const int aoff = isx ? 0 : ls, roff = (isx ? ls : 0) * SAS;   // column of Ad (constraint rows) / row of Ad' (x rows)
+        double rq = sq[l], ra = rq;
         int j = 0;
         for (; j + 8 <= nn; j += 8) {
             double mq[8];
@@ -765,25 +770,19 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             for (int q8 = 0; q8 < 8; ++q8) mq[q8] = qcol[(size_t)(j + q8) * nn];
 #pragma unroll
             for (int q8 = 0; q8 < 8; ++q8) {
-                double ma = sA[(j + q8) * SAS + aoff];
-                asm volatile("" : "+v"(ma));        // keep the LDS read a read (no select of pointers)
                 const double zj = sz[j + q8];
-                const double mv = isx ? mq[q8] : ma;
-                rk = (zj != 0.0) ? fma(mv, zj, rk) : rk;
+                rq = fma(mq[q8], zj, rq);
+                ra = fma(sA[(j + q8) * SAS + aoff], zj, ra);
             }
         }
         for (; j < nn; ++j) {
-            double ma = sA[j * SAS + aoff];
-            asm volatile("" : "+v"(ma));
-            const double zj = sz[j], mq1 = qcol[(size_t)j * nn];
-            const double mv = isx ? mq1 : ma;
-            rk = (zj != 0.0) ? fma(mv, zj, rk) : rk;
+            const double zj = sz[j];
+            rq = fma(qcol[(size_t)j * nn], zj, rq);
+            ra = fma(sA[j * SAS + aoff], zj, ra);
         }
 #pragma unroll 8
-        for (int k = 0; k < nm; ++k) {                         // columns of lambda: -A' (x rows only)
-            const double mv = -sA[roff + k], zj = sz[nn + k];
-            rk = (zj != 0.0 && isx) ? fma(mv, zj, rk) : rk;
-        }
+        for (int k = 0; k < nm; ++k) rq = fma(-sA[roff + k], sz[nn + k], rq);      // columns of lambda: -A' (x rows)
+        rk = isx ? rq : ra;
     } else {
         rk = act ? ae.q[vo + l] : 0.0;
         int j = 0;
