@@ -14,7 +14,7 @@
 //   * the bottom half is never eliminated: with W = H^-1 C and h = H^-1 g in hand,
 //         S = D - A W   (32 MFMAs, A operands straight from the staged A block)   and   c = b - A h.
 //     This is 25 % fewer flops than eliminating all four quadrants and -- the point -- needs 8 live tiles
-//     instead of 16, so THREE waves fit a SIMD (<= 168 VGPRs) instead of two.  The solve is a chain of
+//     instead of 16, so FOUR waves fit a SIMD (<= 128 VGPRs, 10 KB LDS each) instead of two.  The solve is a chain of
 //     dependent LDS / cross-lane / MFMA latencies, and resident waves are what hides them.
 // Stage B (Lemke) then runs on the 32 x 33 dictionary of S in the same tile layout, one MFMA per tile per
 // pivot, and x = -(W lambda + h) is recovered at the end.  Post-check, residual and active-set masks
@@ -84,7 +84,7 @@ __device__ __forceinline__ double rcp64(double x)
 }
 
 template <bool NODES>
-__global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
+__global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
     const int N = NODES ? a.nd.n + a.nd.m : a.N;
     const int l = threadIdx.x;
@@ -93,17 +93,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
 
     // Stage A scratch (sU: pivot columns, [row][k]) and Stage B / read-back scratch never live at the
     // same time: one buffer.
-    __shared__ __attribute__((aligned(32))) double sbuf[224];
+    __shared__ __attribute__((aligned(32))) double sbuf[192];
     double *const sU = sbuf;                    // Stage A: pivot columns of the top half, [32][4]
     double *const sucol = sbuf;                 // Stage B: entering column + extra          [40]
     double *const svrow = sbuf + 40;            // Stage B: pivot row                         [40]
-    double *const sval = sbuf + 80;             // values by variable id                      [66]
-    double *const sz = sbuf + 160;              // h, then the solution in item order         [64]
-    __shared__ double sq[64];                   // q in item order (fused path; g and b of the header)
-    // fused node path: one block buffer -- Qd (column stride SQS) while the H tiles are built, then Ad
-    // (column stride SAS) for the rest of the solve
-    constexpr int SQS = 34, SAS = 33;
+    double *const sval = sbuf;                  // read-back: values by variable id           [66]
+    double *const sz = sbuf + 128;              // h, then the solution in item order         [64]
+    // fused node path: one block buffer -- Qd while the H tiles are built, then Ad for the rest of the
+    // solve, both with column stride 34 (conflict-free tile reads); the two spare slots per column hold
+    // q in item order (g and b of the header).  1536 + 8704 = 10240 B: 16 waves per CU.
+    constexpr int SQS = 34, SAS = 34;
     __shared__ double sA[NODES ? 32 * SQS : 1];
+#define SQ(i) sA[((i) >> 1) * SQS + 32 + ((i) & 1)]
 
     const double *Mg = NODES ? nullptr : a.M + (size_t)b * (size_t)a.strideM;
     const size_t vo = (size_t)b * (size_t)N;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
             vq[t] = Q_[okq ? (size_t)cj * ((FULL) ? 32 : nn) + r5 : 0];                             \
             va[t] = A_[oka ? (size_t)cj * ((FULL) ? 32 : nm) + r5 : 0];                             \
         }                                                                                           \
-        sq[l] = act ? qelem(l) : 0.0;                                                               \
+        SQ(l) = act ? qelem(l) : 0.0;                                                               \
         _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
             const int cj = 2 * t + ch;                                                              \
             const double q_ = ((FULL) || (cj < nn && r5 < nn)) ? vq[t] : 0.0;                       \
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
     }
     // extra column: g = q of the x rows, lane l <-> row l of the top half (lanes >= 32 idle)
     double kx;
-    if constexpr (NODES) kx = (l < n) ? sq[l] : 0.0; else kx = (l < n) ? qelem(l) : 0.0;
+    if constexpr (NODES) kx = (l < n) ? SQ(l) : 0.0; else kx = (l < n) ? qelem(l) : 0.0;
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
 
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         const bool lowr = l < m;
         const int ls = lowr ? l : 0;
         double acc;
-        if constexpr (NODES) acc = lowr ? sq[n + ls] : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
+        if constexpr (NODES) acc = lowr ? SQ(n + ls) : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
         if constexpr (NODES) {
 #pragma unroll 8
             for (int j = 0; j < 32; ++j) acc = fma(-sA[j * SAS + ls], sz[j], acc);      // zero columns beyond n
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 3 : 2) void avi_solve_schur(AviBatchA
         const int ls = act ? (isx ? l : l - nn) : 0;
         const double *qcol = Qe_ + (isx ? ls : 0);
         const int aoff = isx ? 0 : ls, roff = (isx ? ls : 0) * SAS;   // column of Ad (constraint rows) / row of Ad' (x rows)
-        double rq = sq[l], ra = rq;
+        double rq = SQ(l), ra = rq;
         int j = 0;
         for (; j + 8 <= nn; j += 8) {
             double mq[8];
