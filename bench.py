@@ -87,16 +87,20 @@ def main():
             bufs["asm"] = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["asm"])
             Mc, q, lo, hi, kind = bufs["asm"]
             res = bufs["sol"] = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind, out=bufs["sol"])   # cold start
+            if record:
+                e1.record(); ev_pairs.append((e0, e1))
+            xloc = res["z"][:, :n].contiguous()
+            if not use_dist:
+                x_all[lo_id:hi_id].copy_(xloc)
         else:
-            # (A5+A6+A2+A3+A9) one fused pass: KKT blocks assembled on the fly inside the solve kernel
-            res = bufs["sol"] = eng.solve_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["sol"])
-        if record:
-            e1.record(); ev_pairs.append((e0, e1))
-        xloc = res["z"][:, :n].contiguous()
+            # (A5+A6+A2+A3+A9) one fused pass: KKT blocks assembled on the fly inside the solve kernel,
+            # primal blocks written straight into this rank's rows of the iterate x
+            xloc = x_all[lo_id:hi_id]
+            res = bufs["sol"] = eng.solve_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["sol"], x_out=xloc)
+            if record:
+                e1.record(); ev_pairs.append((e0, e1))
         if use_dist:
             sharding.all_gather_primal(x_all, xloc, counts, dist)
-        else:
-            x_all[lo_id:hi_id].copy_(xloc)
         return res
 
     def barrier():

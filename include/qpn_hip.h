@@ -138,6 +138,17 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
                     int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
                     const qpn_avi_opts *opts, int mem);
 
+/* Same, and additionally scatters every node's primal block x_d = z[0..n) into the caller's iterate:
+ *   x[b * stride_x + i] = z[b][i], i < n   (stride_x >= n, in doubles; x in the same memory space as z).
+ * This is the write-back the outer sweep does after each solve (src/algorithm.jl:97-101,
+ * x[decision_inds] = x_opt[decision_inds]); doing it from the solve kernel spares two copy kernels per
+ * sweep.  x == NULL behaves exactly like qpn_solve_nodes. */
+int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                         const double *R, const double *qd, const double *Ad, const double *B,
+                         const double *l, const double *u, const double *w, int64_t stride_w, double *z,
+                         int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
+                         const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x);
+
 /* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
  *   xd [batch][n] current decision values, w as above.
  *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower

@@ -19,6 +19,7 @@ const LIB = get(ENV, "QPN_HIP_LIB", joinpath(@__DIR__, "..", "quadraticprogramne
 const QPN_MEM_HOST = Cint(0)
 const QPN_SUCCESS = Int32(1)
 
+const QPN_AVI_FLAG_COLD_START = Int32(1)   # include/qpn_hip.h
 struct AviOpts                # qpn_avi_opts, include/qpn_hip.h
     check_tol::Cdouble
     piv_tol::Cdouble
@@ -89,6 +90,35 @@ function solve_avi_batch(M::Array{Float64}, q::Matrix{Float64}, l::Matrix{Float6
                     Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{UInt8}, Ref{AviOpts}, Cint),
                    ctx(), Int32(batch), Int32(N), M, strideM, q, l, u, kp, sk, z, status, resid, pivots, active, o, QPN_MEM_HOST)
         rc == 0 || error("qpn_solve_avi_batch failed ($rc)")
+    end
+    (z, status, resid, pivots, active)
+end
+
+"""
+    solve_nodes!(x, Qd, R, qd, Ad, B, l, u, w) -> (z, status, resid, pivots, active)
+
+One sweep over `batch` single-node pools: `Qd` n×n×batch, `R` n×p×batch, `qd` n×batch, `Ad` m×n×batch,
+`B` m×p×batch, `l,u` m×batch, `w` p (shared) or p×batch.  Each node's reduced KKT system is assembled
+on the fly and solved (`qpn_solve_nodes_into`); `z` is (n+m)×batch = [x_d; λ] and the primal blocks are
+also written into the columns of `x` (n×batch view of the iterate: the write-back of
+src/algorithm.jl:97-101).
+"""
+function solve_nodes!(x::Union{Nothing,StridedMatrix{Float64}}, Qd::Array{Float64,3}, R::Array{Float64,3}, qd::Matrix{Float64},
+                      Ad::Array{Float64,3}, B::Array{Float64,3}, l::Matrix{Float64}, u::Matrix{Float64}, w::VecOrMat{Float64})
+    n, batch = size(qd); m = size(l, 1); p = size(w, 1)
+    N = n + m
+    z = zeros(N, batch); status = zeros(Int32, batch); resid = zeros(batch); pivots = zeros(Int32, batch); active = zeros(UInt8, N, batch)
+    o = default_opts(); o = AviOpts(o.check_tol, o.piv_tol, o.feas_tol, o.comp_tol, o.max_pivots, o.flags | QPN_AVI_FLAG_COLD_START)
+    xp = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    sx = x === nothing ? Int64(0) : Int64(stride(x, 2))
+    GC.@preserve x begin
+        rc = ccall((:qpn_solve_nodes_into, LIB), Cint,
+                   (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                    Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{UInt8},
+                    Ref{AviOpts}, Cint, Ptr{Cdouble}, Int64),
+                   ctx(), Int32(batch), Int32(n), Int32(m), Int32(p), Qd, R, qd, Ad, B, l, u, w, ndims(w) == 1 ? Int64(0) : Int64(p),
+                   z, status, resid, pivots, active, Ref(o), QPN_MEM_HOST, xp, sx)
+        rc == 0 || error("qpn_solve_nodes_into failed ($rc)")
     end
     (z, status, resid, pivots, active)
 end

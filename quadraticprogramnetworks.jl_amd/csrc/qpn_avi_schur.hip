@@ -703,7 +703,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     asm volatile("" : "+s"(kp));
     AviBatchArgs ae{};
     ae.z = kp->z; ae.status = kp->status; ae.resid = kp->resid; ae.pivots = kp->pivots; ae.active = kp->active;
-    ae.check_tol = kp->check_tol; ae.comp_tol = kp->comp_tol;
+    ae.check_tol = kp->check_tol; ae.comp_tol = kp->comp_tol; ae.x = kp->x; ae.stride_x = kp->stride_x;
 #ifdef QPN_STAMPS
     ae.stamps = kp->stamps;
 #endif
@@ -826,6 +826,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     if (bad > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
     if (act) {
         ae.z[vo + l] = zk;
+        if (ae.x && l < n) ae.x[(size_t)b * (size_t)ae.stride_x + l] = zk;      // primal block -> the caller's iterate
         if (ae.active) ae.active[vo + l] = (uint8_t)mask;
     }
     if (l == 0) {

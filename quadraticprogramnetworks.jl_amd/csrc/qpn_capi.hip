@@ -411,7 +411,18 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
                     int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
                     const qpn_avi_opts *opts, int mem)
 {
+    return qpn_solve_nodes_into(ctx, batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, z, status, resid,
+                                pivots, active, opts, mem, nullptr, 0);
+}
+
+int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                         const double *R, const double *qd, const double *Ad, const double *B,
+                         const double *l, const double *u, const double *w, int64_t stride_w, double *z,
+                         int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
+                         const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x)
+{
     if (!ctx) return QPN_ERR_ARG;
+    if (x && stride_x < n) return fail_arg(ctx, "qpn_solve_nodes_into: stride_x < n");
     if (batch < 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_solve_nodes: bad sizes");
     if (batch == 0) return QPN_OK;
     if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || !w || (m > 0 && !B))) || !z || !status)
@@ -470,6 +481,8 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
     a.stamps = g_stamps;
 #endif
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
+    const bool x_dev = x && mem == QPN_MEM_DEVICE;
+    if (x_dev && mfma_shape) { a.x = x; a.stride_x = stride_x; }      // written by the solve kernels themselves
     if (mfma_shape) {
         // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
         // (one small scan-mode launch: its waves pick the flagged items, assemble their blocks into the
@@ -487,6 +500,9 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
         if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
         else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
     }
+    if (x_dev && !mfma_shape)       // general sizes: strided device copy of the primal blocks
+        HIPCHK(ctx, hipMemcpy2DAsync(x, (size_t)stride_x * 8, dz, (size_t)N * 8, (size_t)n * 8, (size_t)batch,
+                                     hipMemcpyDeviceToDevice, s));
     if (mem == QPN_MEM_HOST) {
         HIPCHK(ctx, hipMemcpyAsync(z, dz, bN * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipMemcpyAsync(status, dst, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
@@ -494,6 +510,9 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
         if (pivots) HIPCHK(ctx, hipMemcpyAsync(pivots, dpv, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
         if (active) HIPCHK(ctx, hipMemcpyAsync(active, dact, bN, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
+        if (x)
+            for (int32_t b = 0; b < batch; ++b)
+                for (int32_t i = 0; i < n; ++i) x[(size_t)b * (size_t)stride_x + i] = z[(size_t)b * N + i];
     }
     return QPN_OK;
 }

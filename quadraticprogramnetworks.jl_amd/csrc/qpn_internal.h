@@ -43,6 +43,9 @@ struct AviBatchArgs {
     // diagnostic builds only (-DQPN_STAMPS): per-item cycle sums per phase, [batch][8] uint64
     unsigned long long *stamps;
     NodeSrc nd;      // used by the fused node path only
+    // optional scatter of the primal block z[b][0..nd.n) into x[b * stride_x + i] (qpn_solve_nodes_into)
+    double *x;
+    int64_t stride_x;
 };
 
 // qpn_avi_solve.hip

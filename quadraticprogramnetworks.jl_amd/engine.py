@@ -231,9 +231,13 @@ class Engine:
         return Mout, qout, lout, uout, kind
 
     # -- (A5+A6+A2+A3+A9 fused) --------------------------------------------------------------
-    def solve_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w, z0=None, opts=None, want_active=True, out=None):
+    def solve_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w, z0=None, opts=None, want_active=True, out=None,
+                    x_out=None):
         """Assemble every node's KKT blocks on the fly and solve (one kernel for n, m <= 32); same
-        results as assemble_nodes + solve_avi_batch without materialising M.  z = [x_d; lambda]."""
+        results as assemble_nodes + solve_avi_batch without materialising M.  z = [x_d; lambda].
+        x_out (optional, [batch, >= n] fp64, rows may be strided): the primal blocks are also written
+        there by the solve itself -- the outer sweep's x[decision_inds] = x_opt[decision_inds]
+        (src/algorithm.jl:97-101)."""
         dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, w, z0)
         self._bind_stream(dev)
         if not dev:
@@ -263,11 +267,23 @@ class Engine:
             z.copy_(z0)
         else:
             z[...] = np.asarray(z0, dtype=np.float64)
-        rc = self.lib.qpn_solve_nodes(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac),
-                                      _ptr(Bc), _ptr(l), _ptr(u), _ptr(w), sw, _ptr(z), _ptr(status),
-                                      _ptr(resid), _ptr(pivots), _ptr(active), C.byref(o),
-                                      MEM_DEVICE if dev else MEM_HOST)
-        self._chk(rc, "qpn_solve_nodes")
+        sx = 0
+        if x_out is not None:
+            if dev:
+                if x_out.dtype != z.dtype or x_out.dim() != 2 or x_out.shape[0] != batch or x_out.shape[1] < n \
+                        or x_out.stride(1) != 1:
+                    raise ValueError("x_out must be a [batch, >= n] fp64 tensor with unit inner stride")
+                sx = x_out.stride(0)
+            else:
+                if x_out.dtype != np.float64 or x_out.ndim != 2 or x_out.shape[0] != batch or x_out.shape[1] < n \
+                        or x_out.strides[1] != 8:
+                    raise ValueError("x_out must be a [batch, >= n] float64 array with unit inner stride")
+                sx = x_out.strides[0] // 8
+        rc = self.lib.qpn_solve_nodes_into(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac),
+                                           _ptr(Bc), _ptr(l), _ptr(u), _ptr(w), sw, _ptr(z), _ptr(status),
+                                           _ptr(resid), _ptr(pivots), _ptr(active), C.byref(o),
+                                           MEM_DEVICE if dev else MEM_HOST, _ptr(x_out), sx)
+        self._chk(rc, "qpn_solve_nodes_into")
         return dict(z=z, status=status, resid=resid, pivots=pivots, active=active)
 
     # -- (A8) ------------------------------------------------------------------------------

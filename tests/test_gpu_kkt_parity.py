@@ -173,3 +173,41 @@ def test_solve_nodes_fused_equals_assemble_then_solve(engine, oracle):
     rh = engine.solve_nodes(colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, np.zeros(1))
     assert np.array_equal(rh["status"], rc["status"]) and np.all(rc["status"] == 1)
     assert np.array_equal(rh["active"], rc["active"]) and np.max(np.abs(rh["z"] - rc["z"])) <= 1e-9
+
+
+def test_solve_nodes_into_scatters_primal_blocks(engine, oracle):
+    """qpn_solve_nodes_into: the primal block of every node lands in the caller's iterate (row-strided),
+    for the matrix-core shape, the declined-item fallback, general sizes and host buffers; the rest of
+    the iterate is left untouched (src/algorithm.jl:97-101 write-back)."""
+    import torch
+    from qpn_amd.engine import colmajor
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    for n, m, p, cnt in [(32, 32, 8, 200), (7, 19, 3, 40), (40, 50, 4, 3)]:
+        Q, R, qd, A, B, l, u = P.synth_nodes(4100 + n, cnt, n, m, p)
+        w = P.shared_params(p)
+        args = (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+        ref = engine.solve_nodes(*args)
+        # device, rows strided (x lives inside a wider iterate)
+        xbig = torch.full((cnt, n + 5), -7.0, dtype=torch.float64, device="cuda:0")
+        rd = engine.solve_nodes(*[t(x) for x in args], x_out=xbig[:, 2:2 + n + 1])
+        torch.cuda.synchronize()
+        xb = xbig.cpu().numpy()
+        assert np.array_equal(rd["z"].cpu().numpy(), ref["z"])
+        assert np.array_equal(xb[:, 2:2 + n], ref["z"][:, :n])
+        assert np.all(xb[:, :2] == -7.0) and np.all(xb[:, 2 + n:] == -7.0)
+        # host buffers
+        xh = np.full((cnt, n), np.nan)
+        rh = engine.solve_nodes(*args, x_out=xh)
+        assert np.array_equal(xh, rh["z"][:, :n])
+    # declined items (Q = 0) go through the scan-mode fallback, which writes x too
+    n, m, cnt = 6, 14, 10
+    rng = np.random.default_rng(3)
+    Q = np.zeros((cnt, n, n)); R = np.zeros((cnt, n, 1)); B = np.zeros((cnt, m, 1)); qd = rng.standard_normal((cnt, n))
+    A = np.stack([np.vstack([np.eye(n), rng.standard_normal((m - n, n))]) for _ in range(cnt)])
+    l = np.tile(np.concatenate([-2 * np.ones(n), -1.5 * np.ones(m - n)]), (cnt, 1)); u = -l
+    args = (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, np.zeros(1))
+    x = torch.zeros((cnt, n), dtype=torch.float64, device="cuda:0")
+    rd = engine.solve_nodes(*[t(a) for a in args], x_out=x)
+    torch.cuda.synchronize()
+    assert np.all(rd["status"].cpu().numpy() == 1)
+    assert np.array_equal(x.cpu().numpy(), rd["z"].cpu().numpy()[:, :n])
