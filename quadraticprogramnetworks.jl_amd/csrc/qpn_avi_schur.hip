@@ -99,6 +99,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     double *const svrow = sbuf + 40;            // Stage B: pivot row                         [40]
     double *const sval = sbuf;                  // read-back: values by variable id           [66]
     double *const sz = sbuf + 128;              // h, then the solution in item order         [64]
+    double *const sPi = sbuf + 128;             // Stage A: P^-1, [i][k]                      [16]
     // fused node path: one block buffer -- Qd while the H tiles are built, then Ad for the rest of the
     // solve, both with column stride 34 (conflict-free tile reads); the two spare slots per column hold
     // q in item order (g and b of the header).  1536 + 8704 = 10240 B: 16 waves per CU.
@@ -267,67 +268,76 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
 
     STAMP(0);   // setup + load
     // ---- Stage A: 8 rank-4 block pivots of the top half on the matrix cores ------------------------------
-    // Pivot rows carry P - I in sU so that the update T -= U (P^-1 V) turns them into P^-1 V themselves.
+    // Pivot rows carry P - I in sU so that the update T -= (U P^-1) V turns them into P^-1 V themselves:
+    // no separate V' = P^-1 V product (an MFMA that would use 4 of its 16 output rows) is needed.
     bool fail = false;
-#define M_GATHER(I, JP)                                                                             \
+#define M_GATHER(I, JP, GP)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq;                                                       \
         double v = TL(I, JP)[g];                                                                    \
-        if (rr == p0 + kcol) v -= 1.0;                                                              \
+        /* row p0 + kcol sits in tile JP, register GP, lane group lq == kcol: a static test */      \
+        if ((I) == (JP) && g == (GP) && lq == kcol) v -= 1.0;                                       \
         sU[rr * 4 + kcol] = v;                                                                      \
     }
 #define M_COLTILE(J, IP, GP)                                                                        \
     {                                                                                               \
-        const double vraw = TL(IP, J)[GP];                                                          \
-        d4 z4 = {0.0, 0.0, 0.0, 0.0};                                                               \
-        const d4 vn4 = MFMA(ap, vraw, z4);                                                          \
-        const double vn = vn4[0];                                                                   \
-        TL(0, J) = MFMA(au0, vn, TL(0, J));                                                         \
-        TL(1, J) = MFMA(au1, vn, TL(1, J));                                                         \
+        const double vraw = TL(IP, J)[GP];              /* the 4 pivot rows of this column tile: a B operand */ \
+        TL(0, J) = MFMA(au0, vraw, TL(0, J));                                                       \
+        TL(1, J) = MFMA(au1, vraw, TL(1, J));                                                       \
     }
 #define M_STEP(KB, JP, GP)                                                                          \
     if (!fail) {                                                                                    \
         constexpr int p0 = 4 * (KB);                                                                \
         constexpr int cq = p0 & 15;                                                                 \
         const int kcol = lc - cq;                                                                   \
-        if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP) M_GATHER(1, JP) }                              \
-        wave_sync();                                                                            \
-        /* [P | e_lq | x_piv] -> [I | column lq of P^-1 | y = P^-1 x_piv] by Gauss-Jordan */        \
-        double pm[4][4], qv[4], xv[4];                                                              \
+        if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP, GP) M_GATHER(1, JP, GP) }                      \
+        wave_sync();                                                                                \
+        /* [P | e_lq] -> [I | column lq of P^-1] by Gauss-Jordan (the P part is uniform) */         \
+        double pm[4][4], qv[4];                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
             const d4 row = *reinterpret_cast<const d4 *>(sU + (p0 + i) * 4);                        \
             pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];             \
             pm[i][i] += 1.0;                                                                        \
             qv[i] = (lq == i) ? 1.0 : 0.0;                                                          \
-            xv[i] = readlane_f64(kx, p0 + i);                                                       \
         }                                                                                           \
+        const double x0 = readlane_f64(kx, p0), x1 = readlane_f64(kx, p0 + 1);                      \
+        const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);                  \
         bool okp = true;                                                                            \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
             okp = okp && fabs(pm[s][s]) >= diag_thr;                                                \
             const double iv = rcp64(pm[s][s]);                                                      \
             _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[s][j] *= iv;                       \
-            qv[s] *= iv; xv[s] *= iv;                                                               \
+            qv[s] *= iv;                                                                            \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i != s) {                             \
                 const double f = pm[i][s];                                                          \
                 _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]); \
-                qv[i] = fma(-f, qv[s], qv[i]); xv[i] = fma(-f, xv[s], xv[i]);                       \
+                qv[i] = fma(-f, qv[s], qv[i]);                                                      \
             }                                                                                       \
         }                                                                                           \
         if (!ubool(okp)) { fail = true; }                                                           \
         else {                                                                                      \
-            /* A operand of V' = P^-1 V: element (i = lc, k = lq) of P^-1, padded to 16 x 4 */      \
-            const double ap = lc == 0 ? qv[0] : lc == 1 ? qv[1] : lc == 2 ? qv[2] : lc == 3 ? qv[3] : 0.0; \
-            /* extra column: kx_i -= sum_k U[i][k] y_k   (lane l <-> row l) */                       \
+            /* P^-1 to every lane through LDS: sPi[i][k], lane group k owns column k */             \
+            if (lc == 0) { sPi[0 + lq] = qv[0]; sPi[4 + lq] = qv[1]; sPi[8 + lq] = qv[2]; sPi[12 + lq] = qv[3]; } \
+            wave_sync();                                                                            \
+            /* U' = U P^-1 (row l of the panel; pivot rows hold P - I, so theirs is I - P^-1), and  \
+               the extra column kx_l -= U'[l] . x_piv */                                            \
             if (l < 32) {                                                                           \
                 const d4 ur = *reinterpret_cast<const d4 *>(sU + l * 4);                            \
-                kx -= ur[0] * xv[0] + ur[1] * xv[1] + ur[2] * xv[2] + ur[3] * xv[3];                \
+                const d4 i0 = *reinterpret_cast<const d4 *>(sPi), i1 = *reinterpret_cast<const d4 *>(sPi + 4); \
+                const d4 i2 = *reinterpret_cast<const d4 *>(sPi + 8), i3 = *reinterpret_cast<const d4 *>(sPi + 12); \
+                d4 up;                                                                              \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                       \
+                    up[k] = fma(ur[3], i3[k], fma(ur[2], i2[k], fma(ur[1], i1[k], ur[0] * i0[k]))); \
+                kx -= fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));                   \
+                *reinterpret_cast<d4 *>(sU + l * 4) = up;                                           \
             }                                                                                       \
+            wave_sync();                                                                            \
             const double au0 = -sU[(0 + lc) * 4 + lq], au1 = -sU[(16 + lc) * 4 + lq];               \
             if ((JP) <= 0) M_COLTILE(0, JP, GP)                                                     \
             if ((JP) <= 1) M_COLTILE(1, JP, GP)                                                     \
             M_COLTILE(2, JP, GP)                                                                    \
             M_COLTILE(3, JP, GP)                                                                    \
-            wave_sync();                                                                        \
+            wave_sync();                                                                            \
         }                                                                                           \
     }
     M_STEP(0, 0, 0) M_STEP(1, 0, 1) M_STEP(2, 0, 2) M_STEP(3, 0, 3)
