@@ -99,7 +99,6 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     double *const svrow = sbuf + 40;            // Stage B: pivot row                         [40]
     double *const sval = sbuf;                  // read-back: values by variable id           [66]
     double *const sz = sbuf + 128;              // h, then the solution in item order         [64]
-    double *const sPi = sbuf + 128;             // Stage A: P^-1, [i][k]                      [16]
     // fused node path: one block buffer -- Qd while the H tiles are built, then Ad for the rest of the
     // solve, both with column stride 34 (conflict-free tile reads); the two spare slots per column hold
     // q in item order (g and b of the header).  1536 + 8704 = 10240 B: 16 waves per CU.
@@ -292,42 +291,41 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
         const int kcol = lc - cq;                                                                   \
         if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP, GP) M_GATHER(1, JP, GP) }                      \
         wave_sync();                                                                                \
-        /* [P | e_lq] -> [I | column lq of P^-1] by Gauss-Jordan (the P part is uniform) */         \
-        double pm[4][4], qv[4];                                                                     \
+        /* P = L U (unit lower L, no pivoting; uniform, every lane) */                              \
+        double pm[4][4];                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
             const d4 row = *reinterpret_cast<const d4 *>(sU + (p0 + i) * 4);                        \
             pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];             \
             pm[i][i] += 1.0;                                                                        \
-            qv[i] = (lq == i) ? 1.0 : 0.0;                                                          \
         }                                                                                           \
         const double x0 = readlane_f64(kx, p0), x1 = readlane_f64(kx, p0 + 1);                      \
         const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);                  \
         bool okp = true;                                                                            \
+        double rd[4];                                   /* reciprocals of the pivots u_ss */        \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
             okp = okp && fabs(pm[s][s]) >= diag_thr;                                                \
-            const double iv = rcp64(pm[s][s]);                                                      \
-            _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[s][j] *= iv;                       \
-            qv[s] *= iv;                                                                            \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) if (i != s) {                             \
-                const double f = pm[i][s];                                                          \
+            rd[s] = rcp64(pm[s][s]);                                                                \
+            _Pragma("unroll") for (int i = s + 1; i < 4; ++i) {                                     \
+                const double f = pm[i][s] * rd[s];      /* l_is, kept in place */                   \
+                pm[i][s] = f;                                                                       \
                 _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]); \
-                qv[i] = fma(-f, qv[s], qv[i]);                                                      \
             }                                                                                       \
         }                                                                                           \
         if (!ubool(okp)) { fail = true; }                                                           \
         else {                                                                                      \
-            /* P^-1 to every lane through LDS: sPi[i][k], lane group k owns column k */             \
-            if (lc == 0) { sPi[0 + lq] = qv[0]; sPi[4 + lq] = qv[1]; sPi[8 + lq] = qv[2]; sPi[12 + lq] = qv[3]; } \
-            wave_sync();                                                                            \
-            /* U' = U P^-1 (row l of the panel; pivot rows hold P - I, so theirs is I - P^-1), and  \
-               the extra column kx_l -= U'[l] . x_piv */                                            \
+            /* U' = U P^-1, row l of the panel: solve x L U = u (pivot rows hold P - I, so theirs   \
+               is I - P^-1), and the extra column kx_l -= U'[l] . x_piv */                          \
             if (l < 32) {                                                                           \
                 const d4 ur = *reinterpret_cast<const d4 *>(sU + l * 4);                            \
-                const d4 i0 = *reinterpret_cast<const d4 *>(sPi), i1 = *reinterpret_cast<const d4 *>(sPi + 4); \
-                const d4 i2 = *reinterpret_cast<const d4 *>(sPi + 8), i3 = *reinterpret_cast<const d4 *>(sPi + 12); \
+                const double y0 = ur[0] * rd[0];                                                    \
+                const double y1 = fma(-y0, pm[0][1], ur[1]) * rd[1];                                \
+                const double y2 = fma(-y1, pm[1][2], fma(-y0, pm[0][2], ur[2])) * rd[2];            \
+                const double y3 = fma(-y2, pm[2][3], fma(-y1, pm[1][3], fma(-y0, pm[0][3], ur[3]))) * rd[3]; \
                 d4 up;                                                                              \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                       \
-                    up[k] = fma(ur[3], i3[k], fma(ur[2], i2[k], fma(ur[1], i1[k], ur[0] * i0[k]))); \
+                up[3] = y3;                                                                         \
+                up[2] = fma(-up[3], pm[3][2], y2);                                                  \
+                up[1] = fma(-up[3], pm[3][1], fma(-up[2], pm[2][1], y1));                           \
+                up[0] = fma(-up[3], pm[3][0], fma(-up[2], pm[2][0], fma(-up[1], pm[1][0], y0)));    \
                 kx -= fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));                   \
                 *reinterpret_cast<d4 *>(sU + l * 4) = up;                                           \
             }                                                                                       \
