@@ -454,10 +454,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     if (__ballot(actb && lo == hi)) { if (l == 0) a.status[b] = -1; return; }
     const double lo0 = lo, hi0 = hi;      // bounds of pair l (fixed); lo/hi follow the row's basic variable
     int satv = 0;                         // pair l: 1 = bounded variable rests at its upper bound
-    int rowvar = actb ? l : -1, colvar = actb ? NBP + l : -1;
+    // row vectors live in lanes 0..31; column vectors (colvar, nbval) in lanes 0..32: lane 32 is the extra
+    // (covering) column, so no column is a special case in the bookkeeping
+    int rowvar = actb ? l : -1, colvar = actb ? NBP + l : (l == XC ? VTH : -1);
     double nbval = 0.0, tcol = 0.0;
-    int cNvar = VTH;
-    double cNval = 0.0;
     wave_sync();                      // Stage A and the c sweep are done with sbuf
 
     // the dictionary as 16 named doubles: element g of tile (Ib, Jb) = row 16 Ib + 4 g + lq, column 16 Jb + lc
@@ -467,11 +467,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
            SD(Ib, Jb, 3) = SB(Ib, Jb)[3];
     M_SDECL(0, 0) M_SDECL(0, 1) M_SDECL(1, 0) M_SDECL(1, 1)
 #undef M_SDECL
-    auto col_of = [&](int v) -> int {
-        int cc = wave_first(actb && colvar == v);
-        if (cc < 0 && cNvar == v) cc = XC;
-        return cc;
-    };
+    auto col_of = [&](int v) -> int { return wave_first(colvar == v); };     // ids are >= 0, idle lanes hold -1
     int pivots = n;                       // the crash brought n free variables in (Stage A)
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
     int status = QPN_FAILURE;
@@ -498,7 +494,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
                 }
                 tcol = cov;
             }
-            cNval = theta0; self_lim = theta0;
+            if (l == XC) nbval = theta0;
+            self_lim = theta0;
             status = QPN_MAX_ITERS;
         }
     }
@@ -539,16 +536,13 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
             // the entering variable reaches its own opposite bound first: no basis change
             const double dl = sneg ? -self_lim : self_lim;
             if (actb) xb = fma(dl, cm, xb);
-            const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
-            if (ve == VTH) {
-                if (c == XC) cNval = 0.0; else if (l == c) nbval = 0.0;
-                status = QPN_SUCCESS; break;
-            }
+            const int ve = readlane_i32(colvar, c);
+            if (ve == VTH) { nbval = writelane_f64(nbval, c, 0.0); status = QPN_SUCCESS; break; }
             const int k = ve;
             const int au = sneg ? 0 : 1;
             const double nv = au ? readlane_f64(hi0, k) : readlane_f64(lo0, k);
-            if (l == k) satv = au;
-            if (c == XC) cNval = nv; else if (l == c) nbval = nv;
+            satv = writelane_i32(satv, k, au);
+            nbval = writelane_f64(nbval, c, nv);
             pivots++;
             cnext = col_of(NBP + k);
             if (cnext < 0) { status = QPN_FAILURE; break; }
@@ -584,7 +578,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
             const double delta = sneg ? -step : step;
             const int vl = readlane_i32(rowvar, r);
             const double vxr = readlane_f64(tcol, r);
-            const double enter_val = ((c == XC) ? cNval : readlane_f64(nbval, c)) + delta;
+            const double enter_val = readlane_f64(nbval, c) + delta;
             wave_sync();
             {
                 // extra column and values (lane l <-> row l)
@@ -604,10 +598,9 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
             }
             STAMP(3);   // pivot row through LDS
             {
-                const int ve = (c == XC) ? cNvar : readlane_i32(colvar, c);
-                if (l == r) { rowvar = ve; lo = elo; hi = ehi; }
-                if (c == XC) { cNvar = vl; cNval = leave_val; }
-                else if (l == c) { colvar = vl; nbval = leave_val; }
+                const int ve = readlane_i32(colvar, c);
+                rowvar = writelane_i32(rowvar, r, ve); lo = writelane_f64(lo, r, elo); hi = writelane_f64(hi, r, ehi);
+                colvar = writelane_i32(colvar, c, vl); nbval = writelane_f64(nbval, c, leave_val);
             }
             pivots++;
             if (vl == VTH) { status = QPN_SUCCESS; break; }
@@ -619,7 +612,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
                 const bool isfreek = Lk == -QINF && Uk == QINF;
                 if (vl < NBP) {
                     // the bounded variable p_k left at a bound: its multiplier d_k enters from 0
-                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); if (l == k) satv = au; }
+                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); satv = writelane_i32(satv, k, au); }
                     vn = NBP + k;
                     sneg = au != 0;
                     self_lim = QINF;
@@ -733,8 +726,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     };
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
     wave_sync();
-    if (actb) { sval[rowvar] = xb; sval[colvar] = nbval; }
-    if (l == 0) sval[cNvar] = cNval;
+    if (actb) sval[rowvar] = xb;
+    if (l <= XC) sval[colvar] = nbval;
     wave_sync();
     const double lam0 = sval[NBP + lc], lam1 = sval[NBP + 16 + lc];     // lambda of this lane's two columns
     {
