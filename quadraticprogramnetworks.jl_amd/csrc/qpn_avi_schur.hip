@@ -531,24 +531,30 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
         // masks: a no-op), so the dictionary registers have one definition per iteration.
         double v0 = 0.0, v1 = 0.0, inv = 0.0;
         unsigned long long mcol = 0ull, mrow = 0ull;
-        int cx = XC, rsel = 0, cnext;
+        int cx = XC, rsel = 0, cnext = -1;
+        // ... and the same single-lane writes of the bookkeeping vectors (a write that does not apply goes to
+        // idle lane 63), so those registers are never copied around a branch either
+        int rW = 63, veW = 0, cW = 63, vlW = 0, kW = 63, auW = 0;
+        double eloW = 0.0, ehiW = 0.0, nbW = 0.0;
+        bool stop = false;
         if (bal == 0ull) {
             // the entering variable reaches its own opposite bound first: no basis change
             const double dl = sneg ? -self_lim : self_lim;
             if (actb) xb = fma(dl, cm, xb);
             const int ve = readlane_i32(colvar, c);
-            if (ve == VTH) { nbval = writelane_f64(nbval, c, 0.0); status = QPN_SUCCESS; break; }
-            const int k = ve;
-            const int au = sneg ? 0 : 1;
-            const double nv = au ? readlane_f64(hi0, k) : readlane_f64(lo0, k);
-            satv = writelane_i32(satv, k, au);
-            nbval = writelane_f64(nbval, c, nv);
-            pivots++;
-            cnext = col_of(NBP + k);
-            if (cnext < 0) { status = QPN_FAILURE; break; }
-            sneg = au != 0;
-            self_lim = QINF;
-            if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+            if (ve == VTH) { nbW = 0.0; status = QPN_SUCCESS; stop = true; }
+            else {
+                const int k = ve;
+                const int au = sneg ? 0 : 1;
+                nbW = au ? readlane_f64(hi0, k) : readlane_f64(lo0, k);
+                kW = k; auW = au;
+                pivots++;
+                cnext = col_of(NBP + k);
+                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
+                sneg = au != 0;
+                self_lim = QINF;
+                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+            }
             STAMP(4);
         } else {
             int r;
@@ -597,13 +603,11 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
                 cx = c;
             }
             STAMP(3);   // pivot row through LDS
-            {
-                const int ve = readlane_i32(colvar, c);
-                rowvar = writelane_i32(rowvar, r, ve); lo = writelane_f64(lo, r, elo); hi = writelane_f64(hi, r, ehi);
-                colvar = writelane_i32(colvar, c, vl); nbval = writelane_f64(nbval, c, leave_val);
-            }
+            rW = r; veW = readlane_i32(colvar, c); eloW = elo; ehiW = ehi;      // row r now holds the entering variable
+            cW = c; vlW = vl; nbW = leave_val;                                  // column c the leaving one
             pivots++;
-            if (vl == VTH) { status = QPN_SUCCESS; break; }
+            if (vl == VTH) { status = QPN_SUCCESS; stop = true; }
+            else {
             int vn;
             {
                 const int k = vl < NBP ? vl : vl - NBP;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
                 const bool isfreek = Lk == -QINF && Uk == QINF;
                 if (vl < NBP) {
                     // the bounded variable p_k left at a bound: its multiplier d_k enters from 0
-                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); satv = writelane_i32(satv, k, au); }
+                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); kW = k; auW = au; }
                     vn = NBP + k;
                     sneg = au != 0;
                     self_lim = QINF;
@@ -629,10 +633,19 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
                     elo = Lk; ehi = Uk;
                 }
             }
-            cnext = col_of(vn);
-            if (cnext < 0) { status = QPN_FAILURE; break; }
+            // (colvar still holds the entering id veW at column c here -- the write-back is below --, so that
+            // column must not match; the new id there, vl, is never its own complement vn)
+            cnext = (vn == veW) ? -1 : col_of(vn);
+            if (cnext < 0) { status = QPN_FAILURE; stop = true; }
+            }
             STAMP(4);
         }
+        // ---- write-back of the single-lane bookkeeping updates
+        rowvar = writelane_i32(rowvar, rW, veW); lo = writelane_f64(lo, rW, eloW); hi = writelane_f64(hi, rW, ehiW);
+        colvar = writelane_i32(colvar, cW, vlW);
+        nbval = writelane_f64(nbval, c, nbW);
+        satv = writelane_i32(satv, kW, auW);
+        if (stop) break;
         // ---- the exchange on the 32 x 32 dictionary (see the header of this stage)
         {
             const d4 ua = *reinterpret_cast<const d4 *>(sucol + lq * 8);
