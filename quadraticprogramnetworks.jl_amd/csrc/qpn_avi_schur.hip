@@ -280,7 +280,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     }
 #define M_COLTILE(J, IP, GP)                                                                        \
     {                                                                                               \
-        const double vraw = TL(IP, J)[GP];              /* the 4 pivot rows of this column tile: a B operand */ \
+        /* the 4 pivot rows of this column tile are a B operand; a private copy, because they are also part \
+           of the accumulator tile TL(IP, J) (else the compiler moves the whole tile out and back) */ \
+        double vraw = TL(IP, J)[GP];                                                                \
+        asm volatile("" : "+v"(vraw));      /* opaque: the copy itself is the compiler's (hazard-aware) */ \
         TL(0, J) = MFMA(au0, vraw, TL(0, J));                                                       \
         TL(1, J) = MFMA(au1, vraw, TL(1, J));                                                       \
     }
