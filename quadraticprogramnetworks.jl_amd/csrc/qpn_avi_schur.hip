@@ -112,6 +112,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
 #ifdef QPN_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime() & 0xffffffffull;
 #endif
     // node records (fused path): M = [[Qd, -Ad'],[Ad, 0]], q = [qd + R w; B w], src/avi.jl:205-251 + :305-377
     const int nn = a.nd.n, nm = a.nd.m, np_ = a.nd.p;
@@ -853,8 +854,11 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     }
     STAMP(5);   // read-back + post-check + stores
 #ifdef QPN_STAMPS
-    if (ae.stamps && l == 0)
+    if (ae.stamps && l == 0) {
+        // wall-clock start / end of this block (s_memrealtime: one 100 MHz counter for the whole device)
+        stamp_acc[7] = (stamp_rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
         for (int i = 0; i < 8; ++i) ae.stamps[(size_t)b * 8 + i] = stamp_acc[i];
+    }
 #endif
 }
 

@@ -38,7 +38,24 @@ piv = res["pivots"].cpu().numpy().mean()
 names = ["setup+load", "loop control", "extract column", "pivot selection", "rank-1 update", "readback+check", "crash fast path"]
 if fused or os.environ.get("SCHUR_NAMES"):
     names = ["setup+load", "B: column via LDS", "B: ratio test+row", "B: row via LDS+exchange", "B: bookkeeping/flips", "readback+check", "A: MFMA crash"]
+endt = s[:, 7].copy(); s[:, 7] = 0
 tot = s.sum(axis=1).mean()
 print(f"mean pivots {piv:.1f} (Stage B: {piv - n:.1f}), mean cycles per solve {tot:.0f} ({tot/piv:.0f} per pivot)")
 for i, nm in enumerate(names):
     print(f"  {nm:18s} {s[:, i].mean():10.0f} cycles  {100*s[:, i].mean()/tot:5.1f} %")
+
+if fused:
+    # timeline of the launch from the device-wide 100 MHz clock (10 ns ticks)
+    raw = st.cpu().numpy()[:, 7].astype(np.uint64)
+    start = (raw >> np.uint64(32)).astype(np.float64) * 0.01; endt = (raw & np.uint64(0xffffffff)).astype(np.float64) * 0.01
+    t0 = start.min(); start -= t0; endt -= t0
+    print(f"launch timeline (us from the first block's start): last start {start.max():.1f}, last end {endt.max():.1f}")
+    order = np.argsort(start)
+    for lo_, hi_ in ((0, 4096), (4096, 8192), (8192, cnt)):
+        idx = order[lo_:hi_]
+        if len(idx):
+            d = endt[idx] - start[idx]
+            print(f"  blocks {lo_}-{hi_} by start: starts {start[idx].min():6.1f}..{start[idx].max():6.1f} us, duration mean {d.mean():5.1f} (min {d.min():5.1f}, max {d.max():5.1f}) us, "
+                  f"ends {endt[idx].min():6.1f}..{endt[idx].max():6.1f} us, load phase {s[idx, 0].mean():7.0f} cycles")
+    for tq in (10, 20, 30, 40, 60, 80, 100, 120, 140, 160):
+        print(f"    t = {tq:3d} us: running {int(((start <= tq) & (endt > tq)).sum()):5d}, finished {int((endt <= tq).sum()):5d}")
