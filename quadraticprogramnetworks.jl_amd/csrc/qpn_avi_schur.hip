@@ -33,6 +33,7 @@
 // DESIGN.md section 2.
 #include "qpn_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define QINF __builtin_huge_val()
 
@@ -748,16 +749,31 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     wave_sync();
     const double lam0 = sval[NBP + lc], lam1 = sval[NBP + 16 + lc];     // lambda of this lane's two columns
     {
-        // partial row sums of W lambda over this lane's columns, reduced across the 16 lanes of a DPP row
-#define M_WROW(Ib, g, slot)                                                                         \
-    {                                                                                               \
-        double pr = TL(Ib, 2)[g] * lam0 + TL(Ib, 3)[g] * lam1;                                      \
-        pr += dpp_f64<0xB1>(pr); pr += dpp_f64<0x4E>(pr); pr += dpp_f64<0x141>(pr); pr += dpp_f64<0x140>(pr); \
-        if (lc == 0) sz[16 * (Ib) + 4 * (g) + lq] = pr;                                             \
-    }
-        M_WROW(0, 0, 0) M_WROW(0, 1, 1) M_WROW(0, 2, 2) M_WROW(0, 3, 3)
-        M_WROW(1, 0, 4) M_WROW(1, 1, 5) M_WROW(1, 2, 6) M_WROW(1, 3, 7)
-#undef M_WROW
+        // (W lambda)_row = sum over the 16 lanes of a DPP row of this lane's two-column partial, for the 8
+        // rows j = 4 Ib + g a lane holds.  Folded butterfly: at each of the first three stages a lane gives
+        // half of its values to its partner and adds the partner's other half, so 8 -> 4 -> 2 -> 1 values
+        // (7 exchanges instead of 8 x 4); lane bits 0..2 of lc then name the row, bit 3 is summed last.
+        double p0 = TL(0, 2)[0] * lam0 + TL(0, 3)[0] * lam1, p1 = TL(0, 2)[1] * lam0 + TL(0, 3)[1] * lam1;
+        double p2 = TL(0, 2)[2] * lam0 + TL(0, 3)[2] * lam1, p3 = TL(0, 2)[3] * lam0 + TL(0, 3)[3] * lam1;
+        double p4 = TL(1, 2)[0] * lam0 + TL(1, 3)[0] * lam1, p5 = TL(1, 2)[1] * lam0 + TL(1, 3)[1] * lam1;
+        double p6 = TL(1, 2)[2] * lam0 + TL(1, 3)[2] * lam1, p7 = TL(1, 2)[3] * lam0 + TL(1, 3)[3] * lam1;
+        const bool b0 = (lc & 1) != 0, b1 = (lc & 2) != 0, b2 = (lc & 4) != 0;
+        // stage 1 (partner lc ^ 1): keep rows with bit0 == b0
+        const double q0 = (b0 ? p1 : p0) + dpp_f64<0xB1>(b0 ? p0 : p1), q1 = (b0 ? p3 : p2) + dpp_f64<0xB1>(b0 ? p2 : p3);
+        const double q2 = (b0 ? p5 : p4) + dpp_f64<0xB1>(b0 ? p4 : p5), q3 = (b0 ? p7 : p6) + dpp_f64<0xB1>(b0 ? p6 : p7);
+        // stage 2 (partner lc ^ 2): q_i is row 2 i + b0; keep rows with bit1 == b1
+        const double r0 = (b1 ? q1 : q0) + dpp_f64<0x4E>(b1 ? q0 : q1), r1 = (b1 ? q3 : q2) + dpp_f64<0x4E>(b1 ? q2 : q3);
+        // stages 3, 4 (partners lc ^ 4, lc ^ 8) go through ds_swizzle: the LDS crossbar, not the VALU
+        auto swz = [](double v, auto pat) -> double {
+            const int lo_ = __builtin_amdgcn_ds_swizzle(__double2loint(v), decltype(pat)::value);
+            const int hi_ = __builtin_amdgcn_ds_swizzle(__double2hiint(v), decltype(pat)::value);
+            return __hiloint2double(hi_, lo_);
+        };
+        double t0 = (b2 ? r1 : r0) + swz(b2 ? r0 : r1, std::integral_constant<int, 0x101F>{});   // keep rows with bit2 == b2
+        t0 += swz(t0, std::integral_constant<int, 0x201F>{});
+        // the lane now holds the full sum for row j = b0 + 2 b1 + 4 b2 of its own lc bits
+        const int jrow = lc & 7;
+        if (lc < 8) sz[16 * (jrow >> 2) + 4 * (jrow & 3) + lq] = t0;
     }
     wave_sync();
     // item order: rows < n are x, rows n.. are lambda
