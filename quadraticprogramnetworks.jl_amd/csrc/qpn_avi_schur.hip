@@ -458,6 +458,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
     // equality GAVI rows need their multiplier crashed in: left to the general kernel
     if (__ballot(actb && lo == hi)) { if (l == 0) a.status[b] = -1; return; }
     const double lo0 = lo, hi0 = hi;      // bounds of pair l (fixed); lo/hi follow the row's basic variable
+    // class of pair l (0 bounded on at least one side, 2 free; equal bounds were sent to the general kernel
+    // above) and its range, so that the per-pivot bookkeeping is integer / scalar work, not fp64 compares
+    const int clsv = (lo0 == -QINF && hi0 == QINF) ? 2 : 0;
+    const double rngv = hi0 - lo0;
     int satv = 0;                         // pair l: 1 = bounded variable rests at its upper bound
     // row vectors live in lanes 0..31; column vectors (colvar, nbval) in lanes 0..32: lane 32 is the extra
     // (covering) column, so no column is a special case in the bookkeeping
@@ -616,26 +620,25 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
             int vn;
             {
                 const int k = vl < NBP ? vl : vl - NBP;
-                const double Lk = readlane_f64(lo0, k), Uk = readlane_f64(hi0, k);
+                const int cls = readlane_i32(clsv, k);
                 int au = readlane_i32(satv, k);
-                const bool isfreek = Lk == -QINF && Uk == QINF;
                 if (vl < NBP) {
-                    // the bounded variable p_k left at a bound: its multiplier d_k enters from 0
-                    if (Lk != Uk) { au = (leave_val == Uk) ? 1 : 0; au = uni(au); kW = k; auW = au; }
+                    // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --:
+                    // its multiplier d_k enters from 0
+                    au = (int)((__ballot(cndhi) >> r) & 1ull); kW = k; auW = au;
                     vn = NBP + k;
                     sneg = au != 0;
                     self_lim = QINF;
-                    if (Lk == Uk) { elo = -QINF; ehi = QINF; }
-                    else if (isfreek) { elo = 0.0; ehi = 0.0; }
+                    if (cls == 2) { elo = 0.0; ehi = 0.0; }
                     else if (au) { elo = -QINF; ehi = 0.0; }
                     else { elo = 0.0; ehi = QINF; }
                 } else {
                     // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
                     vn = k;
                     sneg = au != 0;
-                    self_lim = Uk - Lk;
-                    if (isfreek) { self_lim = QINF; sneg = false; }
-                    elo = Lk; ehi = Uk;
+                    self_lim = readlane_f64(rngv, k);           // +inf for a free pair
+                    if (cls == 2) sneg = false;
+                    elo = readlane_f64(lo0, k); ehi = readlane_f64(hi0, k);
                 }
             }
             // (colvar still holds the entering id veW at column c here -- the write-back is below --, so that
