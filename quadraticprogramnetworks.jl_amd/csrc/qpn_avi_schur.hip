@@ -523,19 +523,17 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
         const double cm = actb ? sucol[(l & 3) * 8 + ((l >> 4) << 2) + ((l >> 2) & 3)] : 0.0;
         STAMP(1);   // entering column through LDS
         // ---- ratio test (same rule as the general kernel; reciprocal by Newton instead of a division)
-        const double gdir = sneg ? -cm : cm;
+        const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
         const double rc = rcp64(gdir);
         const bool cndlo = actb && gdir < -ptol && lo > -QINF;
         const bool cndhi = actb && gdir > ptol && hi < QINF;
         const bool cnd = cndlo || cndhi;
-        const double arc = cndlo ? -rc : rc;
+        const double arc = fabs(rc);                              // = cndlo ? -rc : rc on every candidate row
         const double dd = (cndlo ? xb - lo : hi - xb) * arc;
         const double d1 = fma(slack, arc, dd);
-        double dmax = wave_min32_f64(cnd ? d1 : QINF);
-        if (self_lim < dmax) dmax = self_lim;
-        if (ubool(dmax == QINF)) { status = QPN_RAY_TERM; break; }
-        const bool cand = cnd && dd <= dmax;
-        const unsigned long long bal = __ballot(cand);
+        const double dmax = min_f64_nc(wave_min32_all_f64(cnd ? d1 : QINF), self_lim);      // uniform over lanes 0..31, in a VGPR
+        if (__ballot(actb && dmax == QINF) != 0ull) { status = QPN_RAY_TERM; break; }
+        const unsigned long long bal = __ballot(cnd && dd <= dmax);
         // Both outcomes below end in the SAME exchange block (a bound flip runs it with v = 0 and empty lane
         // masks: a no-op), so the dictionary registers have one definition per iteration.
         double v0 = 0.0, v1 = 0.0, inv = 0.0;
@@ -569,6 +567,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
             int r;
             if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
             else {
+                const bool cand = cnd && dd <= dmax;
                 double ag = cand ? fabs(gdir) : -1.0;
                 if (cand && rowvar == VTH) ag = QINF;
                 const double bestg = wave_max_f64(ag);

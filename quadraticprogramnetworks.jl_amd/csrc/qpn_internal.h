@@ -204,6 +204,26 @@ __device__ __forceinline__ double wave_min32_f64(double v)
     double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
     return qpn_min2(r0, r1);
 }
+// v_min_f64 without the canonicalising v_max the compiler puts in front of fmin() (callers feed no NaNs).
+// Inline asm is invisible to the hazard recognizer: the s_nop covers a DPP read of the result.
+__device__ __forceinline__ double min_f64_nc(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// min over lanes 0..31, returned in EVERY lane 0..31 (lanes 32..63 get the min of their own half):
+// four DPP row stages + one ds_swizzle (lane ^ 16, on the LDS crossbar) -- no v_readlane, no SGPR detour
+__device__ __forceinline__ double wave_min32_all_f64(double v)
+{
+    v = min_f64_nc(v, dpp_f64<0xB1>(v));
+    v = min_f64_nc(v, dpp_f64<0x4E>(v));
+    v = min_f64_nc(v, dpp_f64<0x141>(v));
+    v = min_f64_nc(v, dpp_f64<0x140>(v));
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+    return min_f64_nc(v, __hiloint2double(hi, lo));
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
 #pragma unroll
