@@ -1,0 +1,125 @@
+"""BASELINE config 4 at FULL size (10 000 nodes x 32 vars, the bench workload) through the C-ABI.
+
+The oracle cannot run 10 000 solves inside a test budget on the driver's CPU share, so the full batch
+is held to size-independent properties of the path, and a seeded subset
+of nodes is compared with the oracle directly:
+
+* every item solved, natural-map residual <= 1e-8, and the INDEPENDENT check kernel (A3,
+  src/avi.jl:148-156, on blocks assembled by the stand-alone assembly kernel) finds 0 violations;
+* fused pass == assemble + solve (same primal/dual to 1e-9, identical active-set masks and pivots);
+* shard invariance: solving a node range on its own gives bit-identical rows (what multi-GPU relies on);
+* scale covariance: (Q, R, qd) -> alpha (Q, R, qd) leaves x unchanged, scales lambda by alpha and keeps
+  the active sets (away from the absolute 1e-2 mask tolerance);  constraint-permutation equivariance: permuting the rows of (A, B, l, u) permutes
+  lambda and the GAVI part of the masks and leaves x unchanged;
+* the primal write-back equals z[:, :n].
+"""
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+NODES, N_, M_, P_ = 10_000, 32, 32, 8
+
+
+@pytest.fixture(scope="module")
+def full(engine):
+    import torch
+    from qpn_amd.engine import colmajor
+    Q, R, qd, A, B, l, u = P.synth_nodes(0, NODES, N_, M_, P_)
+    w = P.shared_params(P_)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    host = dict(Q=Q, R=R, qd=qd, A=A, B=B, l=l, u=u, w=w)
+    dev = [t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(w)]
+    x = torch.zeros((NODES, N_), dtype=torch.float64, device="cuda:0")
+    res = engine.solve_nodes(*dev, x_out=x)
+    torch.cuda.synchronize()
+    return host, dev, {k: v.cpu().numpy() for k, v in res.items()}, x.cpu().numpy()
+
+
+def test_full_batch_solved_and_certified(engine, full):
+    import torch
+    host, dev, res, x = full
+    assert np.all(res["status"] == 1)
+    assert np.max(res["resid"]) <= 1e-8
+    assert np.array_equal(x, res["z"][:, :N_])
+    # independent certificate: stand-alone assembly kernel + stand-alone KKT check kernel
+    Mc, q, lo, hi, kind = engine.assemble_nodes(*dev)
+    z = torch.tensor(res["z"], dtype=torch.float64, device="cuda:0")
+    degree, r = engine.check_avi_batch(Mc, q, lo, hi, z, kind=kind, tol=1e-6)
+    torch.cuda.synchronize()
+    assert int(degree.sum().item()) == 0
+    # complementarity as the masks state it: a GAVI row whose multiplier is non-zero sits at a bound
+    lam = res["z"][:, N_:]
+    s = r.cpu().numpy()[:, N_:]
+    at_bound = (np.abs(s - host["l"]) <= 1e-6) | (np.abs(s - host["u"]) <= 1e-6)
+    assert np.all(at_bound[np.abs(lam) > 1e-9])
+    assert np.all((res["active"][:, N_:] >> 4) > 0) and np.all(res["active"][:, :N_] == 2)
+
+
+def test_full_batch_fused_equals_two_calls(engine, full):
+    import torch
+    host, dev, res, _ = full
+    Mc, q, lo, hi, kind = engine.assemble_nodes(*dev)
+    r2 = engine.solve_avi_batch(Mc, q, lo, hi, kind=kind)
+    torch.cuda.synchronize()
+    assert np.array_equal(r2["status"].cpu().numpy(), res["status"])
+    assert np.array_equal(r2["active"].cpu().numpy(), res["active"])
+    assert np.array_equal(r2["pivots"].cpu().numpy(), res["pivots"])
+    assert np.max(np.abs(r2["z"].cpu().numpy() - res["z"])) <= 1e-9
+
+
+def test_subset_against_oracle(oracle, full):
+    host, _, res, _ = full
+    idx = np.random.default_rng(5).choice(NODES, 400, replace=False)
+    M, q, lo, hi, kind = P.reduced_blocks(host["Q"][idx], host["R"][idx], host["qd"][idx], host["A"][idx], host["B"][idx],
+                                          host["l"][idx], host["u"][idx], host["w"])
+    rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+    assert np.array_equal(res["status"][idx], rc["status"])
+    assert np.array_equal(res["active"][idx], rc["active"])          # bit-exact active sets
+    assert np.array_equal(res["pivots"][idx], rc["pivots"])
+    assert np.max(np.abs(res["z"][idx] - rc["z"])) <= 1e-9           # fp64 tolerance of the path
+
+
+def test_shard_invariance(engine, full):
+    """Rows of a node range solved alone are bit-identical to the same rows of the full solve."""
+    import torch
+    _, dev, res, _ = full
+    for lo_, hi_ in [(0, 1250), (3750, 5000), (8750, 10_000), (4999, 5003)]:
+        part = [a[lo_:hi_] if a.dim() > 1 or a.shape[0] == NODES else a for a in dev[:-1]] + [dev[-1]]
+        r = engine.solve_nodes(*part)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["z"].cpu().numpy(), res["z"][lo_:hi_])
+        assert np.array_equal(r["active"].cpu().numpy(), res["active"][lo_:hi_])
+
+
+def test_scale_and_permutation_covariance(engine, full):
+    import torch
+    from qpn_amd.engine import colmajor
+    host, _, res, _ = full
+    sub = slice(0, 2000)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    Q, R, qd, A, B, l, u, w = (host[k][sub] if k != "w" else host[k] for k in ("Q", "R", "qd", "A", "B", "l", "u", "w"))
+    alpha = 4.0                                                      # a power of two: the scaling itself is exact
+    r = engine.solve_nodes(t(colmajor(alpha * Q)), t(colmajor(alpha * R)), t(alpha * qd), t(colmajor(A)), t(colmajor(B)),
+                           t(l), t(u), t(w))
+    torch.cuda.synchronize()
+    z = r["z"].cpu().numpy()
+    assert np.all(r["status"].cpu().numpy() == 1)
+    assert np.max(np.abs(z[:, :N_] - res["z"][sub, :N_])) <= 1e-9
+    assert np.max(np.abs(z[:, N_:] - alpha * res["z"][sub, N_:])) <= 1e-8
+    # the masks classify multipliers with the reference's ABSOLUTE tolerance 1e-2 (src/avi_solutions.jl:511),
+    # so they are scale-covariant only where lambda is zero or clear of that threshold before and after
+    lam = res["z"][sub, N_:]
+    stable = np.concatenate([np.ones((lam.shape[0], N_), bool), (lam == 0.0) | (np.abs(lam) > 1e-2)], axis=1)
+    assert np.array_equal(r["active"].cpu().numpy()[stable], res["active"][sub][stable])
+    assert stable.mean() > 0.95
+    perm = np.random.default_rng(9).permutation(M_)
+    r = engine.solve_nodes(t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A[:, perm, :])), t(colmajor(B[:, perm, :])),
+                           t(l[:, perm]), t(u[:, perm]), t(w))
+    torch.cuda.synchronize()
+    z = r["z"].cpu().numpy()
+    assert np.max(np.abs(z[:, :N_] - res["z"][sub, :N_])) <= 1e-9
+    assert np.max(np.abs(z[:, N_:] - res["z"][sub, N_:][:, perm])) <= 1e-9
+    assert np.array_equal(r["active"].cpu().numpy()[:, N_:], res["active"][sub, N_:][:, perm])
