@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="assemble M in HBM, then solve (two kernels) instead of the fused pass")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
+    ap.add_argument("--no-schedule", action="store_true",
+                    help="natural node order (default: longest-first schedule hint, refreshed from the pivot counts every 16 steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,11 +110,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Schedule hint (qpn_order_nodes_by_pivots): the outer loop sweeps the same nodes again and again, so the
+    # pivot counts of one sweep order the next ones longest-first (shorter launch tail).  It is refreshed on the
+    # device every REFRESH steps, INSIDE the timed region; it changes which wavefront solves which node, nothing else.
+    REFRESH = 16
+    use_sched = not (args.no_schedule or args.unfused)
+
+    def maybe_refresh(i, res):
+        if use_sched and res is not None and (i == 1 or i % REFRESH == 0):      # first sweep's counts, then periodically
+            eng.order_nodes_by_pivots(res["pivots"])
+
+    res = None
+    for i in range(args.warmup):
+        maybe_refresh(i, res)
         res = step(False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        maybe_refresh(i + args.warmup, res)
         res = step(True)
     barrier()
     dt = time.perf_counter() - t0
@@ -150,7 +165,8 @@ def main():
                                    f"(n=m={n}, N_red={N}, p={p}; BASELINE.json configs[3]); step = "
                                    "KKT assembly + cold-start AVI solve + check + active sets ("
                                    + ("two kernels" if args.unfused else "one fused kernel") + ")"
-                                   + (" + RCCL all-gather of primals" if use_dist else ""),
+                                   + (" + RCCL all-gather of primals" if use_dist else "")
+                                   + ("; longest-first node schedule refreshed from the previous sweep's pivot counts every 16 steps" if use_sched else ""),
                        "nodes": args.nodes, "n": n, "m": m, "params": p,
                        "sharding": f"node ranges over {world} GPU(s)",
                        "max_resid": max_resid, "solved": solved},

@@ -149,6 +149,19 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
                          int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
                          const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x);
 
+/* ---- schedule hint for qpn_solve_nodes[_into]: longest solves first ---------------------------------
+ * The outer loop (src/algorithm.jl:13-117) sweeps the SAME nodes again and again, and a node's pivot
+ * count changes little between sweeps, while a launch ends with a tail in which the last, longest
+ * solves run on a nearly empty GPU.  qpn_order_nodes_by_pivots builds, on the device, a permutation of
+ * 0..count-1 by DESCENDING pivot count (`pivots` = the output of an earlier sweep over the same nodes)
+ * and installs it in the context; later qpn_solve_nodes[_into] calls with batch == count hand node
+ * order[i] to the i-th wavefront.  Inputs, outputs and their layout do not change -- only which
+ * wavefront solves which node (results are independent of it, bit for bit).  qpn_set_node_order installs
+ * a caller-made permutation (entries outside 0..count-1 leave their slot unsolved) or, with order ==
+ * NULL, clears the hint.  The hint is ignored whenever batch != count. */
+int qpn_order_nodes_by_pivots(qpn_ctx *ctx, const int32_t *pivots, int32_t count, int mem);
+int qpn_set_node_order(qpn_ctx *ctx, const int32_t *order, int32_t count, int mem);
+
 /* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
  *   xd [batch][n] current decision values, w as above.
  *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower

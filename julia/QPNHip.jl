@@ -123,6 +123,19 @@ function solve_nodes!(x::Union{Nothing,StridedMatrix{Float64}}, Qd::Array{Float6
     (z, status, resid, pivots, active)
 end
 
+"""
+    order_nodes_by_pivots!(pivots)
+
+Schedule hint for later `solve_nodes!` calls over the same nodes (longest solves first); `pivots` is the
+`pivots` output of an earlier sweep.  `clear_node_order!()` removes it.  Results do not depend on it.
+"""
+function order_nodes_by_pivots!(pivots::Vector{Int32})
+    rc = ccall((:qpn_order_nodes_by_pivots, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), pivots, Int32(length(pivots)), QPN_MEM_HOST)
+    rc == 0 || error("qpn_order_nodes_by_pivots failed ($rc)")
+    nothing
+end
+clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), C_NULL, Int32(0), QPN_MEM_HOST); nothing)
+
 # ---- drop-in bodies -------------------------------------------------------------------------------
 # src/avi.jl:63-77 with the PATH call replaced; StatusCode / check_avi_solution stay the reference's.
 function solve_avi_hip(QPN, avi, z0, w; convergence_tolerance = 1e-10)

@@ -14,7 +14,8 @@ ABI_SYMBOLS = (
     "qpn_ctx_use_own_stream",
     "qpn_ctx_synchronize", "qpn_ctx_last_error", "qpn_strerror", "qpn_avi_default_opts",
     "qpn_solve_avi_batch", "qpn_solve_mcp_csc", "qpn_check_avi_batch", "qpn_comp_indices",
-    "qpn_assemble_nodes", "qpn_solve_nodes", "qpn_solve_nodes_into", "qpn_verify_nodes",
+    "qpn_assemble_nodes", "qpn_solve_nodes", "qpn_solve_nodes_into", "qpn_order_nodes_by_pivots",
+    "qpn_set_node_order", "qpn_verify_nodes",
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -76,6 +77,8 @@ def load_library():
                                     C.c_int64, vp, vp, vp, vp, vp, C.POINTER(AviOpts), C.c_int]
     lib.qpn_solve_nodes_into.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp,
                                          vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(AviOpts), C.c_int, vp, C.c_int64]
+    lib.qpn_order_nodes_by_pivots.argtypes = [vp, vp, C.c_int32, C.c_int]
+    lib.qpn_set_node_order.argtypes = [vp, vp, C.c_int32, C.c_int]
     lib.qpn_verify_nodes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
     for s in ABI_SYMBOLS:

@@ -89,7 +89,11 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
 {
     const int N = NODES ? a.nd.n + a.nd.m : a.N;
     const int l = threadIdx.x;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if constexpr (NODES) {
+        // schedule hint (qpn_order_nodes_by_pivots): this wavefront's node; a bad entry leaves the slot idle
+        if (a.order) { b = a.order[blockIdx.x]; if ((unsigned)b >= (unsigned)a.batch) return; }
+    }
     const int lc = l & 15, lq = l >> 4;
 
     // Stage A scratch (sU: pivot columns, [row][k]) and Stage B / read-back scratch never live at the

@@ -17,6 +17,10 @@ struct qpn_ctx {
     // grow-only device workspace used by the host-pointer paths and multi-kernel entry points
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // schedule hint of qpn_solve_nodes (qpn_order_nodes_by_pivots / qpn_set_node_order): context-owned
+    int32_t *order = nullptr;
+    int32_t order_count = 0;      // 0 = no hint installed
+    int32_t order_cap = 0;
 };
 
 namespace {
@@ -121,6 +125,7 @@ int qpn_ctx_destroy(qpn_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return QPN_OK;
@@ -483,6 +488,7 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
     const bool x_dev = x && mem == QPN_MEM_DEVICE;
     if (x_dev && mfma_shape) { a.x = x; a.stride_x = stride_x; }      // written by the solve kernels themselves
+    if (mfma_shape && ctx->order_count == batch) a.order = ctx->order;      // schedule hint (longest first)
     if (mfma_shape) {
         // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
         // (one small scan-mode launch: its waves pick the flagged items, assemble their blocks into the
@@ -514,6 +520,58 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
             for (int32_t b = 0; b < batch; ++b)
                 for (int32_t i = 0; i < n; ++i) x[(size_t)b * (size_t)stride_x + i] = z[(size_t)b * N + i];
     }
+    return QPN_OK;
+}
+
+namespace {
+int order_reserve(qpn_ctx *ctx, int32_t count)
+{
+    if (count <= ctx->order_cap) return QPN_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // earlier launches may still read the old buffer
+    if (ctx->order) { HIPCHK(ctx, hipFree(ctx->order)); ctx->order = nullptr; ctx->order_cap = 0; ctx->order_count = 0; }
+    HIPCHK(ctx, hipMalloc((void **)&ctx->order, (size_t)count * 4));
+    ctx->order_cap = count;
+    return QPN_OK;
+}
+} // namespace
+
+int qpn_order_nodes_by_pivots(qpn_ctx *ctx, const int32_t *pivots, int32_t count, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!pivots || count <= 0) return fail_arg(ctx, "qpn_order_nodes_by_pivots: bad arguments");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_order_nodes_by_pivots: bad mem kind");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = order_reserve(ctx, count);
+    if (rc != QPN_OK) return rc;
+    const int32_t *dp = pivots;
+    if (mem == QPN_MEM_HOST) {
+        int32_t *tmp;
+        Carver cv(ctx);
+        cv.add((void **)&tmp, (size_t)count * 4);
+        rc = cv.commit();
+        if (rc != QPN_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(tmp, pivots, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+        dp = tmp;
+    }
+    HIPCHK(ctx, qpn_launch_order_by_pivots(dp, count, ctx->order, ctx->stream));
+    if (mem == QPN_MEM_HOST) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->order_count = count;
+    return QPN_OK;
+}
+
+int qpn_set_node_order(qpn_ctx *ctx, const int32_t *order, int32_t count, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!order) { ctx->order_count = 0; return QPN_OK; }
+    if (count <= 0) return fail_arg(ctx, "qpn_set_node_order: bad count");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_set_node_order: bad mem kind");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = order_reserve(ctx, count);
+    if (rc != QPN_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->order, order, (size_t)count * 4,
+                               mem == QPN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    if (mem == QPN_MEM_HOST) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->order_count = count;
     return QPN_OK;
 }
 

@@ -46,6 +46,8 @@ struct AviBatchArgs {
     // optional scatter of the primal block z[b][0..nd.n) into x[b * stride_x + i] (qpn_solve_nodes_into)
     double *x;
     int64_t stride_x;
+    // optional schedule of the fused node kernel: wavefront i solves node order[i] (a permutation)
+    const int32_t *order;
 };
 
 // qpn_avi_solve.hip
@@ -67,6 +69,7 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream);  // register-tableau kernel
 
 // qpn_kkt.hip
+hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int32_t *order, hipStream_t stream);
 hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,
                                 const double *q, const double *l, const double *u,
                                 const uint8_t *kind, int64_t stride_kind, const double *z,

@@ -86,7 +86,49 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(
     qpn_assemble_item(nd, b, lane, Mout, qout, lout, uout, kind_out);
 }
 
+// ---- schedule hint: permutation of 0..count-1 by descending pivot count (counting sort, ONE workgroup) ----
+// Pivot counts are small integers; bins 0..1023 (larger counts share the last bin).  The order inside a
+// bin is whatever the atomics give -- any order is a valid schedule.
+__global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pivots, int32_t count, int32_t *order)
+{
+    __shared__ int hist[1024];
+    __shared__ int wsum[16];
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < count; i += 1024) {
+        int p = pivots[i];
+        p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
+        atomicAdd(&hist[1023 - p], 1);                      // descending: bin 0 holds the largest counts
+    }
+    __syncthreads();
+    // exclusive prefix sum of the 1024 bins: wave scans + a scan of the 16 wave totals
+    const int v = hist[t];
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if ((t & 63) >= off) incl += o; }
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int wv = 0; wv < (t >> 6); ++wv) base += wsum[wv];
+    __syncthreads();
+    hist[t] = base + incl - v;                              // start of this bin
+    __syncthreads();
+    for (int i = t; i < count; i += 1024) {
+        int p = pivots[i];
+        p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
+        order[atomicAdd(&hist[1023 - p], 1)] = i;
+    }
+}
+
 } // namespace
+
+hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int32_t *order, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(order_by_pivots_kernel, dim3(1), dim3(1024), 0, stream, pivots, count, order);
+    return hipGetLastError();
+}
 
 hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,
                                 const double *q, const double *l, const double *u,

@@ -286,6 +286,29 @@ class Engine:
         self._chk(rc, "qpn_solve_nodes_into")
         return dict(z=z, status=status, resid=resid, pivots=pivots, active=active)
 
+    def order_nodes_by_pivots(self, pivots):
+        """Schedule hint for later solve_nodes calls over the SAME nodes: longest solves first, from the
+        pivot counts of an earlier sweep (device or host int32 array).  Results do not depend on it."""
+        dev = self._mode(pivots)
+        self._bind_stream(dev)
+        if not dev:
+            pivots = self._host(pivots, np.int32)
+        rc = self.lib.qpn_order_nodes_by_pivots(self.ctx, _ptr(pivots), int(pivots.shape[0]),
+                                                MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_order_nodes_by_pivots")
+
+    def set_node_order(self, order=None):
+        """Install a caller-made permutation of the nodes as the schedule (None clears the hint)."""
+        if order is None:
+            self._chk(self.lib.qpn_set_node_order(self.ctx, None, 0, MEM_HOST), "qpn_set_node_order")
+            return
+        dev = self._mode(order)
+        self._bind_stream(dev)
+        if not dev:
+            order = self._host(order, np.int32)
+        rc = self.lib.qpn_set_node_order(self.ctx, _ptr(order), int(order.shape[0]), MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_set_node_order")
+
     # -- (A8) ------------------------------------------------------------------------------
     def verify_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, xd, w, tol=1e-4):
         """Batched verify_solution (src/qp_processing.jl:57-149) -> (solution, lambda, path)."""

@@ -123,3 +123,64 @@ def test_scale_and_permutation_covariance(engine, full):
     assert np.max(np.abs(z[:, :N_] - res["z"][sub, :N_])) <= 1e-9
     assert np.max(np.abs(z[:, N_:] - res["z"][sub, N_:][:, perm])) <= 1e-9
     assert np.array_equal(r["active"].cpu().numpy()[:, N_:], res["active"][sub, N_:][:, perm])
+
+
+def test_schedule_hint_changes_nothing_but_the_order(engine, full):
+    """qpn_order_nodes_by_pivots / qpn_set_node_order: results are bit-identical under any permutation of the
+    wavefront -> node map; the device-built order is a permutation sorted by descending pivot count; the hint is
+    ignored for another batch size and can be cleared."""
+    import torch
+    _, dev, res, _ = full
+    try:
+        piv = torch.tensor(res["pivots"], dtype=torch.int32, device="cuda:0")
+        engine.order_nodes_by_pivots(piv)
+        r = engine.solve_nodes(*dev)
+        torch.cuda.synchronize()
+        for k in ("z", "status", "active", "pivots", "resid"):
+            assert np.array_equal(r[k].cpu().numpy(), res[k]), k
+        # a random permutation, given from the host
+        perm = np.random.default_rng(4).permutation(NODES).astype(np.int32)
+        engine.set_node_order(perm)
+        r = engine.solve_nodes(*dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["z"].cpu().numpy(), res["z"]) and np.array_equal(r["active"].cpu().numpy(), res["active"])
+        # other batch size: hint ignored
+        part = [a[:777] if a.dim() > 1 or a.shape[0] == NODES else a for a in dev[:-1]] + [dev[-1]]
+        r = engine.solve_nodes(*part)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["z"].cpu().numpy(), res["z"][:777])
+        # an order with bad entries leaves exactly those slots unsolved (status untouched), nothing faults
+        bad = perm.copy(); bad[:5] = [-1, NODES, NODES + 7, 2**30, -2**31]
+        engine.set_node_order(bad)
+        st = torch.full((NODES,), 77, dtype=torch.int32, device="cuda:0")
+        out = dict(z=torch.zeros((NODES, N_ + M_), dtype=torch.float64, device="cuda:0"), status=st,
+                   resid=torch.zeros(NODES, dtype=torch.float64, device="cuda:0"),
+                   pivots=torch.zeros(NODES, dtype=torch.int32, device="cuda:0"),
+                   active=torch.zeros((NODES, N_ + M_), dtype=torch.uint8, device="cuda:0"))
+        r = engine.solve_nodes(*dev, out=out)
+        torch.cuda.synchronize()
+        stn = r["status"].cpu().numpy()
+        assert set(np.nonzero(stn == 77)[0]) == set(int(v) for v in perm[:5]) and np.all(stn[stn != 77] == 1)
+    finally:
+        engine.set_node_order(None)
+    r = engine.solve_nodes(*dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["z"].cpu().numpy(), res["z"])
+
+
+def test_order_by_pivots_is_a_sorted_permutation(engine):
+    """The counting-sort kernel through a host round trip: install from host pivots, read back by solving a
+    batch whose status slots reveal the order is a permutation (every node solved exactly once)."""
+    import torch
+    from qpn_amd.engine import colmajor
+    cnt, n, m = 3000, 8, 12
+    Q, R, qd, A, B, l, u = P.synth_nodes(900, cnt, n, m, 2)
+    w = P.shared_params(2)
+    args = (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+    ref = engine.solve_nodes(*args)
+    try:
+        engine.order_nodes_by_pivots(ref["pivots"])            # host int32 array
+        r = engine.solve_nodes(*args)
+        assert np.array_equal(r["z"], ref["z"]) and np.all(r["status"] == 1)
+    finally:
+        engine.set_node_order(None)
