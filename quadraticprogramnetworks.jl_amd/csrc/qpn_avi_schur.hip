@@ -588,6 +588,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
                 else { if (rsel < 6) { if (rsel < 5) M_XROW(1, 0) else M_XROW(1, 1) } else { if (rsel < 7) M_XROW(1, 2) else M_XROW(1, 3) } }
 #undef M_XROW
             }
+            // the row's extra-column entry rides along as "column 32", and the entry of the pivot column itself is
+            // replaced by -1 so that row * inv carries -inv there (what the exchange needs) without any select
+            if (l == r) svrow[XC] = tcol;
+            if (l == 0) svrow[c] = -1.0;
             double step = readlane_f64(dd, r);
             if (step < 0.0) step = 0.0;
             const double leave_val = readlane_f64(cndlo ? lo : hi, r);
@@ -595,22 +599,20 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchA
             inv = sneg ? -rcr : rcr;
             const double delta = sneg ? -step : step;
             const int vl = readlane_i32(rowvar, r);
-            const double vxr = readlane_f64(tcol, r);
             const double enter_val = readlane_f64(nbval, c) + delta;
             wave_sync();
             {
-                // extra column and values (lane l <-> row l)
-                const double ninv = -inv;
-                const double vx = (c == XC) ? ninv : vxr * inv;
-                double xbn = fma(delta, cm, xb);
-                double tcn = (c == XC) ? cm * inv : fma(-cm, vx, tcol);
-                if (l == r) { xbn = enter_val; tcn = (c == XC) ? inv : -vx; }
-                xb = xbn; tcol = tcn;
-                double pa = svrow[lc], pb = svrow[16 + lc];
-                asm volatile("" : "+v"(pa), "+v"(pb));
+                double pa = svrow[lc], pb = svrow[16 + lc], px = svrow[XC];
+                asm volatile("" : "+v"(pa), "+v"(pb), "+v"(px));
                 v0 = pa * inv; v1 = pb * inv;
-                if (lc == c) v0 = ninv;
-                if (16 + lc == c) v1 = ninv;
+                // extra column and values (lane l <-> row l): the same exchange formulas, the pivot column's own
+                // entries start from 0 when it is the extra column
+                const double vx = px * inv;
+                const double tc0 = (c == XC) ? 0.0 : tcol;
+                double xbn = fma(delta, cm, xb);
+                double tcn = fma(-cm, vx, tc0);
+                if (l == r) { xbn = enter_val; tcn = -vx; }
+                xb = xbn; tcol = tcn;
                 mcol = __ballot(lc == (c & 15)); mrow = __ballot(lq == rq);
                 cx = c;
             }
