@@ -4,7 +4,7 @@
 set -euo pipefail
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/prof_r01"
 mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- $BENCH > "$O/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- $BENCH > "$O/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- $BENCH > "$O/pmc_write.log" 2>&1
