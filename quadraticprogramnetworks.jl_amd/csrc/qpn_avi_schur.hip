@@ -901,7 +901,12 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
 {
     if (a.batch <= 0) return hipSuccess;
     SchurDebug d{nullptr, nullptr, nullptr, nullptr};
+#ifdef QPN_DIAG
+    // diagnostic builds only: extra dynamic LDS per block lowers the occupancy (occupancy-sensitivity experiments)
     static const unsigned pad = [] { const char *e = getenv("QPN_DEBUG_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+#else
+    const unsigned pad = 0;
+#endif
     hipLaunchKernelGGL(avi_solve_schur<true>, dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
     return hipGetLastError();
 }
