@@ -85,7 +85,7 @@ __device__ __forceinline__ double rcp64(double x)
 }
 
 template <bool NODES>
-__global__ __launch_bounds__(WAVE, NODES ? 4 : 2) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
+__global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
     const int N = NODES ? a.nd.n + a.nd.m : a.N;
     const int l = threadIdx.x;
