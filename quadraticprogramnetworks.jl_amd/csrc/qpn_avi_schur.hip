@@ -475,13 +475,13 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     double nbval = 0.0, tcol = 0.0;
     wave_sync();                      // Stage A and the c sweep are done with sbuf
 
-    // the dictionary as 16 named doubles: element g of tile (Ib, Jb) = row 16 Ib + 4 g + lq, column 16 Jb + lc
-#define SD(Ib, Jb, g) s##Ib##Jb##_##g
-#define M_SDECL(Ib, Jb)                                                                             \
-    double SD(Ib, Jb, 0) = SB(Ib, Jb)[0], SD(Ib, Jb, 1) = SB(Ib, Jb)[1], SD(Ib, Jb, 2) = SB(Ib, Jb)[2],     \
-           SD(Ib, Jb, 3) = SB(Ib, Jb)[3];
-    M_SDECL(0, 0) M_SDECL(0, 1) M_SDECL(1, 0) M_SDECL(1, 1)
-#undef M_SDECL
+    // the dictionary as two 8-vectors per lane: element 4 Ib + g of SJ<Jb> = row 16 Ib + 4 g + lq, column
+    // 16 Jb + lc.  Static element accesses are plain registers; the pivot row is read with a wave-uniform
+    // DYNAMIC index (s_set_gpr_idx_on + v_mov: no branch tree, no scratch).
+    typedef double d8 __attribute__((ext_vector_type(8)));
+    d8 SJ0 = {SB(0, 0)[0], SB(0, 0)[1], SB(0, 0)[2], SB(0, 0)[3], SB(1, 0)[0], SB(1, 0)[1], SB(1, 0)[2], SB(1, 0)[3]};
+    d8 SJ1 = {SB(0, 1)[0], SB(0, 1)[1], SB(0, 1)[2], SB(0, 1)[3], SB(1, 1)[0], SB(1, 1)[1], SB(1, 1)[2], SB(1, 1)[3]};
+#define SD(Ib, Jb, g) SJ##Jb[4 * (Ib) + (g)]
     auto col_of = [&](int v) -> int { return wave_first(colvar == v); };     // ids are >= 0, idle lanes hold -1
     int pivots = n;                       // the crash brought n free variables in (Stage A)
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
@@ -584,11 +584,9 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             // ---- pivot row r -> svrow (raw): the 16 lanes that hold it pick the register under a uniform tree
             const int rq = r & 3;
             rsel = ((r >> 4) << 2) | ((r >> 2) & 3);      // leaf = Ib*4 + g
-            if (lq == rq) {
-#define M_XROW(Ib, g) { svrow[lc] = SD(Ib, 0, g); svrow[16 + lc] = SD(Ib, 1, g); }
-                if (rsel < 4) { if (rsel < 2) { if (rsel < 1) M_XROW(0, 0) else M_XROW(0, 1) } else { if (rsel < 3) M_XROW(0, 2) else M_XROW(0, 3) } }
-                else { if (rsel < 6) { if (rsel < 5) M_XROW(1, 0) else M_XROW(1, 1) } else { if (rsel < 7) M_XROW(1, 2) else M_XROW(1, 3) } }
-#undef M_XROW
+            {
+                const double pr0 = SJ0[rsel], pr1 = SJ1[rsel];          // uniform dynamic register index
+                if (lq == rq) { svrow[lc] = pr0; svrow[16 + lc] = pr1; }
             }
             // the row's extra-column entry rides along as "column 32", and the entry of the pivot column itself is
             // replaced by -1 so that row * inv carries -inv there (what the exchange needs) without any select
