@@ -49,6 +49,41 @@ def verify_solution(qp, pid, constraints: List[Poly], dec_inds, x, check_convexi
                 e=None if ok else msgs.get(path, ""), path=path)
 
 
+_VERIFY_MSGS = {0: "Current point is infeasible when using tolerance {tol}.", 1: "Current point is suboptimal",
+                4: "Current point is suboptimal (via QP).", 5: "Solving for duals failed."}
+
+
+def verify_solutions_batched(qp, pid, constraint_lists: List[List[Poly]], dec_inds, x, tol=1e-4, engine=None):
+    """verify_solution for MANY constraint stacks of the same node in ONE qpn_verify_nodes call -- the
+    sub-piece combinations of src/qp_processing.jl:162-205: the stacks
+    share Q, q, x and differ only in the appended child pieces.  Ragged stacks are padded with inert rows
+    (0' x in [-inf, inf]: never infeasible, never active, so they enter neither the least-squares system
+    of :114-115 nor the fallback of :129-137).  Returns one verify_solution dict per stack, in order."""
+    recs = [node_record(qp, cons, dec_inds, x) for cons in constraint_lists]
+    if not recs:
+        return []
+    nb = len(recs)
+    n = recs[0]["Qd"].shape[0]
+    p = recs[0]["R"].shape[1]
+    ms = [len(r["l"]) for r in recs]
+    mm = max(max(ms), 1)
+    Qc = np.repeat(colmajor(recs[0]["Qd"])[None], nb, axis=0)
+    Rc = np.repeat(colmajor(recs[0]["R"])[None], nb, axis=0)
+    qd = np.repeat(recs[0]["qd"][None], nb, axis=0)
+    xd = np.repeat(recs[0]["xd"][None], nb, axis=0)
+    Ad = np.zeros((nb, mm, n)); Bp = np.zeros((nb, mm, p))
+    lo = np.full((nb, mm), -INF); hi = np.full((nb, mm), INF)
+    for i, r in enumerate(recs):
+        Ad[i, :ms[i]] = r["Ad"]; Bp[i, :ms[i]] = r["B"]; lo[i, :ms[i]] = r["l"]; hi[i, :ms[i]] = r["u"]
+    sol, lam, path = _eng(engine).verify_nodes(Qc, Rc, qd, colmajor(Ad), colmajor(Bp), lo, hi, xd, recs[0]["w"], tol=tol)
+    out = []
+    for i in range(nb):
+        pth = int(path[i]); ok = bool(sol[i])
+        out.append(dict(solution=ok, lam=(np.asarray(lam[i])[:ms[i]].copy() if pth in (1, 2, 3, 4) else None),
+                        e=None if ok else _VERIFY_MSGS.get(pth, "").format(tol=tol), path=pth))
+    return out
+
+
 def solve_qp(Q, q, A, l, u, solver="PATH", engine=None):
     """src/qp_processing.jl:12-33 (PATH branch): min 1/2 x'Qx + q'x  s.t. l <= Ax <= u, as the box-MCP
     [Q -A' 0; A 0 -I; 0 I 0] of :16-21 -- sent to the engine in its reduced GAVI-row form."""
@@ -80,9 +115,12 @@ def process_qp(qpn, pid: int, x, S: Dict[int, list], engine=None, exploration_ve
         cards = [range(len(S[j])) for j in children]
         if any(len(c) < 1 for c in cards):
             raise RuntimeError("Solution graphs were not properly populated.")
-        for combo in itertools.product(*cards):
-            cons = base + [S[j][ji] for j, ji in zip(children, combo)]
-            ret = verify_solution(qp, pid, cons, dec_inds, x, engine=engine)
+        # every combination is verified (the reference maps over all of them, :171-205, and then reports the
+        # first failure in product order, :206-216): ONE batched call instead of one call per combination
+        combos = list(itertools.product(*cards))
+        rets = verify_solutions_batched(qp, pid, [base + [S[j][ji] for j, ji in zip(children, combo)] for combo in combos],
+                                        dec_inds, x, engine=engine)
+        for combo, ret in zip(combos, rets):
             if not ret["solution"]:
                 return dict(solution=False, e=ret["e"], failed=False,
                             subpiece_assignments={j: ji for j, ji in zip(children, combo)})

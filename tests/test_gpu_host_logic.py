@@ -62,3 +62,32 @@ def test_four_player_1000_draws_batched(engine, oracle):
     assert np.max(np.abs(rg["z"] - rc["z"])) <= 1e-9 and np.max(rg["resid"]) <= 1e-8
     deg, _ = engine.check_avi_batch(colmajor(M), q, L, U, rg["z"], kind=kind)
     assert np.all(deg == 0)
+
+
+def test_batched_subpiece_verification_on_gpu(engine):
+    """Row F2 on the HIP path: one qpn_verify_nodes call for all sub-piece combinations == one call per
+    combination == the oracle-backed run (verdicts, paths, duals)."""
+    from oracle_engine import OracleEngine
+    from qpn_amd import algorithm, examples
+    from qpn_amd.programs import Poly
+    from qpn_amd.qp_processing import verify_solution, verify_solutions_batched
+    net = examples.setup("synthetic_pairs", pairs=3, n=5, m=7)
+    ret = algorithm.solve(net, engine=engine)
+    assert ret["solved"]
+    x = ret["x_opt"]
+    rng = np.random.default_rng(7)
+    for pid in sorted(net.network_depth_map[1]):
+        qp = net.qps[pid]
+        child = next(iter(net.network_edges[pid]))
+        base = [net.constraints[c].poly for c in qp.constraint_indices]
+        pieces = list(ret["Sol"][child])
+        a = rng.standard_normal((3, len(x)))
+        stacks = [base + [p] for p in pieces] + [base, base + [Poly(a, a @ x + 1.0, a @ x + 2.0)],
+                                                 base + [Poly(a, a @ x - 1.0, a @ x + 1.0)]]
+        many = verify_solutions_batched(qp, pid, stacks, net.decision_inds(pid), x, engine=engine)
+        one = [verify_solution(qp, pid, cons, net.decision_inds(pid), x, engine=engine) for cons in stacks]
+        ref = verify_solutions_batched(qp, pid, stacks, net.decision_inds(pid), x, engine=OracleEngine())
+        for rb, r1, rr in zip(many, one, ref):
+            assert rb["solution"] == r1["solution"] == rr["solution"] and rb["path"] == r1["path"] == rr["path"]
+            if rr["lam"] is not None:
+                assert np.allclose(rb["lam"], r1["lam"], atol=1e-9) and np.allclose(rb["lam"], rr["lam"], atol=1e-7)

@@ -145,3 +145,40 @@ def test_solve_qp_path_branch(eng):
     assert np.max(np.abs(x - ref.x)) < 1e-6
     with pytest.raises(ValueError):
         solve_qp(Q, q, A, l, u, solver="OSQP", engine=eng)
+
+
+def test_batched_subpiece_verification_equals_one_by_one(eng):
+    """SURVEY section 8(f) row F2 (src/qp_processing.jl:162-205): all sub-piece combinations of a node go
+    through ONE batched verify; ragged stacks are padded with inert rows.  Same verdicts, paths and duals
+    as one verify_solution per combination, and process_qp reports the first failing combination."""
+    import qpn_amd  # noqa: F401
+    from qpn_amd import algorithm, examples
+    from qpn_amd.programs import Poly
+    from qpn_amd.qp_processing import process_qp, verify_solution, verify_solutions_batched
+    net = examples.setup("synthetic_pairs", pairs=2, n=4, m=5)
+    ret = algorithm.solve(net, engine=eng)
+    assert ret["solved"]
+    x = ret["x_opt"]
+    rng = np.random.default_rng(2)
+    for pid in sorted(net.network_depth_map[1]):
+        qp = net.qps[pid]
+        child = next(iter(net.network_edges[pid]))
+        base = [net.constraints[c].poly for c in qp.constraint_indices]
+        pieces = list(ret["Sol"][child])
+        # extra stacks of other lengths: an empty appendix, a doubled piece, a piece the point violates
+        a = rng.standard_normal((2, len(x)))
+        bad = Poly(a, a @ x + 1.0, a @ x + 2.0)
+        stacks = [base + [p] for p in pieces] + [base, base + [pieces[0], pieces[0]], base + [bad]]
+        one = [verify_solution(qp, pid, cons, net.decision_inds(pid), x, engine=eng) for cons in stacks]
+        many = verify_solutions_batched(qp, pid, stacks, net.decision_inds(pid), x, engine=eng)
+        assert len(many) == len(one)
+        for r1, rb in zip(one, many):
+            assert r1["solution"] == rb["solution"] and r1["path"] == rb["path"] and r1["e"] == rb["e"]
+            if r1["lam"] is not None:
+                assert np.allclose(r1["lam"], rb["lam"], atol=1e-9)
+        assert not many[-1]["solution"] and many[-1]["path"] == 0         # the violated stack: infeasible
+        assert all(r["solution"] for r in many[:len(pieces)])
+        # process_qp on a solution-graph dict whose second piece is violated: first failure in product order
+        S = {child: [pieces[0], bad] + pieces[1:]}
+        out = process_qp(net, pid, x, S, engine=eng)
+        assert out["solution"] is False and out["subpiece_assignments"] == {child: 1}
