@@ -20,7 +20,8 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int LDV = 65;   // odd leading dimension: column and row sweeps are both conflict-light
+// Leading dimension of the two LDS matrices (odd: column and row sweeps are both conflict-light).  Two size
+// classes: n, m <= 32 -> 33 (17 KB of LDS per node, 9 nodes resident per CU); n, m <= 64 -> 65 (67 KB, 2 per CU).
 
 struct VerifyArgs {
     int32_t batch, n, m, p;
@@ -33,13 +34,14 @@ struct VerifyArgs {
     double *sG, *sq, *slb, *sub, *sz;
 };
 
+template <int LDV>
 __global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
 {
     const int n = a.n, m = a.m, p = a.p;
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    __shared__ double sA[LDV * 64];   // Ad, column-major, ld = LDV
-    __shared__ double sGa[LDV * 64];  // Gram block of the active rows, then its Cholesky factor
+    __shared__ double sA[LDV * (LDV - 1)];   // Ad, column-major, ld = LDV
+    __shared__ double sGa[LDV * (LDV - 1)];  // Gram block of the active rows, then its Cholesky factor
     __shared__ double sqt[64];        // q~
     __shared__ double svec[64];       // broadcast vector (xd, factor column, y)
     __shared__ int srow[64];          // active column -> row
@@ -246,14 +248,15 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
     a.Qd = Qd; a.R = R; a.qd = qd; a.Ad = Ad; a.B = B; a.l = l; a.u = u; a.xd = xd; a.w = w;
     a.stride_w = stride_w; a.tol = tol; a.solution = solution; a.lambda = lambda; a.path = path;
     a.sG = sG; a.sq = sq; a.slb = slb; a.sub = sub; a.sz = sz;
-    hipLaunchKernelGGL(verify_stage1, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+    if (n <= 32 && m <= 32) hipLaunchKernelGGL(verify_stage1<33>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+    else hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || m == 0) return e;
     AviBatchArgs s{};
     s.batch = batch; s.N = m; s.M = sG; s.strideM = (int64_t)m * m; s.q = sq; s.l = slb; s.u = sub;
     s.kind = nullptr; s.stride_kind = 0; s.z = sz; s.status = sst; s.resid = sres; s.pivots = nullptr;
     s.active = nullptr; s.check_tol = 1e-6; s.piv_tol = 1e-11; s.feas_tol = 1e-12; s.comp_tol = 1e-2;
-    s.max_pivots = 0; s.only_if = path; s.only_if_value = -1;
+    s.max_pivots = 0; s.only_if = path; s.only_if_value = -1; s.scan = 1;     // compact fallback launch
     e = qpn_launch_avi_solve(s, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(verify_stage2, dim3((unsigned)batch), dim3(WAVE), 0, stream, a, (const int32_t *)sst);
