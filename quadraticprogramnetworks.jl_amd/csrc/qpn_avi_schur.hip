@@ -7,17 +7,18 @@
 //   * only the TOP half [H | C] (32 x 64, padded) is eliminated, as 2 x 4 tiles of 16 x 16 in the C/D
 //     layout of v_mfma_f64_16x16x4_f64 (lane l, reg g  <->  row (l>>4) + 4g, col l&15); an aligned group
 //     of 4 rows IS a B operand, so the pivot rows need no data movement at all;
-//   * per block pivot (8 of them): the 4 pivot columns go through LDS once (-> A operands), the 4 x 4
-//     pivot block is inverted in registers (lane group k computes column k of the inverse, every lane
-//     carries the uniform part), V' = P^-1 V is one MFMA per column tile, and the rank-4 update of a
-//     tile is ONE instruction (1024 multiply-adds);
+//   * per block pivot (8 of them): the 4 pivot columns go through LDS once, the 4 x 4 pivot block P is
+//     LU-factored in registers (uniform, every lane) and each lane solves x L U = u for its own panel row:
+//     U' = U P^-1 is the A operand and the RAW pivot rows are the B operand, so the rank-4 update of a tile
+//     is ONE instruction (1024 multiply-adds) and the pivot rows become P^-1 V by that same instruction
+//     (they carry P - I); no V' = P^-1 V product, which would use 4 of an MFMA's 16 output rows;
 //   * the bottom half is never eliminated: with W = H^-1 C and h = H^-1 g in hand,
 //         S = D - A W   (32 MFMAs, A operands straight from the staged A block)   and   c = b - A h.
 //     This is 25 % fewer flops than eliminating all four quadrants and -- the point -- needs 8 live tiles
 //     instead of 16, so FOUR waves fit a SIMD (<= 128 VGPRs, 10 KB LDS each) instead of two.  The solve is a chain of
 //     dependent LDS / cross-lane / MFMA latencies, and resident waves are what hides them.
-// Stage B (Lemke) then runs on the 32 x 33 dictionary of S in the same tile layout, one MFMA per tile per
-// pivot, and x = -(W lambda + h) is recovered at the end.  Post-check, residual and active-set masks
+// Stage B (Lemke) then runs on the 32 x 33 dictionary of S in the same tile layout -- a rank-1 exchange per
+// pivot, on the VALU (see there) -- and x = -(W lambda + h) is recovered at the end.  Post-check, residual and active-set masks
 // are computed on the ORIGINAL blocks exactly as in qpn_avi_reg.hip.
 //
 // Fused node path (NODES = true, qpn_solve_nodes): M is never materialised.  Qd and Ad are read from HBM
@@ -27,9 +28,9 @@
 //
 // Items that do not have this shape, or whose H block fails the no-pivoting test
 // (|pivot| >= 1e-4 max(1, max|M|) inside a 4 x 4 block), are flagged (status = -1) and solved by the
-// register kernel in a second, gated launch -- results identical to the general path.
-// Arithmetic differs from the scalar crash only by summation order (block elimination) and Newton
-// reciprocals, so primals agree to ~1e-13 and active sets are identical on well-posed items; parity bar:
+// register kernel in ONE compact scan-mode launch -- results identical to the general path.
+// Arithmetic differs from the scalar crash only by summation order (block elimination) and one-step
+// Newton reciprocals (<= 10 ulp), so primals agree to ~1e-13 and active sets are identical on well-posed items; parity bar:
 // DESIGN.md section 2.
 #include "qpn_internal.h"
 #include <cstdlib>
