@@ -13,6 +13,7 @@
 // This is the correctness/coverage path for large items; the MFMA-tiled blocked variant is the
 // planned replacement.
 #include "qpn_internal.h"
+#include <cstdlib>
 
 #define QINF __builtin_huge_val()
 
@@ -81,10 +82,10 @@ __device__ __forceinline__ int block_sum_i(int v, BigShared &S, int tid)
 
 __global__ __launch_bounds__(TPB) void avi_solve_big(AviBatchArgs a, double *ws)
 {
-    const int N = a.N, NC = N + 1;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (a.only_if && a.only_if[b] != a.only_if_value) return;
+    const int N = a.n_items ? a.n_items[b] : a.N, NC = N + 1;     // per-item size (reduced Schur problems)
 
     __shared__ BigShared S;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(TPB) void avi_solve_big(AviBatchArgs a, double *ws)
     int *colvar = sat + N;
     int *elist = colvar + NC + 1;
 
-    double *T = ws + (size_t)b * (size_t)N * NC;       // T[j*N + i]
+    double *T = ws + (size_t)b * (size_t)a.N * (size_t)(a.N + 1);       // T[j*N + i]
     const double *Mg = a.M + (size_t)b * (size_t)a.strideM;
-    const size_t vo = (size_t)b * (size_t)N;
+    const size_t vo = (size_t)b * (size_t)(a.vec_stride ? a.vec_stride : N);
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
     const double ptol = a.piv_tol, slack = 1e-10;
 
@@ -595,12 +596,16 @@ int qpn_avi_big_max_n() { return NMAX; }
 
 size_t qpn_avi_big_workspace_bytes(int batch, int N)
 {
-    return (size_t)batch * (size_t)N * (size_t)(N + 1) * sizeof(double);
+    // dictionary of the general kernel + the views of the blocked-crash path + a kind vector of ones
+    return (size_t)batch * (size_t)N * (size_t)(N + 1) * sizeof(double) + qpn_schur_big_workspace_bytes(batch, N) +
+           (((size_t)N + 255) & ~(size_t)255);
 }
 
-hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hipStream_t stream)
+namespace {
+__global__ void fill_ones_kernel(uint8_t *p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 1; }
+
+hipError_t launch_big_kernel(const AviBatchArgs &a, double *dict, hipStream_t stream)
 {
-    if (a.batch <= 0) return hipSuccess;
     const int N = a.N, NC = N + 1;
     size_t dbl = (size_t)((NC + 1) & ~1) * 2 + 2 * (size_t)N + (size_t)((2 * N + 2) & ~1);
     size_t bytes = dbl * sizeof(double) + sizeof(int) * ((size_t)N + NC + 1 + 8 * (size_t)N + 8);
@@ -612,6 +617,39 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(avi_solve_big, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, workspace);
+    hipLaunchKernelGGL(avi_solve_big, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, dict);
     return hipGetLastError();
+}
+} // namespace
+
+// Large items.  Node-shaped ones (a kind vector is given) first try the blocked MFMA crash of
+// qpn_avi_schur_big.hip: stage A -> Lemke on the m x m Schur problem (this kernel, per-item sizes) -> finish;
+// what it declines (status -1), and everything else, runs on the general kernel.
+hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hipStream_t stream)
+{
+    if (a.batch <= 0) return hipSuccess;
+    const int N = a.N;
+    static const bool no_schur = [] { const char *e = getenv("QPN_AVI_BIG_KERNEL"); return e && e[0] == 'g'; }();   // "general"
+    if (a.kind == nullptr || a.only_if != nullptr || a.n_items != nullptr || no_schur) return launch_big_kernel(a, workspace, stream);
+    double *dict = workspace;
+    void *sb = workspace + (size_t)a.batch * (size_t)N * (size_t)(N + 1);
+    uint8_t *ones = reinterpret_cast<uint8_t *>(static_cast<char *>(sb) + qpn_schur_big_workspace_bytes(a.batch, N));
+    SchurBigWs w{};
+    hipError_t e = qpn_launch_schur_big_stage_a(a, sb, &w, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, ones, N);
+    AviBatchArgs r{};
+    r.batch = a.batch; r.N = N; r.n_items = w.nred; r.vec_stride = N;
+    r.M = w.S; r.strideM = w.s_stride; r.q = w.c; r.l = w.l2; r.u = w.u2; r.kind = ones; r.stride_kind = 0;
+    r.z = w.lam; r.status = w.st2; r.pivots = w.piv2; r.resid = nullptr; r.active = nullptr;
+    r.check_tol = a.check_tol; r.piv_tol = a.piv_tol; r.feas_tol = a.feas_tol; r.comp_tol = a.comp_tol;
+    r.max_pivots = a.max_pivots; r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
+    r.only_if = a.status; r.only_if_value = -2;
+    e = launch_big_kernel(r, dict, stream);
+    if (e != hipSuccess) return e;
+    e = qpn_launch_schur_big_finish(a, w, stream);
+    if (e != hipSuccess) return e;
+    AviBatchArgs g = a;
+    g.only_if = a.status; g.only_if_value = -1;
+    return launch_big_kernel(g, dict, stream);
 }

@@ -1,0 +1,377 @@
+// qpn_avi_schur_big.hip -- blocked MFMA crash for LARGE node-shaped items (64 < N <= 1024), gfx950.
+//
+// BASELINE config 5 (n = m = 256, N = 512) and any item of shape
+//     kinds = [STD free x n | GAVI x m],  16 <= ... n <= 512,  M = [[H, C],[A, D]],  q = [g; b].
+// The general large-item kernel (qpn_avi_big.hip) keeps the N x (N+1) dictionary in HBM and streams ALL of
+// it through the CU once per pivot: n crash pivots + the Lemke pivots, ~2 N^2 * 8 B each.  Here the crash is
+// the same construction as in qpn_avi_schur.hip, at workgroup scale:
+//   stage_a  (one 256-thread workgroup = 4 wavefronts per item)
+//     * only the top half [H | C | g] is eliminated, row-major in an HBM workspace, as 16 x 16 tiles in the
+//       C/D layout of v_mfma_f64_16x16x4_f64;
+//     * rank-16 block pivots: the 16 pivot columns (a panel, n x 16) go to registers/LDS once, the 16 x 16
+//       pivot block is LU-factored in LDS (no pivoting; every pivot must pass the |u_ss| >= 1e-4 max(1,max|M|)
+//       test, else the item is declined), every thread solves x L U = u for its panel row: U' = U P^-1;
+//       then T -= U' V with the RAW pivot rows V as B operands: 4 MFMAs per tile and pass, the whole top half
+//       is read and written 16 times in all (n / 16 passes) instead of n times;
+//     * S = D - A W and c = b - A h as a tiled GEMM on the matrix cores (A operands straight from M).
+//   the Lemke phase then runs on the m x m Schur problem (all GAVI rows) with the general large-item kernel:
+//     no crash pivots, a quarter of the dictionary;
+//   finish   x = -(W lambda + h), post-check / residual / active sets on the ORIGINAL blocks.
+// Declined items (other shape, equality GAVI rows, n > 512, a pivot below the threshold) keep status -1 and
+// are solved by the general kernel in a gated launch.  Results: same bar as the small MFMA kernel
+// (summation order differs from the scalar crash; primals to ~1e-12, masks and pivot counts identical).
+#include "qpn_internal.h"
+
+#define QINF __builtin_huge_val()
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int PW = 16;                  // panel width (block pivot size)
+constexpr int NMAXA = 512;              // rows of the top half held in LDS as U' (512 x 17 doubles = 68 KB)
+constexpr int LDU = PW + 1;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+
+__device__ __forceinline__ int pad16(int v) { return (v + 15) & ~15; }
+
+struct SbShared {
+    double red[TPB];
+    int redi[TPB];
+    double P[PW * LDU];      // pivot block, then its LU factors (unit lower L below, U on and above the diagonal)
+    double rd[PW];           // reciprocals of the pivots
+    int flag;
+};
+
+__device__ __forceinline__ double sb_block_max(double v, SbShared &S, int tid)
+{
+    S.red[tid] = v;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) { const double o = S.red[tid + s]; if (o > S.red[tid]) S.red[tid] = o; }
+        __syncthreads();
+    }
+    const double r = S.red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int sb_block_min_i(int v, SbShared &S, int tid)
+{
+    S.redi[tid] = v;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) { const int o = S.redi[tid + s]; if (o < S.redi[tid]) S.redi[tid] = o; }
+        __syncthreads();
+    }
+    const int r = S.redi[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int sb_block_sum_i(int v, SbShared &S, int tid)
+{
+    S.redi[tid] = v;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) S.redi[tid] += S.redi[tid + s];
+        __syncthreads();
+    }
+    const int r = S.redi[0];
+    __syncthreads();
+    return r;
+}
+
+// ---- stage A ---------------------------------------------------------------------------------------------
+// Outputs per item (workspace): Tt (top half after elimination: W = columns n_pad.., h = column n_pad+m_pad),
+// S (m x m, column-major), c (m), reduced bounds / start, nsplit = n.  status: -2 accepted, -1 declined.
+__global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBigWs w)
+{
+    const int N = a.N;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
+    __shared__ SbShared S;
+    extern __shared__ __attribute__((aligned(16))) double sUp[];       // U' = U P^-1, [row][LDU]
+
+    const double *Mg = a.M + (size_t)b * (size_t)a.strideM;
+    const size_t vo = (size_t)b * (size_t)N;
+
+    // ---- shape: leading free STD rows, then GAVI rows with l < u ---------------------------------------
+    int first_nonfree = N;
+    bool bad_tail = false;
+    for (int k = tid; k < N; k += TPB) {
+        const double lk = a.l[vo + k], uk = a.u[vo + k];
+        const int gk = a.kind ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + k] : 0;
+        const bool isfree = !gk && lk == -QINF && uk == QINF;
+        if (!isfree && k < first_nonfree) first_nonfree = k;
+    }
+    const int n = sb_block_min_i(first_nonfree, S, tid);
+    const int m = N - n;
+    for (int k = tid; k < N; k += TPB) {
+        if (k < n) continue;
+        const double lk = a.l[vo + k], uk = a.u[vo + k];
+        const int gk = a.kind ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + k] : 0;
+        if (!gk || lk == uk) bad_tail = true;
+    }
+    const int nbad = sb_block_sum_i(bad_tail ? 1 : 0, S, tid);
+    if (nbad > 0 || n < 1 || m < 1 || n > NMAXA) { if (tid == 0) a.status[b] = -1; return; }
+
+    const int n_pad = pad16(n), m_pad = pad16(m);
+    const int ldc = n_pad + m_pad + 16;                 // H part | C part | one tile whose column 0 is g
+    const int xcol = n_pad + m_pad;
+    double *Tt = w.Tt + (size_t)b * (size_t)w.tt_stride;
+
+    // ---- fill the top half (row-major) and take max |M| over the WHOLE item ------------------------------
+    for (int i = tid; i < n_pad; i += TPB)
+        for (int j = 0; j < ldc; ++j) Tt[(size_t)i * ldc + j] = (i >= n && j == i) ? 1.0 : 0.0;
+    __syncthreads();
+    double mabs = 0.0;
+    for (int j = 0; j < N; ++j) {
+        const int jj = j < n ? j : n_pad + (j - n);
+        for (int i = tid; i < N; i += TPB) {
+            const double v = Mg[(size_t)j * N + i];            // coalesced over i
+            mabs = fmax(mabs, fabs(v));
+            if (i < n) Tt[(size_t)i * ldc + jj] = v;
+        }
+    }
+    for (int i = tid; i < n; i += TPB) Tt[(size_t)i * ldc + xcol] = a.q[vo + i];
+    const double mscale = sb_block_max(mabs, S, tid);
+    const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- rank-16 block pivots ---------------------------------------------------------------------------
+    const int nrt = n_pad / 16, nct = ldc / 16;
+    for (int kb = 0; kb < nrt; ++kb) {
+        const int p0 = 16 * kb;
+        // panel rows into registers (thread t <-> rows t, t + 256), pivot block into LDS
+        double ur[2][PW];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = tid + TPB * h;
+            if (t < n_pad) {
+#pragma unroll
+                for (int k = 0; k < PW; ++k) ur[h][k] = Tt[(size_t)t * ldc + p0 + k];
+                if (t >= p0 && t < p0 + PW) {
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) S.P[(t - p0) * LDU + k] = ur[h][k];
+                    ur[h][t - p0] -= 1.0;                       // pivot rows carry P - I
+                }
+            }
+        }
+        if (tid == 0) S.flag = 1;
+        __syncthreads();
+        // LU of the pivot block by wave 0 (lane i <-> row i), no pivoting, threshold on every pivot
+        if (wave == 0) {
+            for (int s = 0; s < PW; ++s) {
+                const double piv = S.P[s * LDU + s];
+                if (!(fabs(piv) >= diag_thr)) { if (lane == 0) S.flag = 0; break; }
+                const double r = 1.0 / piv;
+                if (lane == 0) S.rd[s] = r;
+                if (lane > s && lane < PW) {
+                    const double f = S.P[lane * LDU + s] * r;
+                    S.P[lane * LDU + s] = f;
+                    for (int j = s + 1; j < PW; ++j) S.P[lane * LDU + j] = fma(-f, S.P[s * LDU + j], S.P[lane * LDU + j]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __syncthreads();
+        if (S.flag == 0) { if (tid == 0) a.status[b] = -1; return; }
+        // U' = U P^-1: every thread solves x L U = u for its panel rows
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = tid + TPB * h;
+            if (t < n_pad) {
+                double y[PW];
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    double s = ur[h][j];
+#pragma unroll
+                    for (int i = 0; i < j; ++i) s = fma(-y[i], S.P[i * LDU + j], s);
+                    y[j] = s * S.rd[j];
+                }
+#pragma unroll
+                for (int j = PW - 1; j >= 0; --j) {
+                    double s = y[j];
+#pragma unroll
+                    for (int i = j + 1; i < PW; ++i) s = fma(-y[i], S.P[i * LDU + j], s);
+                    y[j] = s;
+                }
+#pragma unroll
+                for (int k = 0; k < PW; ++k) sUp[t * LDU + k] = y[k];
+            }
+        }
+        __syncthreads();
+        // T -= U' V on the live column tiles (those right of the panel), 4 k-steps per tile
+        for (int J = kb + 1 + wave; J < nct; J += 4) {
+            double vb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) vb[s] = Tt[(size_t)(p0 + 4 * s + lq) * ldc + 16 * J + lc];
+            for (int I = 0; I < nrt; ++I) {
+                d4 c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) c[g] = Tt[(size_t)(16 * I + 4 * g + lq) * ldc + 16 * J + lc];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) c = MFMA(-sUp[(16 * I + lc) * LDU + 4 * s + lq], vb[s], c);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I + 4 * g + lq) * ldc + 16 * J + lc] = c[g];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // ---- S = D - A W, c = b - A h: tiled GEMM, A operands from the original M ---------------------------
+    double *Sg = w.S + (size_t)b * (size_t)w.s_stride;
+    double *cg = w.c + vo;
+    const int mt = m_pad / 16;
+    for (int t = wave; t < mt * (mt + 1); t += 4) {
+        const int I = t / (mt + 1), J = t % (mt + 1);
+        d4 c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+            double v = 0.0;
+            if (J < mt) { if (ri < m && cj < m) v = Mg[(size_t)(n + cj) * N + n + ri]; }
+            else if (lc == 0 && ri < m) v = a.q[vo + n + ri];
+            c[g] = v;
+        }
+        const int ai = 16 * I + lc;
+        for (int kk = 0; kk < n_pad / 4; ++kk) {
+            const int aj = 4 * kk + lq;
+            const double av = (ai < m && aj < n) ? -Mg[(size_t)aj * N + n + ai] : 0.0;
+            const double bv = Tt[(size_t)aj * ldc + n_pad + 16 * J + lc];
+            c = MFMA(av, bv, c);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+            if (J < mt) { if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = c[g]; }
+            else if (lc == 0 && ri < m) cg[ri] = c[g];
+        }
+    }
+    // reduced problem data: bounds of the GAVI rows, cold start
+    for (int k = tid; k < m; k += TPB) {
+        w.l2[vo + k] = a.l[vo + n + k]; w.u2[vo + k] = a.u[vo + n + k]; w.lam[vo + k] = 0.0;
+    }
+    if (tid == 0) { w.nsplit[b] = n; w.nred[b] = m; a.status[b] = -2; }
+}
+
+// ---- finish: x = -(W lambda + h), post-check on the ORIGINAL blocks --------------------------------------
+__global__ __launch_bounds__(TPB) void schur_big_finish(AviBatchArgs a, SchurBigWs w)
+{
+    const int N = a.N;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (a.status[b] != -2) return;
+    __shared__ SbShared S;
+    extern __shared__ __attribute__((aligned(16))) double zs[];       // z, N doubles
+    const int n = w.nsplit[b], m = N - n;
+    const int n_pad = pad16(n), m_pad = pad16(m);
+    const int ldc = n_pad + m_pad + 16, xcol = n_pad + m_pad;
+    const double *Tt = w.Tt + (size_t)b * (size_t)w.tt_stride;
+    const double *Mg = a.M + (size_t)b * (size_t)a.strideM;
+    const size_t vo = (size_t)b * (size_t)N;
+    for (int k = tid; k < m; k += TPB) zs[n + k] = w.lam[vo + k];
+    __syncthreads();
+    for (int i = tid; i < n; i += TPB) {
+        double s = Tt[(size_t)i * ldc + xcol];
+        const double *wr = Tt + (size_t)i * ldc + n_pad;
+        for (int k = 0; k < m; ++k) s = fma(wr[k], zs[n + k], s);
+        zs[i] = -s;
+    }
+    __syncthreads();
+    int bad = 0;
+    double nres = 0.0;
+    for (int k = tid; k < N; k += TPB) {
+        double rk = a.q[vo + k];
+        for (int j = 0; j < N; ++j) {
+            const double zj = zs[j];
+            if (zj != 0.0) rk = fma(Mg[(size_t)j * N + k], zj, rk);
+        }
+        const int gk = k >= n;
+        const double zk = zs[k], lk = a.l[vo + k], uk = a.u[vo + k];
+        const double p = gk ? rk : zk, d = gk ? zk : rk;
+        const double tol = a.check_tol;
+        if (d > tol && fabs(p - lk) > tol) bad++;
+        if (d < -tol && fabs(p - uk) > tol) bad++;
+        if (p - lk < -tol) bad++;
+        if (p - uk > tol) bad++;
+        if (isnan(p) || isnan(d)) bad++;
+        double tt = p - d;
+        if (tt < lk) tt = lk;
+        if (tt > uk) tt = uk;
+        double e = fabs(p - tt);
+        if (isnan(e)) e = QINF;
+        if (e > nres) nres = e;
+        unsigned mask = 0;
+        const double ct = a.comp_tol;
+        auto approx = [&](double x, double y) { return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= ct); };
+        if (!approx(lk, uk)) {
+            if (approx(p, lk) && d >= -ct) mask |= 1u;
+            if (lk - ct <= p && p <= uk + ct && fabs(d) <= ct) mask |= 2u;
+            if (approx(p, uk) && d <= ct) mask |= 4u;
+        } else mask = 8u;
+        if (gk) mask <<= 4;
+        a.z[vo + k] = zk;
+        if (a.active) a.active[vo + k] = (uint8_t)mask;
+    }
+    const int badt = sb_block_sum_i(bad, S, tid);
+    const double nrest = sb_block_max(nres, S, tid);
+    if (tid == 0) {
+        int status = w.st2[b];
+        if (badt > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
+        a.status[b] = status;
+        if (a.resid) a.resid[b] = nrest;
+        if (a.pivots) a.pivots[b] = n + w.piv2[b];
+    }
+}
+
+} // namespace
+
+size_t qpn_schur_big_workspace_bytes(int batch, int N)
+{
+    const size_t rows = (size_t)((N + 15) & ~15);
+    const size_t tt = (rows < 512 ? rows : 512) * (size_t)(((N + 15) & ~15) + 48);
+    return (size_t)batch * (tt + (size_t)N * N + 4 * (size_t)N) * sizeof(double) + (size_t)batch * 4 * sizeof(int32_t) + 1024;
+}
+
+// Carves `ws` (qpn_schur_big_workspace_bytes) and runs stage A; fills `out` for the later launches.
+hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, hipStream_t stream)
+{
+    const int N = a.N, batch = a.batch;
+    const size_t rows = (size_t)((N + 15) & ~15);
+    SchurBigWs w{};
+    w.tt_stride = (int64_t)((rows < 512 ? rows : 512) * (size_t)(((N + 15) & ~15) + 48));
+    w.s_stride = (int64_t)N * N;
+    double *p = static_cast<double *>(ws);
+    w.Tt = p; p += (size_t)batch * w.tt_stride;
+    w.S = p; p += (size_t)batch * w.s_stride;
+    w.c = p; p += (size_t)batch * N;
+    w.l2 = p; p += (size_t)batch * N;
+    w.u2 = p; p += (size_t)batch * N;
+    w.lam = p; p += (size_t)batch * N;
+    int32_t *ip = reinterpret_cast<int32_t *>(p);
+    w.st2 = ip; ip += batch; w.piv2 = ip; ip += batch; w.nsplit = ip; ip += batch; w.nred = ip; ip += batch;
+    *out = w;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_stage_a),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_finish),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t rows_lds = rows < 512 ? rows : 512;
+    hipLaunchKernelGGL(schur_big_stage_a, dim3((unsigned)batch), dim3(TPB), rows_lds * LDU * sizeof(double), stream, a, w);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream)
+{
+    hipLaunchKernelGGL(schur_big_finish, dim3((unsigned)a.batch), dim3(TPB), (size_t)a.N * sizeof(double), stream, a, w);
+    return hipGetLastError();
+}

@@ -48,6 +48,10 @@ struct AviBatchArgs {
     int64_t stride_x;
     // optional schedule of the fused node kernel: wavefront i solves node order[i] (a permutation)
     const int32_t *order;
+    // large-item kernel only: per-item size override (items of different N <= this->N in one launch; vectors
+    // are then laid out with stride vec_stride, the workspace with the launch-wide N)
+    const int32_t *n_items;
+    int64_t vec_stride;
 };
 
 // qpn_avi_solve.hip
@@ -59,6 +63,16 @@ int qpn_avi_max_n();
 int qpn_avi_big_max_n();
 size_t qpn_avi_big_workspace_bytes(int batch, int N);
 hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hipStream_t stream);
+
+// qpn_avi_schur_big.hip: blocked MFMA crash for large node-shaped items (workspace views filled by stage A)
+struct SchurBigWs {
+    double *Tt, *S, *c, *l2, *u2, *lam;
+    int32_t *st2, *piv2, *nsplit, *nred;
+    int64_t tt_stride, s_stride;
+};
+size_t qpn_schur_big_workspace_bytes(int batch, int N);
+hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, hipStream_t stream);
+hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
 
 // qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
 hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,

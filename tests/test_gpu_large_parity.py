@@ -75,3 +75,24 @@ def test_robust_avoid_deepest_pool_reference_form(engine, oracle):
     for a_, b_ in zip(outs["gpu"], outs["cpu"]):
         assert np.max(np.abs(a_ - b_)) <= 1e-9                       # GPU == oracle
     assert np.allclose(outs["gpu"][0][eps_pos], outs["gpu"][1][eps_pos], atol=1e-8)   # same LP optimum
+
+
+def test_large_blocked_crash_declines_fall_back(engine, oracle):
+    """Large node-shaped items go through the blocked MFMA crash (qpn_avi_schur_big.hip); items it must
+    decline -- an equality GAVI row, a singular H block (LP-like node, Q = 0), a non-node shape -- are solved
+    by the general large-item kernel in the same call.  Mixed batch, every item against the oracle."""
+    from qpn_amd.engine import colmajor
+    n, m, cnt = 40, 44, 6
+    Q, R, qd, A, B, l, u = P.synth_nodes(7300, cnt, n, m)
+    l = l.copy(); u = u.copy()
+    l[1, 3] = u[1, 3] = 0.25                                  # item 1: equality GAVI row -> declined
+    Q[2] = 0.0                                                # item 2: LP-like (H = 0) -> pivot test fails -> declined
+    A[2, :n, :] = np.eye(n)                                   #         (box rows make it bounded)
+    l[2, :n] = -2.0; u[2, :n] = 2.0
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, P.shared_params())
+    kind = kind.copy()
+    kind[3, 5] = 1; lo[3, 5] = -3.0; hi[3, 5] = 3.0           # item 3: a GAVI row inside the x block -> other shape
+    rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+    rg = engine.solve_avi_batch(colmajor(M), q, lo, hi, kind=kind)
+    assert np.all(rc["status"] == 1)
+    _cmp(rg, rc, "large mixed batch")
