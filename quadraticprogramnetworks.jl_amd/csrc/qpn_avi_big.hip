@@ -637,15 +637,21 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
     SchurBigWs w{};
     hipError_t e = qpn_launch_schur_big_stage_a(a, sb, &w, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, ones, N);
-    AviBatchArgs r{};
-    r.batch = a.batch; r.N = N; r.n_items = w.nred; r.vec_stride = N;
-    r.M = w.S; r.strideM = w.s_stride; r.q = w.c; r.l = w.l2; r.u = w.u2; r.kind = ones; r.stride_kind = 0;
-    r.z = w.lam; r.status = w.st2; r.pivots = w.piv2; r.resid = nullptr; r.active = nullptr;
-    r.check_tol = a.check_tol; r.piv_tol = a.piv_tol; r.feas_tol = a.feas_tol; r.comp_tol = a.comp_tol;
-    r.max_pivots = a.max_pivots; r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
-    r.only_if = a.status; r.only_if_value = -2;
-    e = launch_big_kernel(r, dict, stream);
+    static const bool lemke_general = [] { const char *e = getenv("QPN_AVI_BIG_LEMKE"); return e && e[0] == 'g'; }();
+    if (lemke_general) {
+        // A/B path: the general large-item kernel on the Schur problem (per-item sizes), one full dictionary pass per pivot
+        hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, ones, N);
+        AviBatchArgs r{};
+        r.batch = a.batch; r.N = N; r.n_items = w.nred; r.vec_stride = N;
+        r.M = w.S; r.strideM = w.s_stride; r.q = w.c; r.l = w.l2; r.u = w.u2; r.kind = ones; r.stride_kind = 0;
+        r.z = w.lam; r.status = w.st2; r.pivots = w.piv2; r.resid = nullptr; r.active = nullptr;
+        r.check_tol = a.check_tol; r.piv_tol = a.piv_tol; r.feas_tol = a.feas_tol; r.comp_tol = a.comp_tol;
+        r.max_pivots = a.max_pivots; r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
+        r.only_if = a.status; r.only_if_value = -2;
+        e = launch_big_kernel(r, dict, stream);
+    } else {
+        e = qpn_launch_schur_big_lemke(a, w, dict, stream);
+    }
     if (e != hipSuccess) return e;
     e = qpn_launch_schur_big_finish(a, w, stream);
     if (e != hipSuccess) return e;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
         if (!gk || lk == uk) bad_tail = true;
     }
     const int nbad = sb_block_sum_i(bad_tail ? 1 : 0, S, tid);
-    if (nbad > 0 || n < 1 || m < 1 || n > NMAXA) { if (tid == 0) a.status[b] = -1; return; }
+    if (nbad > 0 || n < 1 || m < 1 || n > NMAXA || m > 2 * TPB) { if (tid == 0) a.status[b] = -1; return; }   // (Lemke kernel: 2 rows per thread)
 
     const int n_pad = pad16(n), m_pad = pad16(m);
     const int ldc = n_pad + m_pad + 16;                 // H part | C part | one tile whose column 0 is g
@@ -328,6 +328,264 @@ __global__ __launch_bounds__(TPB) void schur_big_finish(AviBatchArgs a, SchurBig
     }
 }
 
+
+// ---- Lemke on the m x m Schur problem with DELAYED updates ------------------------------------------------
+// All pairs are GAVI pairs: p_k = s_k = (S lambda + c)_k in [l_k, u_k], d_k = lambda_k (ids k, m + k; artificial
+// 2m; column m of the dictionary = the extra / covering column).  Same rule as Stage B of qpn_avi_schur.hip.
+// A Gauss-Jordan exchange on (r, c) with pivot p, column u, row w IS a rank-1 update
+//         T' = T - (u + e_r)(w - e_c)' / p,
+// so the dictionary is kept as  T = T_base - sum_k a_k b_k'  with T_base in HBM (row-major) and up to KP pending
+// (a_k, b_k) pairs in LDS.  A pivot then touches ONE column and ONE row of T_base (2 + 8 KB) instead of all of
+// it (1 MB read + written at m = 256); every KP pivots the pending pairs are folded into T_base with a rank-KP
+// MFMA pass.  Entries of the exchanged row / column carry a relative error ~ eps |p| (cancellation in the
+// rank-1 form); the result is certified by the post-check on the original blocks like every other path.
+template <int KP>
+__global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigWs w, double *dict)
+{
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (a.status[b] != -2) return;
+    const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
+    const int m = w.nred[b], XC = m, VTH = 2 * m, ld = m + 1;
+    const size_t vo = (size_t)b * (size_t)a.N;
+    __shared__ SbShared S;
+    __shared__ double bcd[8];
+    __shared__ int bci[8];
+    extern __shared__ __attribute__((aligned(16))) double dynl[];
+    const int mA = m, mB = m + 1;
+    double *PA = dynl;                               // [KP][m]
+    double *PB = PA + (size_t)KP * mA;               // [KP][m + 1]
+    double *cnb = PB + (size_t)KP * mB;              // nonbasic values by column, [m + 1]
+    double *lo0 = cnb + mB + (mB & 1);               // pair bounds
+    double *hi0 = lo0 + m;
+    int *colvar = reinterpret_cast<int *>(hi0 + m);  // [m + 1]
+    int *sat = colvar + mB + (mB & 1);               // [m]
+    double *Tb = dict + (size_t)b * (size_t)a.N * (size_t)(a.N + 1);     // T_base, row-major, ld = m + 1
+    const double *Sg = w.S + (size_t)b * (size_t)w.s_stride;
+
+    // rows owned by this thread
+    bool act[2]; int rowvar[2]; double xb[2], lo[2], hi[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = tid + TPB * h;
+        act[h] = i < m; rowvar[h] = -1; xb[h] = 0.0; lo[h] = -QINF; hi[h] = QINF;
+        if (act[h]) {
+            lo[h] = w.l2[vo + i]; hi[h] = w.u2[vo + i]; xb[h] = w.c[vo + i]; rowvar[h] = i;
+            lo0[i] = lo[h]; hi0[i] = hi[h]; sat[i] = 0; colvar[i] = m + i; cnb[i] = 0.0;
+        }
+    }
+    if (tid == 0) { colvar[m] = VTH; cnb[m] = 0.0; }
+    // T_base = [S | 0]: S is column-major, read coalesced over rows
+    for (int j = 0; j < m; ++j)
+        for (int i = tid; i < m; i += TPB) Tb[(size_t)i * ld + j] = Sg[(size_t)j * m + i];
+    __syncthreads();
+
+    int pivots = 0, status = QPN_FAILURE, npend = 0;
+    const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * a.N + 100;
+    int c = XC;
+    bool sneg = true;
+    double self_lim = 0.0, elo = 0.0, ehi = QINF;
+    const double slack = 1e-10, ptol = a.piv_tol;
+    {
+        double viol = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (act[h]) viol = fmax(viol, xb[h] < lo[h] ? lo[h] - xb[h] : (xb[h] > hi[h] ? xb[h] - hi[h] : 0.0));
+        const double theta0 = sb_block_max(viol, S, tid);
+        if (theta0 <= a.feas_tol) status = QPN_SUCCESS;
+        else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!act[h]) continue;
+                double cov = 0.0;
+                if (xb[h] < lo[h]) {
+                    double tgt = lo[h] + (theta0 - (lo[h] - xb[h]));
+                    if (hi[h] < QINF) { const double mid = 0.5 * (lo[h] + hi[h]); if (tgt > mid) tgt = mid; }
+                    cov = (tgt - xb[h]) / theta0; xb[h] = tgt;
+                } else if (xb[h] > hi[h]) {
+                    double tgt = hi[h] - (theta0 - (xb[h] - hi[h]));
+                    if (lo[h] > -QINF) { const double mid = 0.5 * (lo[h] + hi[h]); if (tgt < mid) tgt = mid; }
+                    cov = (tgt - xb[h]) / theta0; xb[h] = tgt;
+                }
+                Tb[(size_t)(tid + TPB * h) * ld + m] = cov;
+            }
+            if (tid == 0) cnb[m] = theta0;
+            self_lim = theta0;
+            status = QPN_MAX_ITERS;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    auto col_of = [&](int v) -> int {
+        int best = 0x7fffffff;
+        for (int j = tid; j <= m; j += TPB) if (colvar[j] == v) best = j;
+        const int r = sb_block_min_i(best, S, tid);
+        return r == 0x7fffffff ? -1 : r;
+    };
+
+    while (status == QPN_MAX_ITERS) {
+        if (pivots >= max_piv) break;
+        // ---- entering column of the CURRENT dictionary: T_base column minus the pending rank-1 terms
+        double cm[2] = {0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!act[h]) continue;
+            const int i = tid + TPB * h;
+            double v = Tb[(size_t)i * ld + c];
+            for (int k = 0; k < npend; ++k) v = fma(-PA[k * mA + i], PB[k * mB + c], v);
+            cm[h] = v;
+        }
+        // ---- ratio test
+        double gdir[2], rc[2], dd[2], d1min = QINF;
+        bool cndlo[2], cnd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            gdir[h] = sneg ? -cm[h] : cm[h];
+            rc[h] = 1.0 / gdir[h];
+            cndlo[h] = act[h] && gdir[h] < -ptol && lo[h] > -QINF;
+            const bool cndhi = act[h] && gdir[h] > ptol && hi[h] < QINF;
+            cnd[h] = cndlo[h] || cndhi;
+            const double arc = fabs(rc[h]);
+            dd[h] = (cndlo[h] ? xb[h] - lo[h] : hi[h] - xb[h]) * arc;
+            if (cnd[h]) d1min = fmin(d1min, fma(slack, arc, dd[h]));
+        }
+        double dmax = -sb_block_max(-d1min, S, tid);
+        if (self_lim < dmax) dmax = self_lim;
+        if (dmax == QINF) { status = QPN_RAY_TERM; break; }
+        int ncand = 0;
+        bool cand[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { cand[h] = cnd[h] && dd[h] <= dmax; ncand += cand[h] ? 1 : 0; }
+        ncand = sb_block_sum_i(ncand, S, tid);
+        if (ncand == 0) {
+            // the entering variable reaches its own opposite bound first: no basis change
+            const double dl = sneg ? -self_lim : self_lim;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) if (act[h]) xb[h] = fma(dl, cm[h], xb[h]);
+            const int ve = colvar[c];
+            if (ve == VTH) { __syncthreads(); if (tid == 0) cnb[c] = 0.0; status = QPN_SUCCESS; break; }
+            const int k = ve;
+            const int au = sneg ? 0 : 1;
+            const double nv = au ? hi0[k] : lo0[k];
+            __syncthreads();
+            if (tid == 0) { sat[k] = au; cnb[c] = nv; }
+            pivots++;
+            __syncthreads();
+            c = col_of(m + k);
+            if (c < 0) { status = QPN_FAILURE; break; }
+            sneg = au != 0;
+            self_lim = QINF;
+            if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+            continue;
+        }
+        // ---- pivot row: unique candidate, or the largest |pivot| among them, the artificial first; ties -> lowest row
+        double ag = -1.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (cand[h]) { const double v = rowvar[h] == VTH ? QINF : fabs(gdir[h]); if (v > ag) ag = v; }
+        const double bestg = sb_block_max(ag, S, tid);
+        int myr = 0x7fffffff;
+#pragma unroll
+        for (int h = 1; h >= 0; --h) if (cand[h] && (rowvar[h] == VTH ? QINF : fabs(gdir[h])) == bestg) myr = tid + TPB * h;
+        const int r = sb_block_min_i(myr, S, tid);
+        // owner of row r publishes its scalars
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (tid + TPB * h == r) {
+                bcd[0] = dd[h]; bcd[1] = cndlo[h] ? lo[h] : hi[h]; bcd[2] = rc[h]; bcd[3] = cm[h];
+                bci[0] = rowvar[h]; bci[1] = cndlo[h] ? 0 : 1;
+            }
+        }
+        __syncthreads();
+        double step = bcd[0];
+        if (step < 0.0) step = 0.0;
+        const double leave_val = bcd[1];
+        const double inv = sneg ? -bcd[2] : bcd[2];
+        const double delta = sneg ? -step : step;
+        const int vl = bci[0], hit_hi = bci[1];
+        const double enter_val = cnb[c] + delta;
+        const int ve = colvar[c];
+        // ---- pivot row of the CURRENT dictionary -> pending pair (a, b) = ((u + e_r) inv, w - e_c)
+        for (int j = tid; j <= m; j += TPB) {
+            double v = Tb[(size_t)r * ld + j];
+            for (int k = 0; k < npend; ++k) v = fma(-PA[k * mA + r], PB[k * mB + j], v);
+            PB[npend * mB + j] = v - (j == c ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!act[h]) continue;
+            const int i = tid + TPB * h;
+            PA[npend * mA + i] = (cm[h] + (i == r ? 1.0 : 0.0)) * inv;
+            if (i == r) { xb[h] = enter_val; rowvar[h] = ve; lo[h] = elo; hi[h] = ehi; }
+            else xb[h] = fma(delta, cm[h], xb[h]);
+        }
+        __syncthreads();
+        if (tid == 0) { colvar[c] = vl; cnb[c] = leave_val; }
+        npend++;
+        pivots++;
+        if (vl == VTH) { status = QPN_SUCCESS; break; }
+        int vn;
+        {
+            const int k = vl < m ? vl : vl - m;
+            const double Lk = lo0[k], Uk = hi0[k];
+            const bool isfree = Lk == -QINF && Uk == QINF;
+            int au = sat[k];
+            if (vl < m) {
+                au = hit_hi;
+                __syncthreads();
+                if (tid == 0) sat[k] = au;
+                vn = m + k; sneg = au != 0; self_lim = QINF;
+                if (isfree) { elo = 0.0; ehi = 0.0; }
+                else if (au) { elo = -QINF; ehi = 0.0; }
+                else { elo = 0.0; ehi = QINF; }
+            } else {
+                vn = k; sneg = au != 0; self_lim = Uk - Lk;
+                if (isfree) { self_lim = QINF; sneg = false; }
+                elo = Lk; ehi = Uk;
+            }
+        }
+        __syncthreads();
+        c = col_of(vn);
+        if (c < 0) { status = QPN_FAILURE; break; }
+        // ---- fold the pending pairs into T_base: rank-KP MFMA pass over its tiles
+        if (npend == KP) {
+            const int rt = (m + 15) / 16, ct = (m + 1 + 15) / 16;
+            for (int t = wave; t < rt * ct; t += 4) {
+                const int I = t / ct, J = t % ct;
+                d4 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+                    acc[g] = (ri < m && cj <= m) ? Tb[(size_t)ri * ld + cj] : 0.0;
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < KP / 4; ++s4) {
+                    const int ri = 16 * I + lc, cj = 16 * J + lc, kk = 4 * s4 + lq;
+                    const double av = ri < m ? -PA[kk * mA + ri] : 0.0;
+                    const double bv = cj <= m ? PB[kk * mB + cj] : 0.0;
+                    acc = MFMA(av, bv, acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+                    if (ri < m && cj <= m) Tb[(size_t)ri * ld + cj] = acc[g];
+                }
+            }
+            npend = 0;
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+
+    // ---- read-back: lambda_k = value of d_k (id m + k)
+    __syncthreads();
+    double *valv = PA;                                  // 2m + 1 values by id (the pending pairs are done with)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) if (act[h] && rowvar[h] >= 0) valv[rowvar[h]] = xb[h];
+    for (int j = tid; j <= m; j += TPB) valv[colvar[j]] = cnb[j];
+    __syncthreads();
+    for (int k = tid; k < m; k += TPB) w.lam[vo + k] = valv[m + k];
+    if (tid == 0) { w.st2[b] = status; w.piv2[b] = pivots; }
+}
+
 } // namespace
 
 size_t qpn_schur_big_workspace_bytes(int batch, int N)
@@ -373,5 +631,30 @@ hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBi
 hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream)
 {
     hipLaunchKernelGGL(schur_big_finish, dim3((unsigned)a.batch), dim3(TPB), (size_t)a.N * sizeof(double), stream, a, w);
+    return hipGetLastError();
+}
+
+// Lemke on the Schur problems of the accepted items (status -2) with delayed updates; `dict` is the large-item
+// kernel's dictionary workspace (batch x N x (N+1) doubles), reused here as T_base.
+hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream)
+{
+    const int N = a.N;                                   // m <= min(N - 1, 512) (stage A declines larger ones)
+    const int KP = N <= 272 ? 16 : 8;                    // pending pairs: 2 KP (m + 1) doubles of LDS
+    const size_t mB = (size_t)(N < 513 ? N : 513);       // upper bound of m + 1
+    const size_t dbl = (size_t)KP * (2 * mB + 1) + (mB + 2) + 2 * mB;
+    const size_t bytes = ((dbl * sizeof(double) + sizeof(int) * (2 * mB + 4)) + 15) & ~(size_t)15;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_lemke<16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_lemke<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (bytes > 150 * 1024) return hipErrorInvalidValue;
+    if (KP == 16) hipLaunchKernelGGL(schur_big_lemke<16>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict);
+    else hipLaunchKernelGGL(schur_big_lemke<8>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict);
     return hipGetLastError();
 }

@@ -73,6 +73,7 @@ struct SchurBigWs {
 size_t qpn_schur_big_workspace_bytes(int batch, int N);
 hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, hipStream_t stream);
 hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
+hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream);
 
 // qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
 hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,
