@@ -9,13 +9,14 @@
 //     * only the top half [H | C | g] is eliminated, row-major in an HBM workspace, as 16 x 16 tiles in the
 //       C/D layout of v_mfma_f64_16x16x4_f64;
 //     * rank-16 block pivots: the 16 pivot columns (a panel, n x 16) go to registers/LDS once, the 16 x 16
-//       pivot block is LU-factored in LDS (no pivoting; every pivot must pass the |u_ss| >= 1e-4 max(1,max|M|)
-//       test, else the item is declined), every thread solves x L U = u for its panel row: U' = U P^-1;
+//       pivot block is LU-factored and inverted in LDS (no pivoting; every pivot must pass the
+//       |u_ss| >= 1e-4 max(1,max|M|) test, else the item is declined), every thread forms its panel row of
+//       U' = U P^-1;
 //       then T -= U' V with the RAW pivot rows V as B operands: 4 MFMAs per tile and pass, the whole top half
 //       is read and written 16 times in all (n / 16 passes) instead of n times;
 //     * S = D - A W and c = b - A h as a tiled GEMM on the matrix cores (A operands straight from M).
-//   the Lemke phase then runs on the m x m Schur problem (all GAVI rows) with the general large-item kernel:
-//     no crash pivots, a quarter of the dictionary;
+//   lemke    Lemke on the m x m Schur problem (all GAVI rows) with DELAYED rank-1 updates: a pivot touches one
+//            column and one row of the HBM dictionary, the pending pairs are folded in by a rank-8/16 MFMA pass;
 //   finish   x = -(W lambda + h), post-check / residual / active sets on the ORIGINAL blocks.
 // Declined items (other shape, equality GAVI rows, n > 512, a pivot below the threshold) keep status -1 and
 // are solved by the general kernel in a gated launch.  Results: same bar as the small MFMA kernel
@@ -41,6 +42,7 @@ struct SbShared {
     int redi[TPB];
     double P[PW * LDU];      // pivot block, then its LU factors (unit lower L below, U on and above the diagonal)
     double rd[PW];           // reciprocals of the pivots
+    double Pinv[PW * LDU];   // P^-1 (column c solved by lane c of wave 0)
     int flag;
 };
 
@@ -143,20 +145,10 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
     const int nrt = n_pad / 16, nct = ldc / 16;
     for (int kb = 0; kb < nrt; ++kb) {
         const int p0 = 16 * kb;
-        // panel rows into registers (thread t <-> rows t, t + 256), pivot block into LDS
-        double ur[2][PW];
+        // pivot block (rows p0 .. p0+15 of the panel) into LDS
+        if (tid < PW) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int t = tid + TPB * h;
-            if (t < n_pad) {
-#pragma unroll
-                for (int k = 0; k < PW; ++k) ur[h][k] = Tt[(size_t)t * ldc + p0 + k];
-                if (t >= p0 && t < p0 + PW) {
-#pragma unroll
-                    for (int k = 0; k < PW; ++k) S.P[(t - p0) * LDU + k] = ur[h][k];
-                    ur[h][t - p0] -= 1.0;                       // pivot rows carry P - I
-                }
-            }
+            for (int k = 0; k < PW; ++k) S.P[tid * LDU + k] = Tt[(size_t)(p0 + tid) * ldc + p0 + k];
         }
         if (tid == 0) S.flag = 1;
         __syncthreads();
@@ -176,32 +168,43 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            // P^-1: lane c solves L y = e_c, then U x = y, in place in column c of Pinv (rolled loops, LDS only)
+            if (lane < PW && S.flag) {
+                const int cc = lane;
+#pragma unroll 1
+                for (int j = 0; j < PW; ++j) {
+                    double sacc = (j == cc) ? 1.0 : 0.0;
+#pragma unroll 1
+                    for (int i = 0; i < j; ++i) sacc = fma(-S.P[j * LDU + i], S.Pinv[i * LDU + cc], sacc);
+                    S.Pinv[j * LDU + cc] = sacc;
+                }
+#pragma unroll 1
+                for (int j = PW - 1; j >= 0; --j) {
+                    double sacc = S.Pinv[j * LDU + cc];
+#pragma unroll 1
+                    for (int i = j + 1; i < PW; ++i) sacc = fma(-S.P[j * LDU + i], S.Pinv[i * LDU + cc], sacc);
+                    S.Pinv[j * LDU + cc] = sacc * S.rd[j];
+                }
+            }
         }
         __syncthreads();
         if (S.flag == 0) { if (tid == 0) a.status[b] = -1; return; }
-        // U' = U P^-1: every thread solves x L U = u for its panel rows
+        // U' = U P^-1, one panel row per thread at a time: 16 accumulators, P^-1 broadcast from LDS (rolled over
+        // the panel column j so that nothing but the accumulators stays live); pivot rows carry P - I
+        for (int t = tid; t < n_pad; t += TPB) {
+            double acc[PW];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int t = tid + TPB * h;
-            if (t < n_pad) {
-                double y[PW];
+            for (int k = 0; k < PW; ++k) acc[k] = 0.0;
+            const double *ut = Tt + (size_t)t * ldc + p0;
+#pragma unroll 1
+            for (int j = 0; j < PW; ++j) {
+                double uj = ut[j];
+                if (t == p0 + j) uj -= 1.0;
 #pragma unroll
-                for (int j = 0; j < PW; ++j) {
-                    double s = ur[h][j];
-#pragma unroll
-                    for (int i = 0; i < j; ++i) s = fma(-y[i], S.P[i * LDU + j], s);
-                    y[j] = s * S.rd[j];
-                }
-#pragma unroll
-                for (int j = PW - 1; j >= 0; --j) {
-                    double s = y[j];
-#pragma unroll
-                    for (int i = j + 1; i < PW; ++i) s = fma(-y[i], S.P[i * LDU + j], s);
-                    y[j] = s;
-                }
-#pragma unroll
-                for (int k = 0; k < PW; ++k) sUp[t * LDU + k] = y[k];
+                for (int k = 0; k < PW; ++k) acc[k] = fma(uj, S.Pinv[j * LDU + k], acc[k]);
             }
+#pragma unroll
+            for (int k = 0; k < PW; ++k) sUp[t * LDU + k] = acc[k];
         }
         __syncthreads();
         // T -= U' V on the live column tiles (those right of the panel), 4 k-steps per tile
@@ -209,14 +212,26 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
             double vb[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) vb[s] = Tt[(size_t)(p0 + 4 * s + lq) * ldc + 16 * J + lc];
-            for (int I = 0; I < nrt; ++I) {
-                d4 c;
+            // two row tiles at a time: 8 loads in flight ahead of the MFMAs (the pass is a stream over HBM; four at a
+            // time is no faster -- the stream, not its latency, is the limit)
+            for (int I0 = 0; I0 < nrt; I0 += 2) {
+                const int I1 = I0 + 1 < nrt ? I0 + 1 : I0;
+                d4 c0, c1;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) c[g] = Tt[(size_t)(16 * I + 4 * g + lq) * ldc + 16 * J + lc];
+                for (int g = 0; g < 4; ++g) {
+                    c0[g] = Tt[(size_t)(16 * I0 + 4 * g + lq) * ldc + 16 * J + lc];
+                    c1[g] = Tt[(size_t)(16 * I1 + 4 * g + lq) * ldc + 16 * J + lc];
+                }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) c = MFMA(-sUp[(16 * I + lc) * LDU + 4 * s + lq], vb[s], c);
+                for (int s = 0; s < 4; ++s) c0 = MFMA(-sUp[(16 * I0 + lc) * LDU + 4 * s + lq], vb[s], c0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I + 4 * g + lq) * ldc + 16 * J + lc] = c[g];
+                for (int s = 0; s < 4; ++s) c1 = MFMA(-sUp[(16 * I1 + lc) * LDU + 4 * s + lq], vb[s], c1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I0 + 4 * g + lq) * ldc + 16 * J + lc] = c0[g];
+                if (I1 != I0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I1 + 4 * g + lq) * ldc + 16 * J + lc] = c1[g];
+                }
             }
         }
         __threadfence_block();
@@ -239,11 +254,22 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
             c[g] = v;
         }
         const int ai = 16 * I + lc;
-        for (int kk = 0; kk < n_pad / 4; ++kk) {
-            const int aj = 4 * kk + lq;
-            const double av = (ai < m && aj < n) ? -Mg[(size_t)aj * N + n + ai] : 0.0;
-            const double bv = Tt[(size_t)aj * ldc + n_pad + 16 * J + lc];
-            c = MFMA(av, bv, c);
+        // eight k-steps at a time: 16 operand loads in flight ahead of the 8 MFMAs (n_pad / 4 is a multiple of 4;
+        // the tail iteration clamps its addresses and multiplies zeros)
+        for (int kk0 = 0; kk0 < n_pad / 4; kk0 += 8) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kk = kk0 + q;
+                const bool okk = kk < n_pad / 4;
+                const int aj = okk ? 4 * kk + lq : 0;
+                const double ta = Mg[(size_t)((ai < m && aj < n) ? aj : 0) * N + n + (ai < m ? ai : 0)];
+                av[q] = (okk && ai < m && aj < n) ? -ta : 0.0;
+                const double tb = Tt[(size_t)aj * ldc + n_pad + 16 * J + lc];
+                bv[q] = okk ? tb : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c = MFMA(av[q], bv[q], c);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
