@@ -20,7 +20,7 @@ def _cmp(rg, rc, what, ztol=1e-9):
     assert np.array_equal(np.asarray(rg["pivots"]), np.asarray(rc["pivots"])), what
 
 
-@pytest.mark.parametrize("n,m,cnt", [(40, 40, 6), (48, 80, 4), (100, 157, 3), (256, 256, 2)])
+@pytest.mark.parametrize("n,m,cnt", [(40, 40, 6), (48, 80, 4), (100, 157, 3), (256, 256, 2), (300, 330, 2), (17, 500, 2)])
 def test_large_reduced_nodes(engine, oracle, n, m, cnt):
     from qpn_amd.engine import colmajor
     Q, R, qd, A, B, l, u = P.synth_nodes(7000 + n, cnt, n, m)
