@@ -211,3 +211,33 @@ def test_solve_nodes_into_scatters_primal_blocks(engine, oracle):
     torch.cuda.synchronize()
     assert np.all(rd["status"].cpu().numpy() == 1)
     assert np.array_equal(x.cpu().numpy(), rd["z"].cpu().numpy()[:, :n])
+
+
+def test_abi_argument_errors_are_codes_not_crashes(engine):
+    """Error behaviour at the boundary: API misuse comes back as a negative code with
+    a message, never as an exception from native code or a fault; empty batches are a no-op."""
+    import ctypes as C
+    from qpn_amd import _lib
+    lib, ctx = engine.lib, engine.ctx
+    n, m, p, cnt = 4, 3, 1, 2
+    Q, R, qd, A, B, l, u = P.synth_nodes(1, cnt, n, m, p)
+    from qpn_amd.engine import colmajor
+    arrs = [np.ascontiguousarray(a) for a in (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, P.shared_params(p))]
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    z = np.zeros((cnt, n + m)); st = np.zeros(cnt, np.int32); x = np.zeros((cnt, n))
+    o = _lib.AviOpts(); lib.qpn_avi_default_opts(C.byref(o))
+    base = [ctx, cnt, n, m, p] + [ptr(a) for a in arrs] + [0, ptr(z), ptr(st), None, None, None, C.byref(o), 0]
+    assert lib.qpn_solve_nodes_into(*base, ptr(x), n) == 0 and np.all(st == 1)
+    assert lib.qpn_solve_nodes_into(*base, ptr(x), n - 1) < 0                      # stride_x < n
+    assert b"stride_x" in lib.qpn_ctx_last_error(ctx)
+    bad = list(base); bad[1] = -1
+    assert lib.qpn_solve_nodes_into(*bad, None, 0) < 0                              # negative batch
+    bad = list(base); bad[5] = None
+    assert lib.qpn_solve_nodes_into(*bad, None, 0) < 0                              # null Qd
+    bad = list(base); bad[1] = 0
+    assert lib.qpn_solve_nodes_into(*bad, None, 0) == 0                             # empty batch: no-op
+    assert lib.qpn_order_nodes_by_pivots(ctx, None, 5, 0) < 0
+    assert lib.qpn_order_nodes_by_pivots(ctx, ptr(st), 0, 0) < 0
+    assert lib.qpn_set_node_order(ctx, ptr(st), -3, 0) < 0
+    assert lib.qpn_set_node_order(ctx, None, 0, 0) == 0                             # clearing is always fine
+    assert lib.qpn_solve_nodes_into(None, *base[1:], None, 0) < 0                   # no context
