@@ -45,4 +45,9 @@ rounds = -(-cnt // S)
 grid = np.full((S, rounds), -1, dtype=np.int64); grid.flat[:cnt] = lpt        # row-major: slot s holds lpt[s*rounds + j]
 bc = grid.T.reshape(-1); bc = bc[bc >= 0]
 run(bc, "block-cyclic (each slot long+medium+short)")
+run(np.concatenate([lpt[-S:], lpt[:-S]]), "shortest 4096 first, then the rest longest-first")
+run(np.concatenate([lpt[-S:][::-1], lpt[:-S]]), "shortest 4096 first (ascending), then LPT")
+mid = lpt[S:2 * S]
+run(np.concatenate([mid, lpt[:S], lpt[2 * S:]]), "middle 4096 first, then longest, then shortest")
+run(np.concatenate([lpt[S // 2: S // 2 + S], lpt[:S // 2], lpt[S // 2 + S:]]), "offset window first, then LPT")
 eng.set_node_order(None)
