@@ -175,12 +175,14 @@ __device__ __forceinline__ int readlane_i32(int v, int l)
 }
 // v with lane `lane` (wave-uniform) replaced by the wave-uniform value `x`: v_writelane_b32, no
 // compare/select.  (No clang builtin on this toolchain, hence asm; gfx9 allows one SGPR per VALU instruction, so the lane
-// select goes through M0; the s_nop covers the wait states between the SALU write of M0 / a VALU-written
+// select goes through M0 (saved and restored: the compiler owns M0); the s_nop covers the wait states between the SALU write of M0 / a VALU-written
 // data SGPR and their use, which the hazard recognizer cannot see through inline asm.)
 __device__ __forceinline__ int writelane_i32(int v, int lane, int x)
 {
     const int xs = __builtin_amdgcn_readfirstlane(x), ls = __builtin_amdgcn_readfirstlane(lane);
-    asm("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(xs), "s"(ls) : "m0");
+    int m0save;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+        : "+v"(v), "=&s"(m0save) : "s"(xs), "s"(ls));
     return v;
 }
 __device__ __forceinline__ double writelane_f64(double v, int lane, double x)
@@ -188,8 +190,10 @@ __device__ __forceinline__ double writelane_f64(double v, int lane, double x)
     const int ls = __builtin_amdgcn_readfirstlane(lane);
     const int xl = __builtin_amdgcn_readfirstlane(__double2loint(x)), xh = __builtin_amdgcn_readfirstlane(__double2hiint(x));
     int lo = __double2loint(v), hi = __double2hiint(v);
-    asm("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-        : "+v"(lo), "+v"(hi) : "s"(xl), "s"(xh), "s"(ls) : "m0");
+    int m0save;
+    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
+        "s_mov_b32 m0, %2"
+        : "+v"(lo), "+v"(hi), "=&s"(m0save) : "s"(xl), "s"(xh), "s"(ls));
     return __hiloint2double(hi, lo);
 }
 #define QPN_ROW_REDUCE(v, OP)                                  \
