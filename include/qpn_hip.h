@@ -130,8 +130,9 @@ int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_
  * Same inputs as qpn_assemble_nodes, same outputs as qpn_solve_avi_batch (N = n+m, z = [x_d; lambda]);
  * identical results to calling the two in sequence, without materialising M in HBM: one pass of the
  * hot path per outer sweep (src/algorithm.jl:95 -> solve_qep -> src/avi.jl:399-409 for single-node
- * pools).  z: in z0 (ignored with QPN_AVI_FLAG_COLD_START), out solution.  n, m <= 32 run on the
- * matrix-core kernel; other sizes (n+m <= 1024) go through assembly + the general kernels. */
+ * pools).  z: in z0 (ignored with QPN_AVI_FLAG_COLD_START), out solution.  n, m <= 32 run on the fused
+ * matrix-core kernel; larger nodes (n+m <= 1024) are assembled and take the blocked matrix-core path for
+ * large node-shaped items (n, m <= 512) or the general kernels. */
 int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
                     const double *R, const double *qd, const double *Ad, const double *B,
                     const double *l, const double *u, const double *w, int64_t stride_w, double *z,
