@@ -6,10 +6,17 @@ one rank per GPU, RCCL).  One STEP = one pass of the hot path over the whole net
     per rank, for its contiguous node range:
         (A5+A6) qpn_assemble_nodes   per-node KKT blocks from the node records and the parameters w
         (A2+A3+A9) qpn_solve_avi_batch   every node-AVI from cold duals, post-check + active sets
-    all ranks: RCCL all-gather of the primal blocks (the iterate x the outer loop needs), N > 1 only.
-Inputs (node records) are resident in HBM before the timed region.  Total work is fixed at 10 000
-nodes (BASELINE.json configs[3]) => "scaling": "strong".  value = solved node-AVIs / second over
-all ranks (failed items do not count; there are none on this workload).
+    N > 1 only: every rank needs the whole iterate x for the next sweep.  Default exchange "p2p": the solve
+    kernel itself stores each primal block into every rank's replica of x over xGMI (IPC-shared buffers,
+    qpn_set_primal_mirrors) and the sweep ends with qpn_sweep_status -- a 24-byte mailbox exchange that is the
+    stop/raise decision and the barrier; no collective on the data path.  "--exchange rccl" (and the automatic
+    fallback when buffers cannot be shared or the warm-up self-check against an RCCL all-gather fails):
+    all-gather of the primal blocks + a 2-double all-reduce.
+Inputs (node records) are resident in HBM before the timed region.  Independent node-AVIs partition over the
+ranks, so per-GPU work is fixed at 10 000 nodes (BASELINE.json configs[3] on every GPU; the N-GPU net has
+N x 10 000 nodes) => "scaling": "weak"; "--scaling strong" shards ONE 10 000-node net instead (latency-bound:
+a node-AVI is a ~40 us dependent pivot chain whatever the batch).  value = solved
+node-AVIs / second over all ranks (failed items do not count; there are none on this workload).
 
 Extra objects on the JSON line: "roofline" (HBM bound; achieved = algorithmic bytes of SURVEY.md
 section 8(d) per solve-kernel launch / mean launch duration, measured with HIP events on the launch
@@ -38,7 +45,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nodes", type=int, default=NODES)
+    ap.add_argument("--nodes", type=int, default=NODES, help="nodes per GPU (weak) / in the whole net (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--exchange", choices=("p2p", "rccl"), default="p2p", help="N > 1: how the iterate is replicated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="assemble M in HBM, then solve (two kernels) instead of the fused pass")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
@@ -54,8 +63,16 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)            # --force-dist without a launcher
+        backend = os.environ.get("QPN_BENCH_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on ONE GPU
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device(f"cuda:{local_rank}")
@@ -67,7 +84,8 @@ def main():
     eng = qpn_amd.Engine(local_rank)
     n, m, p = NVAR, NCON, NPAR
     N = n + m
-    lo_id, hi_id = sharding.node_range(args.nodes, world, rank)
+    total = args.nodes * world if args.scaling == "weak" else args.nodes
+    lo_id, hi_id = sharding.node_range(total, world, rank)
     cnt = hi_id - lo_id
 
     # ---- this rank's node records, generated from the per-node Philox streams, then made resident
@@ -76,8 +94,20 @@ def main():
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
     dQ, dR, dqd, dA, dB, dl, du, dw = (t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)),
                                        t(colmajor(B)), t(l), t(u), t(w_host))
-    x_all = torch.zeros((args.nodes, n), dtype=torch.float64, device=dev)
-    counts = [sharding.node_range(args.nodes, world, r) for r in range(world)]
+    counts = [sharding.node_range(total, world, r) for r in range(world)]
+    shared = None
+    exchange = "none"
+    if use_dist:
+        exchange = "rccl" if args.unfused else args.exchange      # the replica stores belong to the fused kernel
+        if exchange == "p2p":
+            try:
+                shared = sharding.SharedIterate(eng, dist, total, n, dev)
+            except RuntimeError as e:              # raised on ALL ranks together
+                if rank == 0:
+                    print(f"[bench] p2p exchange unavailable ({e}); using RCCL collectives", file=sys.stderr, flush=True)
+                exchange = "rccl (p2p setup failed)"
+    x_all = torch.zeros((total, n), dtype=torch.float64, device=dev) if shared is None else None
+    sweep_out = torch.zeros(3, dtype=torch.float64, device=dev)
     ev_pairs = []
     bufs = {"asm": None, "sol": None}      # output buffers are allocated once and reused
 
@@ -92,10 +122,14 @@ def main():
         else:
             # (A5+A6+A2+A3+A9) one fused pass: KKT blocks assembled on the fly inside the solve kernel,
             # primal blocks written straight into this rank's rows of the iterate x
-            xloc = x_all[lo_id:hi_id]
+            xloc = (shared.x if shared is not None else x_all)[lo_id:hi_id]
             res = bufs["sol"] = eng.solve_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["sol"], x_out=xloc)
-        if use_dist:
+        if shared is not None:
+            shared.finish_sweep(res["status"], res["resid"])       # mailbox exchange: status pair + barrier
+        elif use_dist:
             sharding.all_gather_primal(x_all, xloc, counts, dist)
+            eng.sweep_status(res["status"], res["resid"], sweep_out)
+            dist.all_reduce(sweep_out, op=dist.ReduceOp.MAX)      # any failure anywhere / worst residual
         return res
 
     def barrier():
@@ -118,6 +152,25 @@ def main():
         maybe_refresh(i, res)
         res = step(False)
     barrier()
+    if shared is not None:
+        # self-check of the p2p route, outside the timed region: every replica must equal what an RCCL
+        # all-gather of the same blocks gives, and every mailbox wait must have been served; else fall back
+        x_all = shared.x_done.clone()
+        chk = torch.zeros_like(x_all)
+        sharding.all_gather_primal(chk, x_all[lo_id:hi_id], counts, dist)
+        okv = torch.tensor([float(torch.equal(chk, x_all) and float(shared.out[2]) == 1.0 and args.warmup > 0)],
+                           dtype=torch.float64, device=dev)
+        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+        del chk
+        if float(okv) != 1.0:
+            if rank == 0:
+                print("[bench] p2p exchange failed its self-check; using RCCL collectives", file=sys.stderr, flush=True)
+            eng.set_primal_mirrors()
+            shared.close(); shared = None
+            exchange = "rccl (p2p self-check failed)"
+            for i in range(min(args.warmup, 5)):
+                res = step(False)
+            barrier()
     # ONE pair of HIP events brackets the whole timed region on the launch stream (a pair per step costs two
     # barrier packets per step, ~10 us of pipeline bubbles -- measured); the per-launch duration reported in
     # "roofline" is elapsed / steps, i.e. it also carries the near-empty fallback launch and the launch gaps
@@ -133,7 +186,8 @@ def main():
     dt = time.perf_counter() - t0
     ev_pairs.append((ev0, ev1))
 
-    solved_local = int((res["status"] == 1).sum().item())
+    sweep_ok = shared is None or float(shared.out[2]) == 1.0
+    solved_local = int((res["status"] == 1).sum().item()) if sweep_ok else 0      # a missed barrier voids the run
     max_resid = float(res["resid"].max().item())
     tt = torch.tensor([dt, float(solved_local), max_resid], dtype=torch.float64, device=dev)
     if use_dist:
@@ -160,16 +214,17 @@ def main():
             "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.nodes}-node x {n}-var two-level QPNet "
+            "config": {"workload": f"synthetic {total}-node x {n}-var two-level QPNet "
                                    f"(n=m={n}, N_red={N}, p={p}; BASELINE.json configs[3]); step = "
                                    "KKT assembly + cold-start AVI solve + check + active sets ("
                                    + ("two kernels" if args.unfused else "one fused kernel") + ")"
-                                   + (" + RCCL all-gather of primals" if use_dist else "")
+                                   + ((" + primal blocks stored into every rank's replica of x by the solve kernel (xGMI p2p) + mailbox status/barrier kernel"
+                                       if shared is not None else " + RCCL all-gather of primals + 2-double all-reduce") if use_dist else "")
                                    + ("; longest-first node schedule refreshed from the previous sweep's pivot counts every 16 steps" if use_sched else ""),
-                       "nodes": args.nodes, "n": n, "m": m, "params": p,
-                       "sharding": f"node ranges over {world} GPU(s)",
+                       "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p,
+                       "sharding": f"node ranges over {world} GPU(s)", "exchange": exchange,
                        "max_resid": max_resid, "solved": solved},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -180,6 +235,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Q, R, qd, A, B, l, u, w_host)
         print(json.dumps(out), flush=True)
     if use_dist:
+        if shared is not None:
+            shared.close()
         dist.destroy_process_group()
 
 

@@ -163,6 +163,43 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
 int qpn_order_nodes_by_pivots(qpn_ctx *ctx, const int32_t *pivots, int32_t count, int mem);
 int qpn_set_node_order(qpn_ctx *ctx, const int32_t *order, int32_t count, int mem);
 
+/* ---- multi-GPU: replicas of the iterate on peer GPUs, written by the solve itself -----------------------
+ * One process per GPU; rank g solves its own node range and every rank needs the whole iterate x for the
+ * next sweep (src/algorithm.jl:95-101 reads x_opt of all children).  Instead of a collective after the solve,
+ * the solve kernel stores each primal block to the local iterate AND to the same offset of the peers'
+ * iterates: xGMI is point-to-point, the blocks are 8n bytes, and the stores ride along with the launch.
+ *   qpn_shared_alloc   zeroed device buffer on ctx's GPU + its 64-byte IPC handle, to be sent to the peers by any
+ *                      host channel (torch.distributed all_gather_object, MPI, a pipe, ...)
+ *   qpn_shared_open    map a peer's buffer into this process (hipIpcOpenMemHandle); qpn_shared_close unmaps
+ *   qpn_shared_free    release a buffer from qpn_shared_alloc (peers must have closed it)
+ *   qpn_set_primal_mirrors  own = this rank's iterate buffer ([bytes], from qpn_shared_alloc), peers[k] = the
+ *                      k-th peer's buffer as opened here (count <= QPN_MAX_MIRRORS; count = 0 clears).  Later
+ *                      qpn_solve_nodes_into calls (device memory) whose x lies inside own[] also write
+ *                      peers[k] + (x - own).  The stores are complete when the launch is; the CALLER orders
+ *                      them against the peers' next reads (one barrier / tiny all-reduce per sweep). */
+#define QPN_MAX_MIRRORS 7
+#define QPN_IPC_HANDLE_BYTES 64
+#define QPN_SHARED_FINE_GRAINED 1 /* qpn_shared_alloc flag: fine-grained (in-kernel cross-GPU visibility), for mailboxes */
+int qpn_shared_alloc(qpn_ctx *ctx, size_t bytes, int flags, void **dev_ptr, uint8_t *handle);
+int qpn_shared_open(qpn_ctx *ctx, const uint8_t *handle, void **dev_ptr);
+int qpn_shared_close(qpn_ctx *ctx, void *dev_ptr);
+int qpn_shared_free(qpn_ctx *ctx, void *dev_ptr);
+int qpn_set_primal_mirrors(qpn_ctx *ctx, const double *own, size_t bytes, int32_t count, double *const *peers);
+
+/* Per-sweep stop / raise decision (the reference ends a sweep with solved = false when any solve of the level
+ * failed, src/algorithm.jl:95-109, src/avi.jl:426): out[0] = number of items with status != QPN_SUCCESS,
+ * out[1] = max resid (NaN if any), out[2] = 1.  status/resid/out in device memory, one small launch, no host sync.
+ * With world > 1 the pair is combined over all ranks (sum, max) WITHOUT a collective: boxes[r] is rank r's
+ * mailbox (QPN_SWEEP_BOX_BYTES, from qpn_shared_alloc(QPN_SHARED_FINE_GRAINED), opened here; boxes[rank] the own
+ * one); each rank posts its pair into every mailbox and waits until its own holds all `world` posts of this
+ * `epoch` (the caller counts sweeps: 1, 2, 3, ... -- identical on all ranks).  Because it is enqueued after the
+ * solve on the same stream, it is also the barrier that orders the solve's replica stores
+ * (qpn_set_primal_mirrors) against the peers' next reads.  A peer that does not arrive within timeout_ms gives
+ * out[2] = 0 (out[0..1] then cover the ranks that did). */
+#define QPN_SWEEP_BOX_BYTES 512
+int qpn_sweep_status(qpn_ctx *ctx, const int32_t *status, const double *resid, int32_t count, double *out,
+                     int32_t rank, int32_t world, void *const *boxes, uint64_t epoch, int32_t timeout_ms);
+
 /* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
  *   xd [batch][n] current decision values, w as above.
  *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower

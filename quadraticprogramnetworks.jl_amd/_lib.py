@@ -16,10 +16,16 @@ ABI_SYMBOLS = (
     "qpn_solve_avi_batch", "qpn_solve_mcp_csc", "qpn_check_avi_batch", "qpn_comp_indices",
     "qpn_assemble_nodes", "qpn_solve_nodes", "qpn_solve_nodes_into", "qpn_order_nodes_by_pivots",
     "qpn_set_node_order", "qpn_verify_nodes",
+    "qpn_shared_alloc", "qpn_shared_open", "qpn_shared_close", "qpn_shared_free", "qpn_set_primal_mirrors",
+    "qpn_sweep_status",
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
 AVI_FLAG_COLD_START = 1
+MAX_MIRRORS = 7
+IPC_HANDLE_BYTES = 64
+SHARED_FINE_GRAINED = 1
+SWEEP_BOX_BYTES = 512
 
 
 class LibraryMissing(RuntimeError):
@@ -81,6 +87,13 @@ def load_library():
     lib.qpn_set_node_order.argtypes = [vp, vp, C.c_int32, C.c_int]
     lib.qpn_verify_nodes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
+    lib.qpn_shared_alloc.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp), vp]
+    lib.qpn_shared_open.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.qpn_shared_close.argtypes = [vp, vp]
+    lib.qpn_shared_free.argtypes = [vp, vp]
+    lib.qpn_set_primal_mirrors.argtypes = [vp, vp, C.c_size_t, C.c_int32, C.POINTER(vp)]
+    lib.qpn_sweep_status.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_uint64,
+                                     C.c_int32]
     for s in ABI_SYMBOLS:
         f = getattr(lib, s)
         if f.restype is C.c_int and s not in ("qpn_abi_version",):

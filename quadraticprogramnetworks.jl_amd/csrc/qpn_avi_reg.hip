@@ -795,7 +795,11 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
 
     if (act) {
         a.z[vo + lane] = zk;
-        if (a.x && lane < a.nd.n) a.x[(size_t)b * (size_t)a.stride_x + lane] = zk;   // qpn_solve_nodes_into
+        if (a.x && lane < a.nd.n) {                                                   // qpn_solve_nodes_into
+            const size_t xo = (size_t)b * (size_t)a.stride_x + lane;
+            a.x[xo] = zk;
+            for (int k = 0; k < a.n_mirror; ++k) a.mirror[k][xo] = zk;
+        }
         if (a.active) a.active[vo + lane] = (uint8_t)mask;
     }
     if (lane == 0) {

@@ -869,7 +869,12 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     if (bad > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
     if (act) {
         ae.z[vo + l] = zk;
-        if (ae.x && l < n) ae.x[(size_t)b * (size_t)ae.stride_x + l] = zk;      // primal block -> the caller's iterate
+        if (ae.x && l < n) {                                                    // primal block -> the caller's iterate
+            const size_t xo = (size_t)b * (size_t)ae.stride_x + l;
+            ae.x[xo] = zk;
+            const int nmir = kp->n_mirror;                                      // ... and its replicas on the peer GPUs
+            for (int k = 0; k < nmir; ++k) kp->mirror[k][xo] = zk;
+        }
         if (ae.active) ae.active[vo + l] = (uint8_t)mask;
     }
     if (l == 0) {

@@ -21,6 +21,11 @@ struct qpn_ctx {
     int32_t *order = nullptr;
     int32_t order_count = 0;      // 0 = no hint installed
     int32_t order_cap = 0;
+    // replicas of the iterate on peer GPUs (qpn_set_primal_mirrors)
+    const double *mirror_own = nullptr;
+    size_t mirror_bytes = 0;
+    int32_t mirror_count = 0;
+    double *mirror_peer[QPN_MAX_MIRRORS] = {};
 };
 
 namespace {
@@ -488,6 +493,15 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
     const bool x_dev = x && mem == QPN_MEM_DEVICE;
     if (x_dev && mfma_shape) { a.x = x; a.stride_x = stride_x; }      // written by the solve kernels themselves
+    // replicas on peer GPUs: only when the whole written range lies inside the registered buffer
+    const size_t x_span = x ? ((size_t)(batch - 1) * (size_t)stride_x + (size_t)n) * 8 : 0;
+    const bool mirrored = x_dev && ctx->mirror_count > 0 && (const char *)x >= (const char *)ctx->mirror_own &&
+                          (const char *)x + x_span <= (const char *)ctx->mirror_own + ctx->mirror_bytes;
+    const ptrdiff_t x_off = mirrored ? x - ctx->mirror_own : 0;
+    if (mirrored && mfma_shape) {
+        a.n_mirror = ctx->mirror_count;
+        for (int k = 0; k < ctx->mirror_count; ++k) a.mirror[k] = ctx->mirror_peer[k] + x_off;
+    }
     if (mfma_shape && ctx->order_count == batch) a.order = ctx->order;      // schedule hint (longest first)
     if (mfma_shape) {
         // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
@@ -506,9 +520,13 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
         if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
         else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
     }
-    if (x_dev && !mfma_shape)       // general sizes: strided device copy of the primal blocks
+    if (x_dev && !mfma_shape) {     // general sizes: strided device copy of the primal blocks (and to the replicas)
         HIPCHK(ctx, hipMemcpy2DAsync(x, (size_t)stride_x * 8, dz, (size_t)N * 8, (size_t)n * 8, (size_t)batch,
                                      hipMemcpyDeviceToDevice, s));
+        for (int k = 0; mirrored && k < ctx->mirror_count; ++k)
+            HIPCHK(ctx, hipMemcpy2DAsync(ctx->mirror_peer[k] + x_off, (size_t)stride_x * 8, dz, (size_t)N * 8,
+                                         (size_t)n * 8, (size_t)batch, hipMemcpyDefault, s));
+    }
     if (mem == QPN_MEM_HOST) {
         HIPCHK(ctx, hipMemcpyAsync(z, dz, bN * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipMemcpyAsync(status, dst, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
@@ -520,6 +538,103 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
             for (int32_t b = 0; b < batch; ++b)
                 for (int32_t i = 0; i < n; ++i) x[(size_t)b * (size_t)stride_x + i] = z[(size_t)b * N + i];
     }
+    return QPN_OK;
+}
+
+// ---- multi-GPU: shared iterate buffers and their replicas ------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) == QPN_IPC_HANDLE_BYTES, "IPC handle size");
+
+int qpn_shared_alloc(qpn_ctx *ctx, size_t bytes, int flags, void **dev_ptr, uint8_t *handle)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!dev_ptr || !handle || bytes == 0) return fail_arg(ctx, "qpn_shared_alloc: null pointer or zero size");
+    if (flags & ~QPN_SHARED_FINE_GRAINED) return fail_arg(ctx, "qpn_shared_alloc: unknown flag");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (flags & QPN_SHARED_FINE_GRAINED) HIPCHK(ctx, hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    else HIPCHK(ctx, hipMalloc(&p, bytes));
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); return fail_hip(ctx, e, "hipIpcGetMemHandle"); }
+    e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(p); return fail_hip(ctx, e, "qpn_shared_alloc: clear"); }
+    memcpy(handle, &h, sizeof h);
+    *dev_ptr = p;
+    return QPN_OK;
+}
+
+int qpn_shared_open(qpn_ctx *ctx, const uint8_t *handle, void **dev_ptr)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!dev_ptr || !handle) return fail_arg(ctx, "qpn_shared_open: null pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    void *p = nullptr;
+    HIPCHK(ctx, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *dev_ptr = p;
+    return QPN_OK;
+}
+
+int qpn_shared_close(qpn_ctx *ctx, void *dev_ptr)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!dev_ptr) return QPN_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < ctx->mirror_count; ++k)
+        if ((void *)ctx->mirror_peer[k] == dev_ptr) { ctx->mirror_count = 0; break; }   // never leave a dangling replica
+    HIPCHK(ctx, hipIpcCloseMemHandle(dev_ptr));
+    return QPN_OK;
+}
+
+int qpn_shared_free(qpn_ctx *ctx, void *dev_ptr)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!dev_ptr) return QPN_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((const void *)ctx->mirror_own == dev_ptr) { ctx->mirror_count = 0; ctx->mirror_own = nullptr; ctx->mirror_bytes = 0; }
+    HIPCHK(ctx, hipFree(dev_ptr));
+    return QPN_OK;
+}
+
+int qpn_set_primal_mirrors(qpn_ctx *ctx, const double *own, size_t bytes, int32_t count, double *const *peers)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (count < 0 || count > QPN_MAX_MIRRORS) return fail_arg(ctx, "qpn_set_primal_mirrors: count outside 0..QPN_MAX_MIRRORS");
+    if (count > 0 && (!own || !peers || bytes == 0)) return fail_arg(ctx, "qpn_set_primal_mirrors: null pointer");
+    for (int k = 0; k < count; ++k)
+        if (!peers[k] || peers[k] == own) return fail_arg(ctx, "qpn_set_primal_mirrors: null or self peer");
+    ctx->mirror_count = 0;
+    ctx->mirror_own = count ? own : nullptr;
+    ctx->mirror_bytes = count ? bytes : 0;
+    for (int k = 0; k < count; ++k) ctx->mirror_peer[k] = peers[k];
+    ctx->mirror_count = count;
+    return QPN_OK;
+}
+
+static_assert(QPN_SWEEP_BOX_BYTES == 2 * QPN_MAX_RANKS * 32, "mailbox = 2 parities x QPN_MAX_RANKS slots of 32 B");
+
+int qpn_sweep_status(qpn_ctx *ctx, const int32_t *status, const double *resid, int32_t count, double *out,
+                     int32_t rank, int32_t world, void *const *boxes, uint64_t epoch, int32_t timeout_ms)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!status || !out || count < 0) return fail_arg(ctx, "qpn_sweep_status: bad arguments");
+    if (world > QPN_MAX_RANKS) return fail_arg(ctx, "qpn_sweep_status: world > QPN_MAX_MIRRORS + 1");
+    SweepBoxes bx{};
+    if (world > 1) {
+        if (rank < 0 || rank >= world || !boxes || epoch == 0 || timeout_ms <= 0)
+            return fail_arg(ctx, "qpn_sweep_status: bad rank / boxes / epoch / timeout");
+        for (int r = 0; r < world; ++r) {
+            if (!boxes[r]) return fail_arg(ctx, "qpn_sweep_status: null mailbox");
+            bx.box[r] = boxes[r];
+        }
+    } else { world = 1; rank = 0; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, qpn_launch_sweep_status(status, resid, count, out, rank, world, bx, epoch,
+                                        (unsigned long long)timeout_ms * 100000ull, ctx->stream));   // 100 MHz wall clock
     return QPN_OK;
 }
 

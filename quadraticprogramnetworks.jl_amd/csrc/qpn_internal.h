@@ -46,6 +46,10 @@ struct AviBatchArgs {
     // optional scatter of the primal block z[b][0..nd.n) into x[b * stride_x + i] (qpn_solve_nodes_into)
     double *x;
     int64_t stride_x;
+    // replicas of the iterate on peer GPUs (qpn_set_primal_mirrors): every primal block stored to x[off] is
+    // also stored to mirror[k][off], k < n_mirror -- plain stores over xGMI, no collective
+    int32_t n_mirror;
+    double *mirror[QPN_MAX_MIRRORS];
     // optional schedule of the fused node kernel: wavefront i solves node order[i] (a permutation)
     const int32_t *order;
     // large-item kernel only: per-item size override (items of different N <= this->N in one launch; vectors
@@ -85,6 +89,12 @@ hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream); 
 
 // qpn_kkt.hip
 hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int32_t *order, hipStream_t stream);
+// per-sweep status pair, optionally exchanged through the ranks' mailboxes (box[r] = rank r's mailbox as mapped here)
+#define QPN_MAX_RANKS (QPN_MAX_MIRRORS + 1)
+struct SweepBoxes { void *box[QPN_MAX_RANKS]; };
+hipError_t qpn_launch_sweep_status(const int32_t *status, const double *resid, int32_t count, double *out,
+                                   int32_t rank, int32_t world, const SweepBoxes &boxes, unsigned long long epoch,
+                                   unsigned long long timeout_ticks, hipStream_t stream);
 hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,
                                 const double *q, const double *l, const double *u,
                                 const uint8_t *kind, int64_t stride_kind, const double *z,

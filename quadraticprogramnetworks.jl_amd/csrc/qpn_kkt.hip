@@ -121,7 +121,95 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
     }
 }
 
+// ---- per-sweep stop / raise decision: (items not solved, max residual), optionally combined over ranks ----
+// ONE workgroup.  With world > 1 the local pair is posted into slot [epoch & 1][rank] of every rank's mailbox
+// (fine-grained shared buffers, system-scope release store of the epoch last) and the workgroup then waits until
+// all `world` slots of ITS OWN mailbox carry this epoch: an all-gather of 24 bytes and the barrier that orders
+// the solve kernel's replica stores (earlier on this stream) against the peers' next reads, in one launch.
+// Two slot sets by epoch parity: a rank can be at most one epoch ahead of the slowest reader.  Every wait is
+// bounded by `timeout_ticks` of the 100 MHz wall clock; on expiry out[2] = 0 and the kernel returns.
+struct SweepSlot { double nfail, maxres; unsigned long long epoch, pad; };
+
+__device__ __forceinline__ double wave_max_nan_f64(double v)          // max over the wave; a NaN wins
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || o != o) ? o : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void sweep_status_kernel(const int32_t *status, const double *resid, int32_t count,
+                                                            double *out, int32_t rank, int32_t world,
+                                                            SweepBoxes boxes, unsigned long long epoch,
+                                                            unsigned long long timeout_ticks)
+{
+    __shared__ double s_res[16];
+    __shared__ int s_bad[16];
+    const int t = threadIdx.x;
+    int bad = 0;
+    double mx = 0.0;
+    for (int base = 0; base < count; base += 4096) {                  // 8 loads in flight per thread and pass
+        int st[4];
+        double r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 1024 + t;
+            st[k] = i < count ? status[i] : QPN_SUCCESS;
+            r[k] = (resid && i < count) ? resid[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bad += st[k] != QPN_SUCCESS;
+            mx = (r[k] > mx || r[k] != r[k]) ? r[k] : mx;              // a NaN residual sticks
+        }
+    }
+    bad = wave_sum_i32(bad);
+    mx = wave_max_nan_f64(mx);
+    if ((t & 63) == 0) { s_bad[t >> 6] = bad; s_res[t >> 6] = mx; }
+    __syncthreads();
+    if (t >= 64) return;
+    bad = t < 16 ? s_bad[t] : 0;
+    mx = t < 16 ? s_res[t] : 0.0;
+    bad = wave_sum_i32(bad);
+    mx = wave_max_nan_f64(mx);
+    double nfail = (double)bad;
+    double ok = 1.0;
+    if (world > 1) {
+        const int par = (int)(epoch & 1ull);
+        if (t < world) {                                               // lane t posts to rank t's mailbox (own included)
+            SweepSlot *dst = (SweepSlot *)boxes.box[t] + par * QPN_MAX_RANKS + rank;
+            dst->nfail = nfail;
+            dst->maxres = mx;
+            __hip_atomic_store(&dst->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        double pf = 0.0, pr = 0.0;
+        if (t < world) {                                               // lane t waits for rank t's post in the own mailbox
+            SweepSlot *src = (SweepSlot *)boxes.box[rank] + par * QPN_MAX_RANKS + t;
+            const unsigned long long t0 = wall_clock64();
+            bool seen = false;
+            for (;;) {
+                if (__hip_atomic_load(&src->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) { seen = true; break; }
+                if (wall_clock64() - t0 > timeout_ticks) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (seen) { pf = src->nfail; pr = src->maxres; } else ok = 0.0;
+        }
+        nfail = wave_sum_f64(pf);
+        mx = wave_max_nan_f64(pr);
+        ok = __all(ok != 0.0) ? 1.0 : 0.0;
+    }
+    if (t == 0) { out[0] = nfail; out[1] = mx; out[2] = ok; }
+}
+
 } // namespace
+
+hipError_t qpn_launch_sweep_status(const int32_t *status, const double *resid, int32_t count, double *out,
+                                   int32_t rank, int32_t world, const SweepBoxes &boxes, unsigned long long epoch,
+                                   unsigned long long timeout_ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sweep_status_kernel, dim3(1), dim3(1024), 0, stream, status, resid, count, out, rank, world,
+                       boxes, epoch, timeout_ticks);
+    return hipGetLastError();
+}
 
 hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int32_t *order, hipStream_t stream)
 {

@@ -310,6 +310,49 @@ class Engine:
         self._chk(rc, "qpn_set_node_order")
 
     # -- (A8) ------------------------------------------------------------------------------
+    # -- multi-GPU: shared iterate buffers, replicas, per-sweep status (include/qpn_hip.h) ----------
+    def shared_alloc(self, nbytes, fine_grained=False):
+        """Zeroed device buffer + its IPC handle: (address, handle bytes)."""
+        from ._lib import IPC_HANDLE_BYTES, SHARED_FINE_GRAINED
+        ptr = C.c_void_p()
+        h = (C.c_uint8 * IPC_HANDLE_BYTES)()
+        rc = self.lib.qpn_shared_alloc(self.ctx, int(nbytes), SHARED_FINE_GRAINED if fine_grained else 0,
+                                       C.byref(ptr), h)
+        self._chk(rc, "qpn_shared_alloc")
+        return int(ptr.value), bytes(h)
+
+    def shared_open(self, handle: bytes) -> int:
+        """Map a peer's shared buffer into this process; returns its address here."""
+        ptr = C.c_void_p()
+        h = (C.c_uint8 * len(handle)).from_buffer_copy(handle)
+        self._chk(self.lib.qpn_shared_open(self.ctx, h, C.byref(ptr)), "qpn_shared_open")
+        return int(ptr.value)
+
+    def shared_close(self, addr: int):
+        self._chk(self.lib.qpn_shared_close(self.ctx, C.c_void_p(addr)), "qpn_shared_close")
+
+    def shared_free(self, addr: int):
+        self._chk(self.lib.qpn_shared_free(self.ctx, C.c_void_p(addr)), "qpn_shared_free")
+
+    def set_primal_mirrors(self, own_addr=0, nbytes=0, peer_addrs=()):
+        """Later solve_nodes(x_out=...) calls whose x_out lies inside [own_addr, own_addr + nbytes) also store
+        every primal block at the same offset of each peer buffer.  No arguments: clear."""
+        arr = (C.c_void_p * max(len(peer_addrs), 1))(*[C.c_void_p(a) for a in peer_addrs])
+        rc = self.lib.qpn_set_primal_mirrors(self.ctx, C.c_void_p(own_addr), int(nbytes), len(peer_addrs), arr)
+        self._chk(rc, "qpn_set_primal_mirrors")
+
+    def sweep_status(self, status, resid, out, rank=0, world=1, boxes=None, epoch=0, timeout_ms=1000):
+        """out[0:3] (device fp64) <- (items not solved, max resid, 1), combined over `world` ranks through their
+        mailboxes when world > 1 (also the barrier after the replica stores).  Asynchronous on the stream."""
+        self._bind_stream(True)
+        arr = None
+        if world > 1:
+            arr = (C.c_void_p * world)(*[C.c_void_p(a) for a in boxes])
+        rc = self.lib.qpn_sweep_status(self.ctx, _ptr(status), _ptr(resid), int(status.shape[0]), _ptr(out),
+                                       int(rank), int(world), arr, int(epoch), int(timeout_ms))
+        self._chk(rc, "qpn_sweep_status")
+        return out
+
     def verify_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, xd, w, tol=1e-4):
         """Batched verify_solution (src/qp_processing.jl:57-149) -> (solution, lambda, path)."""
         dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, xd, w)

@@ -2,10 +2,16 @@
 
 One process per GPU.  Rank g owns the contiguous node range [g*B/G, (g+1)*B/G) and assembles its own
 stacked blocks on its own GPU, so no M/q traffic crosses GPUs.  The only exchange per outer sweep is
-the all-gather of the primal blocks (count x n fp64 per rank) so that every rank holds the full
-iterate x for the next sweep's R_i w / B_i w terms -- RCCL over xGMI on the GPU box
-(torch.distributed backend "nccl"), gloo in the CPU tests.  The message is small (config 4:
-320 KB per rank) and latency-bound; one collective per sweep, no per-node messages.
+the primal blocks (count x n fp64 per rank): every rank must hold the full iterate x for the next
+sweep's R_i w / B_i w terms.  Two routes:
+
+* SharedIterate (the GPU route): the iterate lives in one IPC-shared buffer per GPU and the solve
+  kernel itself stores every primal block into all of them (qpn_set_primal_mirrors) -- xGMI is
+  point-to-point and the blocks are 8n bytes, so the exchange rides inside the launch; the sweep ends
+  with qpn_sweep_status, a 24-byte mailbox exchange that is both the stop/raise decision and the
+  barrier.  No collective on the data path.
+* all_gather_primal + all_reduce_status: the same exchange as two collectives (RCCL on the GPU box,
+  gloo in the CPU tests); the fallback when buffers cannot be shared.
 
 What does NOT shard: a single Nash pool is ONE AVI (src/avi.jl:399-400) -- shard over instances
 instead.
@@ -27,6 +33,14 @@ def all_gather_primal(x_all, x_local, ranges, dist):
     `ranges` = [node_range(total, world, r) for r in range(world)].  Equal shard sizes use one
     all_gather_into_tensor straight into x_all (no staging); ragged shards gather padded blocks."""
     sizes = [hi - lo for lo, hi in ranges]
+    if x_local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal only (several ranks on one GPU, host channel gloo): stage through the host
+        import torch
+        got = [None] * len(sizes)
+        dist.all_gather_object(got, x_local.cpu())
+        for (lo, hi), b in zip(ranges, got):
+            x_all[lo:hi].copy_(b.to(x_all.device))
+        return x_all
     if len(set(sizes)) == 1:
         dist.all_gather_into_tensor(x_all, x_local.contiguous())
         return x_all
@@ -49,3 +63,103 @@ def all_reduce_status(n_failed_local: int, max_resid_local: float, device, dist)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(s[0].item()), float(t[1].item())
+
+
+def _device_tensor(addr: int, shape, device):
+    """fp64 torch view of raw device memory owned by the library (qpn_shared_alloc)."""
+    import torch
+
+    class _Mem:
+        pass
+    m = _Mem()
+    m.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f8", "data": (int(addr), False),
+                                  "version": 3, "strides": None}
+    return torch.as_tensor(m, device=device)
+
+
+class SharedIterate:
+    """The iterate x [total, n] (fp64), one replica per rank, kept identical by the solve kernels.
+
+    x            torch view of the replica half the CURRENT sweep writes; pass x[lo:hi] as solve_nodes(x_out=...)
+    finish_sweep(status, resid) -> device tensor [not solved, max resid, all ranks arrived], asynchronous;
+                 after it (in stream order) x_done -- the half just written -- holds all ranks' blocks of this
+                 sweep on every rank, and x flips to the other half.
+    Two halves because a rank may run one sweep ahead of its slowest peer: its next sweep's stores must not land
+    in the buffer that peer still reads (it cannot get two ahead -- finish_sweep waits for everyone).  A sweep
+    that solves only some nodes carries the other rows over itself (x[rows] = x_done[rows]).
+    Handles travel through `dist` (any backend: they are 64-byte host objects)."""
+
+    def __init__(self, eng, dist, total, n, device, timeout_ms=1000):
+        import torch
+        from ._lib import MAX_MIRRORS, SWEEP_BOX_BYTES
+        self.eng, self.dist = eng, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if self.world - 1 > MAX_MIRRORS:
+            raise ValueError(f"SharedIterate: world {self.world} > {MAX_MIRRORS + 1}")
+        self.nbytes = 2 * int(total) * int(n) * 8
+        self.timeout_ms = int(timeout_ms)
+        self.epoch = 0
+        self._opened = []
+        self.addr = self.box = 0
+        # every rank takes part in both handshakes whatever happens locally, and all ranks raise together
+        mine, err = None, None
+        try:
+            self.addr, hx = eng.shared_alloc(self.nbytes)
+            self.box, hb = eng.shared_alloc(SWEEP_BOX_BYTES, fine_grained=True)
+            mine = (hx, hb)
+        except Exception as e:                      # noqa: BLE001 -- reported to all ranks below
+            err = repr(e)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine)
+        self.boxes, peers = [], []
+        if all(h is not None for h in handles):
+            try:
+                for r in range(self.world):
+                    if r == self.rank:
+                        self.boxes.append(self.box)
+                        continue
+                    px = eng.shared_open(handles[r][0]); self._opened.append(px)
+                    pb = eng.shared_open(handles[r][1]); self._opened.append(pb)
+                    peers.append(px); self.boxes.append(pb)
+                eng.set_primal_mirrors(self.addr, self.nbytes, peers)
+            except Exception as e:                  # noqa: BLE001
+                err = repr(e)
+        elif err is None:
+            err = "a peer could not allocate its shared buffers"
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err)
+        if any(e is not None for e in errs):
+            self.close()
+            raise RuntimeError("SharedIterate: " + "; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e))
+        both = _device_tensor(self.addr, (2, total, n), device)
+        self._halves = [both[0], both[1]]
+        self.out = torch.zeros(3, dtype=torch.float64, device=device)
+
+    @property
+    def x(self):
+        return self._halves[self.epoch & 1]
+
+    @property
+    def x_done(self):
+        return self._halves[(self.epoch & 1) ^ 1]
+
+    def finish_sweep(self, status, resid):
+        self.epoch += 1
+        return self.eng.sweep_status(status, resid, self.out, self.rank, self.world, self.boxes, self.epoch,
+                                     self.timeout_ms)
+
+    def close(self):
+        """Collective: unmap the peers' buffers, then (after a barrier) free the own ones."""
+        import torch
+        torch.cuda.synchronize()
+        self.dist.barrier()                          # nobody unmaps while a peer's kernels may still store
+        self.eng.set_primal_mirrors()
+        for a in self._opened:
+            self.eng.shared_close(a)
+        self._opened = []
+        self.dist.barrier()
+        self._halves = []
+        for a in (self.addr, self.box):
+            if a:
+                self.eng.shared_free(a)
+        self.addr = self.box = 0
