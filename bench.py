@@ -101,13 +101,13 @@ def main():
         exchange = "rccl" if args.unfused else args.exchange      # the replica stores belong to the fused kernel
         if exchange == "p2p":
             try:
-                shared = sharding.SharedIterate(eng, dist, total, n, dev)
+                shared = sharding.SharedIterate(eng, dist, total, n, dev, timeout_ms=10_000)
             except RuntimeError as e:              # raised on ALL ranks together
                 if rank == 0:
                     print(f"[bench] p2p exchange unavailable ({e}); using RCCL collectives", file=sys.stderr, flush=True)
                 exchange = "rccl (p2p setup failed)"
     x_all = torch.zeros((total, n), dtype=torch.float64, device=dev) if shared is None else None
-    sweep_out = torch.zeros(3, dtype=torch.float64, device=dev)
+    sweep_out = torch.zeros(4, dtype=torch.float64, device=dev)
     ev_pairs = []
     bufs = {"asm": None, "sol": None}      # output buffers are allocated once and reused
 
@@ -171,6 +171,8 @@ def main():
             for i in range(min(args.warmup, 5)):
                 res = step(False)
             barrier()
+        else:
+            shared.out[3] = 0.0                # early warm-up steps may have met start-up skew; the timed region may not
     # ONE pair of HIP events brackets the whole timed region on the launch stream (a pair per step costs two
     # barrier packets per step, ~10 us of pipeline bubbles -- measured); the per-launch duration reported in
     # "roofline" is elapsed / steps, i.e. it also carries the near-empty fallback launch and the launch gaps
@@ -186,7 +188,7 @@ def main():
     dt = time.perf_counter() - t0
     ev_pairs.append((ev0, ev1))
 
-    sweep_ok = shared is None or float(shared.out[2]) == 1.0
+    sweep_ok = shared is None or float(shared.out[3]) == 0.0        # no barrier of the timed region was missed
     solved_local = int((res["status"] == 1).sum().item()) if sweep_ok else 0      # a missed barrier voids the run
     max_resid = float(res["resid"].max().item())
     tt = torch.tensor([dt, float(solved_local), max_resid], dtype=torch.float64, device=dev)

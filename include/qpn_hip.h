@@ -188,14 +188,16 @@ int qpn_set_primal_mirrors(qpn_ctx *ctx, const double *own, size_t bytes, int32_
 
 /* Per-sweep stop / raise decision (the reference ends a sweep with solved = false when any solve of the level
  * failed, src/algorithm.jl:95-109, src/avi.jl:426): out[0] = number of items with status != QPN_SUCCESS,
- * out[1] = max resid (NaN if any), out[2] = 1.  status/resid/out in device memory, one small launch, no host sync.
+ * out[1] = max resid (NaN if any), out[2] = 1; out has 4 doubles.  status/resid/out in device memory, one small
+ * launch, no host sync.
  * With world > 1 the pair is combined over all ranks (sum, max) WITHOUT a collective: boxes[r] is rank r's
  * mailbox (QPN_SWEEP_BOX_BYTES, from qpn_shared_alloc(QPN_SHARED_FINE_GRAINED), opened here; boxes[rank] the own
  * one); each rank posts its pair into every mailbox and waits until its own holds all `world` posts of this
  * `epoch` (the caller counts sweeps: 1, 2, 3, ... -- identical on all ranks).  Because it is enqueued after the
  * solve on the same stream, it is also the barrier that orders the solve's replica stores
  * (qpn_set_primal_mirrors) against the peers' next reads.  A peer that does not arrive within timeout_ms gives
- * out[2] = 0 (out[0..1] then cover the ranks that did). */
+ * out[2] = 0 (out[0..1] then cover the ranks that did) and out[3] += 1 -- a sticky count of missed barriers that the
+ * caller zeroes and reads whenever it likes. */
 #define QPN_SWEEP_BOX_BYTES 512
 int qpn_sweep_status(qpn_ctx *ctx, const int32_t *status, const double *resid, int32_t count, double *out,
                      int32_t rank, int32_t world, void *const *boxes, uint64_t epoch, int32_t timeout_ms);

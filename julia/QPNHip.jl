@@ -136,6 +136,65 @@ function order_nodes_by_pivots!(pivots::Vector{Int32})
 end
 clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), C_NULL, Int32(0), QPN_MEM_HOST); nothing)
 
+# ---- multi-GPU (one Julia process per GPU, e.g. under MPI.jl / Distributed): replicas of the iterate ----
+# The ABI works on DEVICE pointers here (the host-array routes above stage through the library's workspace):
+# `x_dev` below is an address inside a buffer from `shared_alloc`, e.g. wrapped by AMDGPU.jl's unsafe_wrap.
+const QPN_IPC_HANDLE_BYTES = 64
+const QPN_SHARED_FINE_GRAINED = Cint(1)
+const QPN_SWEEP_BOX_BYTES = 512
+
+"""
+    shared_alloc(nbytes; fine_grained=false) -> (ptr::Ptr{Cvoid}, handle::Vector{UInt8})
+
+Zeroed device buffer on this process's GPU and its IPC handle; send the handle to the peer processes
+(MPI.Allgather, a socket, ...) and `shared_open` it there.
+"""
+function shared_alloc(nbytes::Integer; fine_grained::Bool = false)
+    p = Ref{Ptr{Cvoid}}(C_NULL); h = zeros(UInt8, QPN_IPC_HANDLE_BYTES)
+    rc = ccall((:qpn_shared_alloc, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Ref{Ptr{Cvoid}}, Ptr{UInt8}),
+               ctx(), Csize_t(nbytes), fine_grained ? QPN_SHARED_FINE_GRAINED : Cint(0), p, h)
+    rc == 0 || error("qpn_shared_alloc failed")
+    (p[], h)
+end
+function shared_open(handle::Vector{UInt8})
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:qpn_shared_open, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ref{Ptr{Cvoid}}), ctx(), handle, p) == 0 || error("qpn_shared_open failed")
+    p[]
+end
+shared_close(p::Ptr{Cvoid}) = (ccall((:qpn_shared_close, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), p); nothing)
+shared_free(p::Ptr{Cvoid}) = (ccall((:qpn_shared_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), p); nothing)
+
+"""
+    set_primal_mirrors!(own, nbytes, peers)
+
+Later device-memory `qpn_solve_nodes_into` calls whose `x` lies inside `own` also store every primal block at the
+same offset of each peer buffer (at most 7).  `set_primal_mirrors!()` clears.
+"""
+function set_primal_mirrors!(own::Ptr{Cvoid} = C_NULL, nbytes::Integer = 0, peers::Vector{Ptr{Cvoid}} = Ptr{Cvoid}[])
+    rc = ccall((:qpn_set_primal_mirrors, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Int32, Ptr{Ptr{Cvoid}}),
+               ctx(), own, Csize_t(nbytes), Int32(length(peers)), peers)
+    rc == 0 || error("qpn_set_primal_mirrors failed")
+    nothing
+end
+
+"""
+    sweep_status!(out_dev, status_dev, resid_dev, count; rank=0, boxes=Ptr{Cvoid}[], epoch=0, timeout_ms=1000)
+
+`out_dev[1:4]` (device) <- (items not solved, max resid, all ranks arrived, missed barriers so far), combined over
+`length(boxes)` ranks through their mailboxes (each `QPN_SWEEP_BOX_BYTES`, `shared_alloc(...; fine_grained=true)`).
+Asynchronous; enqueued after the solve it is also the barrier that completes the replicas (src/algorithm.jl:95-109).
+"""
+function sweep_status!(out_dev::Ptr{Cvoid}, status_dev::Ptr{Cvoid}, resid_dev::Ptr{Cvoid}, count::Integer;
+                       rank::Integer = 0, boxes::Vector{Ptr{Cvoid}} = Ptr{Cvoid}[], epoch::Integer = 0, timeout_ms::Integer = 1000)
+    world = max(length(boxes), 1)
+    rc = ccall((:qpn_sweep_status, LIB), Cint,
+               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, UInt64, Int32),
+               ctx(), status_dev, resid_dev, Int32(count), out_dev, Int32(rank), Int32(world),
+               world > 1 ? pointer(boxes) : Ptr{Ptr{Cvoid}}(C_NULL), UInt64(epoch), Int32(timeout_ms))
+    rc == 0 || error("qpn_sweep_status failed")
+    nothing
+end
+
 # ---- drop-in bodies -------------------------------------------------------------------------------
 # src/avi.jl:63-77 with the PATH call replaced; StatusCode / check_avi_solution stay the reference's.
 function solve_avi_hip(QPN, avi, z0, w; convergence_tolerance = 1e-10)

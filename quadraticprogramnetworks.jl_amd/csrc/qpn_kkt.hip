@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
 // all `world` slots of ITS OWN mailbox carry this epoch: an all-gather of 24 bytes and the barrier that orders
 // the solve kernel's replica stores (earlier on this stream) against the peers' next reads, in one launch.
 // Two slot sets by epoch parity: a rank can be at most one epoch ahead of the slowest reader.  Every wait is
-// bounded by `timeout_ticks` of the 100 MHz wall clock; on expiry out[2] = 0 and the kernel returns.
+// bounded by `timeout_ticks` of the 100 MHz wall clock; on expiry out[2] = 0, out[3] += 1 and the kernel returns.
 struct SweepSlot { double nfail, maxres; unsigned long long epoch, pad; };
 
 __device__ __forceinline__ double wave_max_nan_f64(double v)          // max over the wave; a NaN wins
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void sweep_status_kernel(const int32_t *statu
             const unsigned long long t0 = wall_clock64();
             bool seen = false;
             for (;;) {
-                if (__hip_atomic_load(&src->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) { seen = true; break; }
+                if (__hip_atomic_load(&src->epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) { seen = true; break; }
                 if (wall_clock64() - t0 > timeout_ticks) break;
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void sweep_status_kernel(const int32_t *statu
         mx = wave_max_nan_f64(pr);
         ok = __all(ok != 0.0) ? 1.0 : 0.0;
     }
-    if (t == 0) { out[0] = nfail; out[1] = mx; out[2] = ok; }
+    if (t == 0) { out[0] = nfail; out[1] = mx; out[2] = ok; if (ok == 0.0) out[3] += 1.0; }
 }
 
 } // namespace

@@ -342,8 +342,9 @@ class Engine:
         self._chk(rc, "qpn_set_primal_mirrors")
 
     def sweep_status(self, status, resid, out, rank=0, world=1, boxes=None, epoch=0, timeout_ms=1000):
-        """out[0:3] (device fp64) <- (items not solved, max resid, 1), combined over `world` ranks through their
-        mailboxes when world > 1 (also the barrier after the replica stores).  Asynchronous on the stream."""
+        """out[0:3] (device fp64, 4 entries) <- (items not solved, max resid, 1), combined over `world` ranks
+        through their mailboxes when world > 1 (also the barrier after the replica stores); a missed barrier gives
+        out[2] = 0 and out[3] += 1.  Asynchronous on the stream."""
         self._bind_stream(True)
         arr = None
         if world > 1:

@@ -81,7 +81,7 @@ class SharedIterate:
     """The iterate x [total, n] (fp64), one replica per rank, kept identical by the solve kernels.
 
     x            torch view of the replica half the CURRENT sweep writes; pass x[lo:hi] as solve_nodes(x_out=...)
-    finish_sweep(status, resid) -> device tensor [not solved, max resid, all ranks arrived], asynchronous;
+    finish_sweep(status, resid) -> device tensor [not solved, max resid, all ranks arrived, missed barriers so far], asynchronous;
                  after it (in stream order) x_done -- the half just written -- holds all ranks' blocks of this
                  sweep on every rank, and x flips to the other half.
     Two halves because a rank may run one sweep ahead of its slowest peer: its next sweep's stores must not land
@@ -133,7 +133,7 @@ class SharedIterate:
             raise RuntimeError("SharedIterate: " + "; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e))
         both = _device_tensor(self.addr, (2, total, n), device)
         self._halves = [both[0], both[1]]
-        self.out = torch.zeros(3, dtype=torch.float64, device=device)
+        self.out = torch.zeros(4, dtype=torch.float64, device=device)     # [not solved, max resid, arrived, missed barriers]
 
     @property
     def x(self):

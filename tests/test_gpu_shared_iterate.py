@@ -70,13 +70,13 @@ def test_sweep_status_local_and_timeout(engine):
     from qpn_amd._lib import SWEEP_BOX_BYTES
     st = torch.ones(10_000, dtype=torch.int32, device="cuda:0")
     rs = torch.rand(10_000, dtype=torch.float64, device="cuda:0") * 1e-9
-    out = torch.full((3,), -1.0, dtype=torch.float64, device="cuda:0")
+    out = torch.full((4,), -1.0, dtype=torch.float64, device="cuda:0"); out[3] = 0.0
     engine.sweep_status(st, rs, out)
-    assert out.tolist() == [0.0, float(rs.max()), 1.0]
+    assert out.tolist() == [0.0, float(rs.max()), 1.0, 0.0]
     st[17] = 4; st[9_999] = 3; rs[5] = float("nan")
     engine.sweep_status(st, rs, out)
     o = out.tolist()
-    assert o[0] == 2.0 and np.isnan(o[1]) and o[2] == 1.0
+    assert o[0] == 2.0 and np.isnan(o[1]) and o[2:] == [1.0, 0.0]
     # two "ranks" whose peer never posts: the wait is bounded and reported
     b0, _ = engine.shared_alloc(SWEEP_BOX_BYTES, fine_grained=True)
     b1, _ = engine.shared_alloc(SWEEP_BOX_BYTES, fine_grained=True)
@@ -84,15 +84,15 @@ def test_sweep_status_local_and_timeout(engine):
         rs[5] = 0.0
         engine.sweep_status(st, rs, out, rank=0, world=2, boxes=[b0, b1], epoch=1, timeout_ms=20)
         torch.cuda.synchronize()
-        assert out.tolist()[2] == 0.0 and out.tolist()[0] == 2.0
+        assert out.tolist()[2:] == [0.0, 1.0] and out.tolist()[0] == 2.0
         # the peer posts (same process, its own call): both sides now complete and agree
         st1 = torch.ones(50, dtype=torch.int32, device="cuda:0"); st1[3] = 2
         rs1 = torch.full((50,), 0.5, dtype=torch.float64, device="cuda:0")
-        out1 = torch.zeros(3, dtype=torch.float64, device="cuda:0")
+        out1 = torch.zeros(4, dtype=torch.float64, device="cuda:0")
         engine.sweep_status(st1, rs1, out1, rank=1, world=2, boxes=[b0, b1], epoch=1, timeout_ms=2000)
         engine.sweep_status(st, rs, out, rank=0, world=2, boxes=[b0, b1], epoch=1, timeout_ms=2000)
         torch.cuda.synchronize()
-        assert out.tolist() == [3.0, 0.5, 1.0] and out1.tolist() == [3.0, 0.5, 1.0]
+        assert out.tolist() == [3.0, 0.5, 1.0, 1.0] and out1.tolist() == [3.0, 0.5, 1.0, 0.0]
     finally:
         engine.shared_free(b0); engine.shared_free(b1)
 
@@ -135,11 +135,11 @@ def _rank_main(rank, world, port, total, n, m, sweeps, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total,n,m", [(2000, 32, 32), (333, 9, 6)])
-def test_two_ranks_share_the_iterate(engine, tmp_path, total, n, m):
+@pytest.mark.parametrize("world,total,n,m", [(2, 2000, 32, 32), (2, 333, 9, 6), (4, 4001, 32, 32)])
+def test_ranks_share_the_iterate(engine, tmp_path, world, total, n, m):
     import torch
     import torch.multiprocessing as mp
-    world, sweeps = 2, 3
+    sweeps = 3
     mp.spawn(_rank_main, args=(world, _free_port(), total, n, m, sweeps, str(tmp_path)), nprocs=world, join=True)
     got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     # expectation: the same sweeps in this process, all nodes at once
@@ -157,5 +157,5 @@ def test_two_ranks_share_the_iterate(engine, tmp_path, total, n, m):
         for r in range(world):
             assert np.array_equal(got[r][f"x{s}"], x), (s, r)                 # every replica, bit for bit
             o = got[r][f"o{s}"]
-            assert o[0] == 0.0 and o[2] == 1.0 and o[1] == float(res["resid"].max())
+            assert o[0] == 0.0 and o[2] == 1.0 and o[3] == 0.0 and o[1] == float(res["resid"].max())
         assert max(float(got[r][f"r{s}"]) for r in range(world)) == got[0][f"o{s}"][1]
