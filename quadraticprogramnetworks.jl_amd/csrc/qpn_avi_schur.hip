@@ -169,7 +169,12 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
 
     // ---- structure test: leading free STD rows, then GAVI rows -------------------------------------
     int n, m;
-    {
+    if constexpr (NODES) {
+        // a node record IS of that shape (n free rows, then m GAVI rows): nothing to read, so the block loads
+        // below are the first memory round trip of the wave
+        n = nn; m = nm;
+        if (!(n + m == N && n <= 32 && m <= 32 && n >= 1)) { if (l == 0) a.status[b] = -1; return; }
+    } else {
         double lk, uk; int gk;
         row_bounds(lk, uk, gk);
         const bool isfree = act && !gk && lk == -QINF && uk == QINF;
@@ -392,6 +397,11 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         SB(0, 0) = MFMA(a0_, TL(I, 2)[g], SB(0, 0)); SB(0, 1) = MFMA(a0_, TL(I, 3)[g], SB(0, 1));   \
         SB(1, 0) = MFMA(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = MFMA(a1_, TL(I, 3)[g], SB(1, 1));   \
     }
+    // bounds of pair l for Stage B: requested here so that the round trip hides behind the 32 MFMAs
+    double lo_pre = -QINF, hi_pre = QINF;
+    if constexpr (NODES) {
+        if (l < m) { lo_pre = a.nd.l[(size_t)b * nm + l]; hi_pre = a.nd.u[(size_t)b * nm + l]; }
+    }
     M_SK(0, 0, 0) M_SK(0, 1, 1) M_SK(0, 2, 2) M_SK(0, 3, 3) M_SK(1, 0, 4) M_SK(1, 1, 5) M_SK(1, 2, 6) M_SK(1, 3, 7)
 #undef M_SK
     wave_sync();
@@ -457,10 +467,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     double lo = -QINF, hi = QINF;
     {
         const int it = l < m ? n + l : -1;
-        if (actb && it >= 0) {
-            if constexpr (NODES) { lo = a.nd.l[(size_t)b * nm + l]; hi = a.nd.u[(size_t)b * nm + l]; }
-            else { lo = a.l[vo + it]; hi = a.u[vo + it]; }
-        }
+        if constexpr (NODES) { lo = lo_pre; hi = hi_pre; }
+        else if (actb && it >= 0) { lo = a.l[vo + it]; hi = a.u[vo + it]; }
     }
     // equality GAVI rows need their multiplier crashed in: left to the general kernel
     if (__ballot(actb && lo == hi)) { if (l == 0) a.status[b] = -1; return; }
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         const double arc = fabs(rc);                              // = cndlo ? -rc : rc on every candidate row
         const double dd = (cndlo ? xb - lo : hi - xb) * arc;
         const double d1 = fma(slack, arc, dd);
-        const double dmax = min_f64_nc(wave_min32_all_f64(cnd ? d1 : QINF), self_lim);      // uniform over lanes 0..31, in a VGPR
+        const double dmax = min_f64_nc(wave_min32_all_lowlat_f64(cnd ? d1 : QINF), self_lim);      // uniform over lanes 0..31, in a VGPR
         if (__ballot(actb && dmax == QINF) != 0ull) { status = QPN_RAY_TERM; break; }
         const unsigned long long bal = __ballot(cnd && dd <= dmax);
         // Both outcomes below end in the SAME exchange block (a bound flip runs it with v = 0 and empty lane
@@ -654,6 +662,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             }
             STAMP(4);
         }
+        // the exchange's column operands: requested here so that the LDS trip overlaps the write-backs below
+        const d4 ua = *reinterpret_cast<const d4 *>(sucol + lq * 8);
+        const d4 ub = *reinterpret_cast<const d4 *>(sucol + lq * 8 + 4);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- write-back of the single-lane bookkeeping updates
         rowvar = writelane_i32(rowvar, rW, veW); lo = writelane_f64(lo, rW, eloW); hi = writelane_f64(hi, rW, ehiW);
         colvar = writelane_i32(colvar, cW, vlW);
@@ -662,8 +674,6 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         if (stop) break;
         // ---- the exchange on the 32 x 32 dictionary (see the header of this stage)
         {
-            const d4 ua = *reinterpret_cast<const d4 *>(sucol + lq * 8);
-            const d4 ub = *reinterpret_cast<const d4 *>(sucol + lq * 8 + 4);
             const double nv0 = -v0, nv1 = -v1;
             cx = uni(cx); rsel = uni(rsel);
             asm volatile(
@@ -751,6 +761,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             gk_ = (act && ae.kind) ? (int)ae.kind[(size_t)b * (size_t)ae.stride_kind + l] : 0;
         }
     };
+    // ---- post-check operands requested first: the bounds of item row l and (n = 32) this lane's 32 entries of
+    // Qd, so that the round trip hides behind the read-back below instead of four short ones in the check loop
+    double lk, uk; int gk;
+    row_bounds_e(lk, uk, gk);
+    double mq32[32];
+    if constexpr (NODES) {
+        if (nn == 32) {
+            const double *qc = Qe_ + (l < 32 ? l : 0);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) mq32[j] = qc[(size_t)j * 32];
+        }
+    }
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
     wave_sync();
     if (actb) sval[rowvar] = xb;
@@ -793,8 +815,6 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     wave_sync();
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
-    double lk, uk; int gk;
-    row_bounds_e(lk, uk, gk);
     double rk;
     if constexpr (NODES) {
         // r = q + M z, item columns in ascending order (finite blocks: a zero z_j contributes exactly
@@ -808,6 +828,15 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         const int aoff = isx ? 0 : ls, roff = (isx ? ls : 0) * SAS;   // column of Ad (constraint rows) / row of Ad' (x rows)
         double rq = SQ(l), ra = rq;
         int j = 0;
+        if (nn == 32) {
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                const double zj = sz[jj];
+                rq = fma(mq32[jj], zj, rq);
+                ra = fma(sA[jj * SAS + aoff], zj, ra);
+            }
+            j = 32;
+        }
         for (; j + 8 <= nn; j += 8) {
             double mq[8];
 #pragma unroll

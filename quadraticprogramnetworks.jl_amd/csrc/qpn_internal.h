@@ -256,6 +256,16 @@ __device__ __forceinline__ double wave_min32_all_f64(double v)
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
     return min_f64_nc(v, __hiloint2double(hi, lo));
 }
+// the same minimum with the row crossing through v_readlane (two SGPR pairs) instead of the LDS crossbar: a few
+// more instructions, but ~100 cycles less latency -- for loops whose waves wait on dependent chains, not on issue
+__device__ __forceinline__ double wave_min32_all_lowlat_f64(double v)
+{
+    v = min_f64_nc(v, dpp_f64<0xB1>(v));
+    v = min_f64_nc(v, dpp_f64<0x4E>(v));
+    v = min_f64_nc(v, dpp_f64<0x141>(v));
+    v = min_f64_nc(v, dpp_f64<0x140>(v));
+    return min_f64_nc(readlane_f64(v, 0), readlane_f64(v, 16));
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
 #pragma unroll
