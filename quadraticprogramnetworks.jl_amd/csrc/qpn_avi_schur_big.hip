@@ -406,7 +406,8 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
     __syncthreads();
 
     int pivots = 0, status = QPN_FAILURE, npend = 0;
-    const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * a.N + 100;
+    // the budget counts the n crash pivots of stage A too (`pivots` here counts this kernel's own)
+    const int max_piv = (a.max_pivots > 0 ? a.max_pivots : 50 * (a.n_items ? a.n_items[b] : a.N) + 100) - w.nsplit[b];
     int c = XC;
     bool sneg = true;
     double self_lim = 0.0, elo = 0.0, ehi = QINF;
