@@ -147,32 +147,47 @@ def main():
         if use_sched and res is not None and (i == 1 or i % REFRESH == 0):      # first sweep's counts, then periodically
             eng.order_nodes_by_pivots(res["pivots"])
 
+    def p2p_ok():
+        """Self-check of the p2p route (outside the timed region): every replica equals what a collective all-gather of
+        the same blocks gives, and the last mailbox wait was served -- on every rank."""
+        xd = shared.x_done.clone()
+        chk = torch.zeros_like(xd)
+        sharding.all_gather_primal(chk, xd[lo_id:hi_id], counts, dist)
+        okv = torch.tensor([float(torch.equal(chk, xd) and float(shared.out[2]) == 1.0)], dtype=torch.float64, device=dev)
+        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+        return float(okv) == 1.0 and not os.environ.get("QPN_BENCH_FORCE_FALLBACK")      # (the env: fallback rehearsal)
+
+    def drop_p2p(why):
+        nonlocal shared, exchange, x_all
+        if rank == 0:
+            print(f"[bench] p2p exchange failed its self-check ({why}); using RCCL collectives", file=sys.stderr, flush=True)
+        shared.close(); shared = None
+        exchange = f"rccl (p2p self-check failed: {why})"
+        x_all = torch.zeros((total, n), dtype=torch.float64, device=dev)
+
     res = None
+    if shared is not None:
+        # probe first, with a short mailbox timeout: a route that does not work must cost seconds, not the warm-up
+        barrier()
+        shared.timeout_ms = 2_000
+        res = step(False); res = step(False)
+        barrier()
+        if p2p_ok():
+            shared.timeout_ms = 10_000
+        else:
+            drop_p2p("probe")
     for i in range(args.warmup):
         maybe_refresh(i, res)
         res = step(False)
     barrier()
     if shared is not None:
-        # self-check of the p2p route, outside the timed region: every replica must equal what an RCCL
-        # all-gather of the same blocks gives, and every mailbox wait must have been served; else fall back
-        x_all = shared.x_done.clone()
-        chk = torch.zeros_like(x_all)
-        sharding.all_gather_primal(chk, x_all[lo_id:hi_id], counts, dist)
-        okv = torch.tensor([float(torch.equal(chk, x_all) and float(shared.out[2]) == 1.0 and args.warmup > 0)],
-                           dtype=torch.float64, device=dev)
-        dist.all_reduce(okv, op=dist.ReduceOp.MIN)
-        del chk
-        if float(okv) != 1.0:
-            if rank == 0:
-                print("[bench] p2p exchange failed its self-check; using RCCL collectives", file=sys.stderr, flush=True)
-            eng.set_primal_mirrors()
-            shared.close(); shared = None
-            exchange = "rccl (p2p self-check failed)"
+        if args.warmup > 0 and not p2p_ok():
+            drop_p2p("after warm-up")
             for i in range(min(args.warmup, 5)):
                 res = step(False)
             barrier()
         else:
-            shared.out[3] = 0.0                # early warm-up steps may have met start-up skew; the timed region may not
+            shared.out[3] = 0.0                # start-up skew may have cost a wait before; the timed region may not miss one
     # ONE pair of HIP events brackets the whole timed region on the launch stream (a pair per step costs two
     # barrier packets per step, ~10 us of pipeline bubbles -- measured); the per-launch duration reported in
     # "roofline" is elapsed / steps, i.e. it also carries the near-empty fallback launch and the launch gaps
