@@ -38,47 +38,49 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int pad16(int v) { return (v + 15) & ~15; }
 
 struct SbShared {
-    double red[TPB];
-    int redi[TPB];
+    double red[TPB / 64];    // one slot per wave (sb_block_*)
+    int redi[TPB / 64];
     double P[PW * LDU];      // pivot block, then its LU factors (unit lower L below, U on and above the diagonal)
     double rd[PW];           // reciprocals of the pivots
     double Pinv[PW * LDU];   // P^-1 (column c solved by lane c of wave 0)
     int flag;
 };
 
+// Block reductions (TPB = 256: 4 waves): a shuffle reduction inside each wave, the 4 wave results through LDS --
+// two barriers per call (publish / reuse) instead of the ten of a tree over LDS.  NaN never wins a max.
 __device__ __forceinline__ double sb_block_max(double v, SbShared &S, int tid)
 {
-    S.red[tid] = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    if ((tid & 63) == 0) S.red[tid >> 6] = v;
     __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (tid < s) { const double o = S.red[tid + s]; if (o > S.red[tid]) S.red[tid] = o; }
-        __syncthreads();
-    }
-    const double r = S.red[0];
+    double r = S.red[0];
+#pragma unroll
+    for (int k = 1; k < TPB / 64; ++k) { const double o = S.red[k]; r = o > r ? o : r; }
     __syncthreads();
     return r;
 }
 __device__ __forceinline__ int sb_block_min_i(int v, SbShared &S, int tid)
 {
-    S.redi[tid] = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+    if ((tid & 63) == 0) S.redi[tid >> 6] = v;
     __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (tid < s) { const int o = S.redi[tid + s]; if (o < S.redi[tid]) S.redi[tid] = o; }
-        __syncthreads();
-    }
-    const int r = S.redi[0];
+    int r = S.redi[0];
+#pragma unroll
+    for (int k = 1; k < TPB / 64; ++k) { const int o = S.redi[k]; r = o < r ? o : r; }
     __syncthreads();
     return r;
 }
 __device__ __forceinline__ int sb_block_sum_i(int v, SbShared &S, int tid)
 {
-    S.redi[tid] = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) S.redi[tid >> 6] = v;
     __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (tid < s) S.redi[tid] += S.redi[tid + s];
-        __syncthreads();
-    }
-    const int r = S.redi[0];
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < TPB / 64; ++k) r += S.redi[k];
     __syncthreads();
     return r;
 }
@@ -196,9 +198,14 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
 #pragma unroll
             for (int k = 0; k < PW; ++k) acc[k] = 0.0;
             const double *ut = Tt + (size_t)t * ldc + p0;
+            double uv[PW];                                      // the row's 16 panel entries: one round trip, not 16
+#pragma unroll
+            for (int j = 0; j < PW; ++j) uv[j] = ut[j];
 #pragma unroll 1
             for (int j = 0; j < PW; ++j) {
-                double uj = ut[j];
+                double uj = uv[0];
+#pragma unroll
+                for (int q = 0; q < PW - 1; ++q) uv[q] = uv[q + 1];          // rotate: the rolled loop indexes statically
                 if (t == p0 + j) uj -= 1.0;
 #pragma unroll
                 for (int k = 0; k < PW; ++k) acc[k] = fma(uj, S.Pinv[j * LDU + k], acc[k]);
@@ -242,41 +249,69 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
     double *Sg = w.S + (size_t)b * (size_t)w.s_stride;
     double *cg = w.c + vo;
     const int mt = m_pad / 16;
-    for (int t = wave; t < mt * (mt + 1); t += 4) {
-        const int I = t / (mt + 1), J = t % (mt + 1);
-        d4 c;
+    // Register-blocked: a wave owns a block of GB x GB output tiles and streams k -- per k-step GB + GB operand
+    // loads feed GB * GB MFMAs (one operand load per 2 MFMAs instead of 2 per MFMA), two k-steps of operands in
+    // flight.  Tiles outside the item multiply zeros on clamped addresses and are not stored.
+    constexpr int GB = 4;
+    const int rbk = (mt + GB - 1) / GB, cbk = (mt + 1 + GB - 1) / GB;
+    for (int t = wave; t < rbk * cbk; t += 4) {
+        const int I0 = GB * (t / cbk), J0 = GB * (t % cbk);
+        d4 acc[GB][GB];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
-            double v = 0.0;
-            if (J < mt) { if (ri < m && cj < m) v = Mg[(size_t)(n + cj) * N + n + ri]; }
-            else if (lc == 0 && ri < m) v = a.q[vo + n + ri];
-            c[g] = v;
-        }
-        const int ai = 16 * I + lc;
-        // eight k-steps at a time: 16 operand loads in flight ahead of the 8 MFMAs (n_pad / 4 is a multiple of 4;
-        // the tail iteration clamps its addresses and multiplies zeros)
-        for (int kk0 = 0; kk0 < n_pad / 4; kk0 += 8) {
-            double av[8], bv[8];
+        for (int bi = 0; bi < GB; ++bi)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int kk = kk0 + q;
-                const bool okk = kk < n_pad / 4;
-                const int aj = okk ? 4 * kk + lq : 0;
-                const double ta = Mg[(size_t)((ai < m && aj < n) ? aj : 0) * N + n + (ai < m ? ai : 0)];
-                av[q] = (okk && ai < m && aj < n) ? -ta : 0.0;
-                const double tb = Tt[(size_t)aj * ldc + n_pad + 16 * J + lc];
-                bv[q] = okk ? tb : 0.0;
+            for (int bj = 0; bj < GB; ++bj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int I = I0 + bi, J = J0 + bj;
+                    const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+                    double v = 0.0;
+                    if (I < mt && J < mt) { if (ri < m && cj < m) v = Mg[(size_t)(n + cj) * N + n + ri]; }
+                    else if (I < mt && J == mt && lc == 0 && ri < m) v = a.q[vo + n + ri];
+                    acc[bi][bj][g] = v;
+                }
+        auto load_ops = [&](int kk, double (&av)[GB], double (&bv)[GB]) {
+            const bool okk = kk < n_pad / 4;
+            const int aj = okk ? 4 * kk + lq : 0;
+#pragma unroll
+            for (int bi = 0; bi < GB; ++bi) {
+                const int ai = 16 * (I0 + bi) + lc;
+                const bool oka = okk && ai < m && aj < n;
+                const double ta = Mg[(size_t)(oka ? aj : 0) * N + n + (oka ? ai : 0)];
+                av[bi] = oka ? -ta : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) c = MFMA(av[q], bv[q], c);
+            for (int bj = 0; bj < GB; ++bj) {
+                const bool okb = okk && J0 + bj <= mt;
+                const double tb = Tt[(size_t)aj * ldc + n_pad + 16 * (okb ? J0 + bj : 0) + lc];
+                bv[bj] = okb ? tb : 0.0;
+            }
+        };
+        double a0[GB], b0[GB], a1[GB], b1[GB];
+        load_ops(0, a0, b0);
+        for (int kk = 0; kk < n_pad / 4; kk += 2) {           // n_pad / 4 is even
+            load_ops(kk + 1, a1, b1);
+#pragma unroll
+            for (int bi = 0; bi < GB; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < GB; ++bj) acc[bi][bj] = MFMA(a0[bi], b0[bj], acc[bi][bj]);
+            load_ops(kk + 2, a0, b0);                          // past the end: zeros on clamped addresses
+#pragma unroll
+            for (int bi = 0; bi < GB; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < GB; ++bj) acc[bi][bj] = MFMA(a1[bi], b1[bj], acc[bi][bj]);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
-            if (J < mt) { if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = c[g]; }
-            else if (lc == 0 && ri < m) cg[ri] = c[g];
-        }
+        for (int bi = 0; bi < GB; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < GB; ++bj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int I = I0 + bi, J = J0 + bj;
+                    const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+                    if (I < mt && J < mt) { if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = acc[bi][bj][g]; }
+                    else if (I < mt && J == mt && lc == 0 && ri < m) cg[ri] = acc[bi][bj][g];
+                }
     }
     // reduced problem data: bounds of the GAVI rows, cold start
     for (int k = tid; k < m; k += TPB) {
@@ -366,12 +401,13 @@ __global__ __launch_bounds__(TPB) void schur_big_finish(AviBatchArgs a, SchurBig
 // MFMA pass.  Entries of the exchanged row / column carry a relative error ~ eps |p| (cancellation in the
 // rank-1 form); the result is certified by the post-check on the original blocks like every other path.
 template <int KP>
-__global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigWs w, double *dict)
+__global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigWs w, double *dict, int m_lo, int m_hi)
 {
     const int tid = threadIdx.x, b = blockIdx.x;
     if (a.status[b] != -2) return;
     const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
     const int m = w.nred[b], XC = m, VTH = 2 * m, ld = m + 1;
+    if (m < m_lo || m > m_hi) return;                // this launch's LDS is sized for m_hi
     const size_t vo = (size_t)b * (size_t)a.N;
     __shared__ SbShared S;
     __shared__ double bcd[8];
@@ -574,26 +610,39 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
         if (c < 0) { status = QPN_FAILURE; break; }
         // ---- fold the pending pairs into T_base: rank-KP MFMA pass over its tiles
         if (npend == KP) {
-            const int rt = (m + 15) / 16, ct = (m + 1 + 15) / 16;
-            for (int t = wave; t < rt * ct; t += 4) {
-                const int I = t / ct, J = t % ct;
-                d4 acc;
+            // FT tiles per wave in flight: the loads of all of them are issued before the first MFMA, so the pass
+            // waits for HBM once per FT tiles instead of once per tile
+            constexpr int FT = 4;
+            const int rt = (m + 15) / 16, ct = (m + 1 + 15) / 16, nt = rt * ct;
+            for (int t0 = wave; t0 < nt; t0 += 4 * FT) {
+                d4 acc[FT];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
-                    acc[g] = (ri < m && cj <= m) ? Tb[(size_t)ri * ld + cj] : 0.0;
+                for (int f = 0; f < FT; ++f) {
+                    const int t = t0 + 4 * f;
+                    const int I = t / ct, J = t % ct;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+                        acc[f][g] = (t < nt && ri < m && cj <= m) ? Tb[(size_t)ri * ld + cj] : 0.0;
+                    }
                 }
 #pragma unroll
-                for (int s4 = 0; s4 < KP / 4; ++s4) {
-                    const int ri = 16 * I + lc, cj = 16 * J + lc, kk = 4 * s4 + lq;
-                    const double av = ri < m ? -PA[kk * mA + ri] : 0.0;
-                    const double bv = cj <= m ? PB[kk * mB + cj] : 0.0;
-                    acc = MFMA(av, bv, acc);
-                }
+                for (int f = 0; f < FT; ++f) {
+                    const int t = t0 + 4 * f;
+                    const int I = t / ct, J = t % ct;
+                    if (t >= nt) break;                          // wave-uniform
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
-                    if (ri < m && cj <= m) Tb[(size_t)ri * ld + cj] = acc[g];
+                    for (int s4 = 0; s4 < KP / 4; ++s4) {
+                        const int ri = 16 * I + lc, cj = 16 * J + lc, kk = 4 * s4 + lq;
+                        const double av = ri < m ? -PA[kk * mA + ri] : 0.0;
+                        const double bv = cj <= m ? PB[kk * mB + cj] : 0.0;
+                        acc[f] = MFMA(av, bv, acc[f]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
+                        if (ri < m && cj <= m) Tb[(size_t)ri * ld + cj] = acc[f][g];
+                    }
                 }
             }
             npend = 0;
@@ -665,11 +714,6 @@ hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &
 // kernel's dictionary workspace (batch x N x (N+1) doubles), reused here as T_base.
 hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream)
 {
-    const int N = a.N;                                   // m <= min(N - 1, 512) (stage A declines larger ones)
-    const int KP = N <= 272 ? 16 : 8;                    // pending pairs: 2 KP (m + 1) doubles of LDS
-    const size_t mB = (size_t)(N < 513 ? N : 513);       // upper bound of m + 1
-    const size_t dbl = (size_t)KP * (2 * mB + 1) + (mB + 2) + 2 * mB;
-    const size_t bytes = ((dbl * sizeof(double) + sizeof(int) * (2 * mB + 4)) + 15) & ~(size_t)15;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_lemke<16>),
@@ -680,8 +724,28 @@ hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (bytes > 150 * 1024) return hipErrorInvalidValue;
-    if (KP == 16) hipLaunchKernelGGL(schur_big_lemke<16>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict);
-    else hipLaunchKernelGGL(schur_big_lemke<8>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict);
-    return hipGetLastError();
+    // The reduced size m of an item is known on the device only (stage A found the split), and the LDS of a launch
+    // is sized on the host: two launches, each taking the items of its own m range -- m <= ceil(N / 2) (a node
+    // with no more constraint rows than variables: config 5) gets 16 pending pairs in <= 80 KB, i.e. two
+    // workgroups per CU, the rest is sized for the largest m the path takes.  A launch with no item is a few us.
+    const int N = a.N;
+    const int m_top = N - 1 < 512 ? N - 1 : 512;         // stage A declines larger ones
+    const int m_mid = (N + 1) / 2 < m_top ? (N + 1) / 2 : m_top;
+    auto bytes_for = [](int KP, int mh) -> size_t {
+        const size_t mB = (size_t)mh + 1;
+        const size_t dbl = (size_t)KP * (2 * mB + 1) + (mB + 2) + 2 * mB;
+        return ((dbl * sizeof(double) + sizeof(int) * (2 * mB + 4)) + 15) & ~(size_t)15;
+    };
+    for (int part = 0; part < 2; ++part) {
+        const int m_lo = part == 0 ? 1 : m_mid + 1, m_hi = part == 0 ? m_mid : m_top;
+        if (m_lo > m_hi) continue;
+        const int KP = bytes_for(16, m_hi) <= 78 * 1024 ? 16 : 8;
+        const size_t bytes = bytes_for(KP, m_hi);
+        if (bytes > 150 * 1024) return hipErrorInvalidValue;
+        if (KP == 16) hipLaunchKernelGGL(schur_big_lemke<16>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict, m_lo, m_hi);
+        else hipLaunchKernelGGL(schur_big_lemke<8>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict, m_lo, m_hi);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
