@@ -610,12 +610,13 @@ hipError_t launch_big_kernel(const AviBatchArgs &a, double *dict, hipStream_t st
     size_t dbl = (size_t)((NC + 1) & ~1) * 2 + 2 * (size_t)N + (size_t)((2 * N + 2) & ~1);
     size_t bytes = dbl * sizeof(double) + sizeof(int) * ((size_t)N + NC + 1 + 8 * (size_t)N + 8);
     bytes = (bytes + 15) & ~(size_t)15;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static QpnPerDeviceOnce attr_once;
+    const int attr_dev = attr_once.device();
+    if (!attr_once.done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(avi_solve_big),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done[attr_dev] = true;
     }
     hipLaunchKernelGGL(avi_solve_big, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, dict);
     return hipGetLastError();

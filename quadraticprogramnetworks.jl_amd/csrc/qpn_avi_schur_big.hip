@@ -88,7 +88,7 @@ __device__ __forceinline__ int sb_block_sum_i(int v, SbShared &S, int tid)
 // ---- stage A ---------------------------------------------------------------------------------------------
 // Outputs per item (workspace): Tt (top half after elimination: W = columns n_pad.., h = column n_pad+m_pad),
 // S (m x m, column-major), c (m), reduced bounds / start, nsplit = n.  status: -2 accepted, -1 declined.
-__global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBigWs w)
+__global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, SchurBigWs w, int lds_rows)
 {
     const int N = a.N;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -143,9 +143,11 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
     __threadfence_block();
     __syncthreads();
 
-    // ---- rank-16 block pivots ---------------------------------------------------------------------------
+    // ---- rank-16 block pivots, two per pass over the tiles where LDS holds two panels -----------------------
+    // Factorization of one panel (pivot block kb): P -> LU -> P^-1 in LDS, U' = U P^-1 into sU.  false = a pivot
+    // failed the threshold (uniform over the workgroup).
     const int nrt = n_pad / 16, nct = ldc / 16;
-    for (int kb = 0; kb < nrt; ++kb) {
+    auto factor_panel = [&](int kb, double *sU) -> bool {
         const int p0 = 16 * kb;
         // pivot block (rows p0 .. p0+15 of the panel) into LDS
         if (tid < PW) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
             }
         }
         __syncthreads();
-        if (S.flag == 0) { if (tid == 0) a.status[b] = -1; return; }
+        if (S.flag == 0) return false;
         // U' = U P^-1, one panel row per thread at a time: 16 accumulators, P^-1 broadcast from LDS (rolled over
         // the panel column j so that nothing but the accumulators stays live); pivot rows carry P - I
         for (int t = tid; t < n_pad; t += TPB) {
@@ -211,9 +213,102 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
                 for (int k = 0; k < PW; ++k) acc[k] = fma(uj, S.Pinv[j * LDU + k], acc[k]);
             }
 #pragma unroll
-            for (int k = 0; k < PW; ++k) sUp[t * LDU + k] = acc[k];
+            for (int k = 0; k < PW; ++k) sU[t * LDU + k] = acc[k];
         }
         __syncthreads();
+        return true;
+    };
+    // One pass applies the panels kb and kb + 1 together (half the tile traffic of stage A):
+    //     T2 = T0 - (U'_a - U'_b G) V_a(T0) - U'_b V_b(T0),   G = U'_a[rows of block b]  (16 x 16),
+    // U'_b being factored from panel b AFTER the update by panel a (a look-ahead update of that one column tile).
+    // The pair needs two U' panels in LDS; the launch sizes LDS for one panel of the largest n it accepts, so items
+    // with n_pad <= half of that are paired and the others (and an odd last panel) take single steps.
+    const bool can_pair = 2 * n_pad <= lds_rows;
+    double *const sUa = sUp, *const sUb = sUp + (size_t)n_pad * LDU;
+    for (int kb = 0; kb < nrt;) {
+        const int p0 = 16 * kb;
+        if (!factor_panel(kb, sUa)) { if (tid == 0) a.status[b] = -1; return; }
+        const bool pair = can_pair && kb + 1 < nrt;
+        if (pair) {
+            const int p1 = p0 + 16;
+            // look-ahead: column tile kb + 1 gets panel a's update now (16 row tiles over the 4 waves)
+            {
+                const int J = kb + 1;
+                double vb[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) vb[s4] = Tt[(size_t)(p0 + 4 * s4 + lq) * ldc + 16 * J + lc];
+                __syncthreads();                                   // every wave has its copy of the raw pivot rows
+                for (int I = wave; I < nrt; I += 4) {
+                    d4 c0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) c0[g] = Tt[(size_t)(16 * I + 4 * g + lq) * ldc + 16 * J + lc];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) c0 = MFMA(-sUa[(16 * I + lc) * LDU + 4 * s4 + lq], vb[s4], c0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I + 4 * g + lq) * ldc + 16 * J + lc] = c0[g];
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            if (!factor_panel(kb + 1, sUb)) { if (tid == 0) a.status[b] = -1; return; }
+            // G = U'_a[p1 .. p1+15][:] (kept aside in S.P, free after the factorization), then U'_a -= U'_b G
+            if (tid < PW * PW) S.P[(tid / PW) * LDU + (tid % PW)] = sUa[(p1 + tid / PW) * LDU + (tid % PW)];
+            __syncthreads();
+            for (int t = tid; t < n_pad; t += TPB) {
+                double ub_[PW], acc[PW];
+#pragma unroll
+                for (int q = 0; q < PW; ++q) { ub_[q] = sUb[t * LDU + q]; acc[q] = sUa[t * LDU + q]; }
+#pragma unroll 1
+                for (int q = 0; q < PW; ++q) {
+                    const double uq = ub_[0];
+#pragma unroll
+                    for (int r = 0; r < PW - 1; ++r) ub_[r] = ub_[r + 1];
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) acc[k] = fma(-uq, S.P[q * LDU + k], acc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < PW; ++k) sUa[t * LDU + k] = acc[k];
+            }
+            __syncthreads();
+            // T -= [U~_a | U'_b] [V_a; V_b] on the column tiles right of both panels: 8 k-steps per tile
+            for (int J = kb + 2 + wave; J < nct; J += 4) {
+                double vb[8];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    vb[s4] = Tt[(size_t)(p0 + 4 * s4 + lq) * ldc + 16 * J + lc];
+                    vb[4 + s4] = Tt[(size_t)(p1 + 4 * s4 + lq) * ldc + 16 * J + lc];
+                }
+                for (int I0 = 0; I0 < nrt; I0 += 2) {
+                    const int I1 = I0 + 1 < nrt ? I0 + 1 : I0;
+                    d4 c0, c1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        c0[g] = Tt[(size_t)(16 * I0 + 4 * g + lq) * ldc + 16 * J + lc];
+                        c1[g] = Tt[(size_t)(16 * I1 + 4 * g + lq) * ldc + 16 * J + lc];
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        c0 = MFMA(-sUa[(16 * I0 + lc) * LDU + 4 * s4 + lq], vb[s4], c0);
+                        c0 = MFMA(-sUb[(16 * I0 + lc) * LDU + 4 * s4 + lq], vb[4 + s4], c0);
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        c1 = MFMA(-sUa[(16 * I1 + lc) * LDU + 4 * s4 + lq], vb[s4], c1);
+                        c1 = MFMA(-sUb[(16 * I1 + lc) * LDU + 4 * s4 + lq], vb[4 + s4], c1);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I0 + 4 * g + lq) * ldc + 16 * J + lc] = c0[g];
+                    if (I1 != I0) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I1 + 4 * g + lq) * ldc + 16 * J + lc] = c1[g];
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            kb += 2;
+            continue;
+        }
         // T -= U' V on the live column tiles (those right of the panel), 4 k-steps per tile
         for (int J = kb + 1 + wave; J < nct; J += 4) {
             double vb[4];
@@ -230,9 +325,9 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
                     c1[g] = Tt[(size_t)(16 * I1 + 4 * g + lq) * ldc + 16 * J + lc];
                 }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) c0 = MFMA(-sUp[(16 * I0 + lc) * LDU + 4 * s + lq], vb[s], c0);
+                for (int s = 0; s < 4; ++s) c0 = MFMA(-sUa[(16 * I0 + lc) * LDU + 4 * s + lq], vb[s], c0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) c1 = MFMA(-sUp[(16 * I1 + lc) * LDU + 4 * s + lq], vb[s], c1);
+                for (int s = 0; s < 4; ++s) c1 = MFMA(-sUa[(16 * I1 + lc) * LDU + 4 * s + lq], vb[s], c1);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) Tt[(size_t)(16 * I0 + 4 * g + lq) * ldc + 16 * J + lc] = c0[g];
                 if (I1 != I0) {
@@ -243,6 +338,7 @@ __global__ __launch_bounds__(TPB) void schur_big_stage_a(AviBatchArgs a, SchurBi
         }
         __threadfence_block();
         __syncthreads();
+        kb += 1;
     }
 
     // ---- S = D - A W, c = b - A h: tiled GEMM, A operands from the original M ---------------------------
@@ -689,18 +785,19 @@ hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBi
     int32_t *ip = reinterpret_cast<int32_t *>(p);
     w.st2 = ip; ip += batch; w.piv2 = ip; ip += batch; w.nsplit = ip; ip += batch; w.nred = ip; ip += batch;
     *out = w;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static QpnPerDeviceOnce attr_once;
+    const int attr_dev = attr_once.device();
+    if (!attr_once.done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_stage_a),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_finish),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done[attr_dev] = true;
     }
     const size_t rows_lds = rows < 512 ? rows : 512;
-    hipLaunchKernelGGL(schur_big_stage_a, dim3((unsigned)batch), dim3(TPB), rows_lds * LDU * sizeof(double), stream, a, w);
+    hipLaunchKernelGGL(schur_big_stage_a, dim3((unsigned)batch), dim3(TPB), rows_lds * LDU * sizeof(double), stream, a, w, (int)rows_lds);
     return hipGetLastError();
 }
 
@@ -714,15 +811,16 @@ hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &
 // kernel's dictionary workspace (batch x N x (N+1) doubles), reused here as T_base.
 hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static QpnPerDeviceOnce attr_once;
+    const int attr_dev = attr_once.device();
+    if (!attr_once.done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_lemke<16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_lemke<8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done[attr_dev] = true;
     }
     // The reduced size m of an item is known on the device only (stage A found the split), and the LDS of a launch
     // is sized on the host: two launches, each taking the items of its own m range -- m <= ceil(N / 2) (a node

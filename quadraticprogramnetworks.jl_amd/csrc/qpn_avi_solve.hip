@@ -437,12 +437,13 @@ hipError_t qpn_launch_avi_solve_lds1(const AviBatchArgs &a, hipStream_t stream)
 {
     if (a.batch <= 0) return hipSuccess;
     const LdsLayout L = lds_layout(a.N);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static QpnPerDeviceOnce attr_once;
+    const int attr_dev = attr_once.device();
+    if (!attr_once.done[attr_dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(avi_solve_lds1),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done[attr_dev] = true;
     }
     hipLaunchKernelGGL(avi_solve_lds1, dim3((unsigned)a.batch), dim3(WAVE), L.bytes, stream, a);
     return hipGetLastError();

@@ -58,6 +58,13 @@ struct AviBatchArgs {
     int64_t vec_stride;
 };
 
+// Function attributes (dynamic LDS limits) are per device: a launcher sets them once per device it is used on.
+// (Two host threads racing here both set the same value.)
+struct QpnPerDeviceOnce {
+    bool done[64] = {};
+    int device() const { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+};
+
 // qpn_avi_solve.hip
 hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream);      // dispatcher
 hipError_t qpn_launch_avi_solve_lds1(const AviBatchArgs &a, hipStream_t stream); // LDS-tableau kernel
