@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Developer aid: node-solve rate across node sizes (where the kernel families hand over)."""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch
+import qpn_amd
+import problems as P
+from qpn_amd.engine import colmajor
+eng = qpn_amd.Engine(0)
+t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+for n, m, cnt in [(16, 16, 10000), (32, 32, 10000), (33, 33, 4000), (40, 40, 4000), (48, 48, 4000), (64, 64, 2000), (96, 96, 1000), (128, 128, 1000), (256, 256, 512)]:
+    Q, R_, qd, A, B, l, u = P.synth_nodes(5000 + n, cnt, n, m)
+    args = [t(colmajor(Q)), t(colmajor(R_)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(P.shared_params())]
+    out = None
+    for _ in range(2):
+        res = eng.solve_nodes(*args)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = eng.solve_nodes(*args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    st = res["status"].cpu().numpy()
+    print(f"n=m={n:4d} ({cnt:5d} nodes): {dt*1e3:8.3f} ms/batch = {cnt/dt/1e3:10.1f} K solves/s, solved {(st==1).mean()*100:.0f} %, mean pivots {res['pivots'].double().mean().item():.0f}", flush=True)
