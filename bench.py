@@ -225,6 +225,17 @@ def main():
                 traffic = json.load(open(tj)).get("avi_solve_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # fp64 pipe utilisation of the dominant kernel from the committed PMC pass (rocprofv3 --pmc, own run):
+        # (VALU-active + MFMA-busy cycles) / wall cycles per SIMD; SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in
+        # units of 4 cycles, 4 waves share a SIMD
+        pipe = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pj):
+            try:
+                sq = json.load(open(pj)).get("avi_solve_schur_sq_per_launch", {})
+                pipe = (4.0 * sq["SQ_ACTIVE_INST_VALU"] + sq["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * sq["SQ_WAVE_CYCLES"] / 4.0)
+            except Exception:
+                pipe = None
         out = {
             "metric": "node-AVI solves/sec (fp64) on synthetic N-node QPNet",
             "value": solved * args.steps / dt / 1.0,
@@ -246,7 +257,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "avi_solve_schur<nodes> (+ gated fallback launches)" if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt},
+                         "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt,
+                         "fp64_pipe_busy_frac": pipe},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Q, R, qd, A, B, l, u, w_host)
