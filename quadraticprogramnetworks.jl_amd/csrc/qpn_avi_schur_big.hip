@@ -149,47 +149,53 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
     const int nrt = n_pad / 16, nct = ldc / 16;
     auto factor_panel = [&](int kb, double *sU) -> bool {
         const int p0 = 16 * kb;
-        // pivot block (rows p0 .. p0+15 of the panel) into LDS
-        if (tid < PW) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) S.P[tid * LDU + k] = Tt[(size_t)(p0 + tid) * ldc + p0 + k];
-        }
-        if (tid == 0) S.flag = 1;
-        __syncthreads();
-        // LU of the pivot block by wave 0 (lane i <-> row i), no pivoting, threshold on every pivot
+        // Pivot block P (rows / columns p0 .. p0+15) -> LU -> P^-1, all in the registers of wave 0: lane i < 16 holds
+        // row i, a pivot row is broadcast with v_readlane (every index below is a compile-time constant after
+        // unrolling), lane c then solves L y = e_c and U x = y for column c of P^-1 with the factors broadcast the
+        // same way.  No pivoting; every pivot must pass the threshold (else the item is declined).
         if (wave == 0) {
-            for (int s = 0; s < PW; ++s) {
-                const double piv = S.P[s * LDU + s];
-                if (!(fabs(piv) >= diag_thr)) { if (lane == 0) S.flag = 0; break; }
+            double prow[PW];
+            const int li = lane < PW ? lane : 0;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) prow[k] = Tt[(size_t)(p0 + li) * ldc + p0 + k];
+            bool ok = true;
+            double rdv[PW];
+#pragma unroll
+            for (int s_ = 0; s_ < PW; ++s_) {
+                const double piv = readlane_f64(prow[s_], s_);
+                ok = ok && (fabs(piv) >= diag_thr);
                 const double r = 1.0 / piv;
-                if (lane == 0) S.rd[s] = r;
-                if (lane > s && lane < PW) {
-                    const double f = S.P[lane * LDU + s] * r;
-                    S.P[lane * LDU + s] = f;
-                    for (int j = s + 1; j < PW; ++j) S.P[lane * LDU + j] = fma(-f, S.P[s * LDU + j], S.P[lane * LDU + j]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            // P^-1: lane c solves L y = e_c, then U x = y, in place in column c of Pinv (rolled loops, LDS only)
-            if (lane < PW && S.flag) {
-                const int cc = lane;
-#pragma unroll 1
-                for (int j = 0; j < PW; ++j) {
-                    double sacc = (j == cc) ? 1.0 : 0.0;
-#pragma unroll 1
-                    for (int i = 0; i < j; ++i) sacc = fma(-S.P[j * LDU + i], S.Pinv[i * LDU + cc], sacc);
-                    S.Pinv[j * LDU + cc] = sacc;
-                }
-#pragma unroll 1
-                for (int j = PW - 1; j >= 0; --j) {
-                    double sacc = S.Pinv[j * LDU + cc];
-#pragma unroll 1
-                    for (int i = j + 1; i < PW; ++i) sacc = fma(-S.P[j * LDU + i], S.Pinv[i * LDU + cc], sacc);
-                    S.Pinv[j * LDU + cc] = sacc * S.rd[j];
+                rdv[s_] = r;
+                const double f = prow[s_] * r;                      // l_is of this lane's row (kept in place below the diagonal)
+                const bool below = lane > s_;
+                if (below) prow[s_] = f;
+#pragma unroll
+                for (int j2 = s_ + 1; j2 < PW; ++j2) {
+                    const double psj = readlane_f64(prow[j2], s_);
+                    if (below) prow[j2] = fma(-f, psj, prow[j2]);
                 }
             }
+            // column `lane` of P^-1: forward (unit lower L), then backward (U, reciprocals rdv)
+            double y[PW];
+#pragma unroll
+            for (int j2 = 0; j2 < PW; ++j2) {
+                double sacc = (j2 == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i2 = 0; i2 < j2; ++i2) sacc = fma(-readlane_f64(prow[i2], j2), y[i2], sacc);
+                y[j2] = sacc;
+            }
+#pragma unroll
+            for (int j2 = PW - 1; j2 >= 0; --j2) {
+                double sacc = y[j2];
+#pragma unroll
+                for (int i2 = j2 + 1; i2 < PW; ++i2) sacc = fma(-readlane_f64(prow[i2], j2), y[i2], sacc);
+                y[j2] = sacc * rdv[j2];
+            }
+            if (lane < PW) {
+#pragma unroll
+                for (int j2 = 0; j2 < PW; ++j2) S.Pinv[j2 * LDU + lane] = y[j2];
+            }
+            if (lane == 0) S.flag = ok ? 1 : 0;
         }
         __syncthreads();
         if (S.flag == 0) return false;
