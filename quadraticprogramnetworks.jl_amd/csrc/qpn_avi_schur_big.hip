@@ -85,6 +85,30 @@ __device__ __forceinline__ int sb_block_sum_i(int v, SbShared &S, int tid)
     return r;
 }
 
+// Row choice of the ratio test in ONE reduction: the candidate with the largest key, ties -> the lowest row;
+// key < 0 = no candidate (returns -1).  Shuffle tournament inside each wave, the 4 wave winners through LDS.
+__device__ __forceinline__ int sb_block_argbest(double key, int row, SbShared &S, int tid)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ok_ = __shfl_xor(key, off, 64);
+        const int or_ = __shfl_xor(row, off, 64);
+        if (ok_ > key || (ok_ == key && or_ < row)) { key = ok_; row = or_; }
+    }
+    if ((tid & 63) == 0) { S.red[tid >> 6] = key; S.redi[tid >> 6] = row; }
+    __syncthreads();
+    double bk = S.red[0];
+    int br = S.redi[0];
+#pragma unroll
+    for (int k = 1; k < TPB / 64; ++k) {
+        const double ok_ = S.red[k];
+        const int or_ = S.redi[k];
+        if (ok_ > bk || (ok_ == bk && or_ < br)) { bk = ok_; br = or_; }
+    }
+    __syncthreads();
+    return bk < 0.0 ? -1 : br;
+}
+
 // ---- stage A ---------------------------------------------------------------------------------------------
 // Outputs per item (workspace): Tt (top half after elimination: W = columns n_pad.., h = column n_pad+m_pad),
 // S (m x m, column-major), c (m), reduced bounds / start, nsplit = n.  status: -2 accepted, -1 declined.
@@ -616,11 +640,20 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
         double dmax = -sb_block_max(-d1min, S, tid);
         if (self_lim < dmax) dmax = self_lim;
         if (dmax == QINF) { status = QPN_RAY_TERM; break; }
-        int ncand = 0;
+        // candidates, and among them the pivot row (largest |pivot|, the artificial first; ties -> lowest row)
         bool cand[2];
+        double ag = -1.0;
+        int myr = 0x7fffffff;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { cand[h] = cnd[h] && dd[h] <= dmax; ncand += cand[h] ? 1 : 0; }
-        ncand = sb_block_sum_i(ncand, S, tid);
+        for (int h = 1; h >= 0; --h) {
+            cand[h] = cnd[h] && dd[h] <= dmax;
+            if (cand[h]) {
+                const double v = rowvar[h] == VTH ? QINF : fabs(gdir[h]);
+                if (v >= ag) { ag = v; myr = tid + TPB * h; }          // h = 0 (the lower row) wins a tie within the thread
+            }
+        }
+        const int r = sb_block_argbest(ag, myr, S, tid);
+        const int ncand = r < 0 ? 0 : 1;
         if (ncand == 0) {
             // the entering variable reaches its own opposite bound first: no basis change
             const double dl = sneg ? -self_lim : self_lim;
@@ -642,15 +675,6 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
             if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
             continue;
         }
-        // ---- pivot row: unique candidate, or the largest |pivot| among them, the artificial first; ties -> lowest row
-        double ag = -1.0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) if (cand[h]) { const double v = rowvar[h] == VTH ? QINF : fabs(gdir[h]); if (v > ag) ag = v; }
-        const double bestg = sb_block_max(ag, S, tid);
-        int myr = 0x7fffffff;
-#pragma unroll
-        for (int h = 1; h >= 0; --h) if (cand[h] && (rowvar[h] == VTH ? QINF : fabs(gdir[h])) == bestg) myr = tid + TPB * h;
-        const int r = sb_block_min_i(myr, S, tid);
         // owner of row r publishes its scalars
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
