@@ -95,3 +95,26 @@ def test_node_shaped_items_with_awkward_rows(engine, oracle, n, m):
         items.append((Mx[0], q[0], lo[0], hi[0], kind[0], np.zeros(n + m)))
     rc = _run(engine, oracle, items, f"awkward nodes n={n} m={m}")
     assert np.any(rc["status"] == 1)
+
+
+def test_large_path_random_shapes(engine, oracle):
+    """Node shapes across the large-item path's internal boundaries: one / two panels per pass (2 n_pad against the
+    LDS rows), odd and even panel counts, m on either side of the Lemke launches' split at (N + 1) / 2, padding in
+    both blocks, 8 / 16 pending pairs."""
+    from qpn_amd.engine import colmajor
+    rng = np.random.default_rng(77)
+    shapes = [(33, 33), (48, 17), (17, 48), (64, 64), (65, 64), (80, 81), (81, 80), (97, 40), (31, 130), (130, 31),
+              (144, 145), (160, 100), (100, 160), (200, 90), (257, 40), (40, 257), (272, 273)]
+    while len(shapes) < 24:
+        n = int(rng.integers(20, 220)); m = int(rng.integers(20, 220))
+        if n + m > 64:
+            shapes.append((n, m))
+    for n, m in shapes:
+        cnt = 3 if n + m <= 300 else 2
+        Q, R, qd, A, B, l, u = P.synth_nodes(9000 + 7 * n + m, cnt, n, m, 2)
+        w = P.shared_params(2)
+        M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+        rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+        rg = engine.solve_nodes(colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+        _cmp(rg, rc, f"large path n={n} m={m}")
+        assert np.all(rc["status"] == 1), (n, m)
