@@ -650,6 +650,20 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
         r.max_pivots = a.max_pivots; r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
         r.only_if = a.status; r.only_if_value = -2;
         e = launch_big_kernel(r, dict, stream);
+    } else if (a.nd.Qd && a.nd.m >= 1 && a.nd.m <= 64 && a.nd.n + a.nd.m == N &&
+               (a.max_pivots <= 0 || a.max_pivots - a.nd.n >= 1)) {
+        // node path with m <= 64 (uniform, known here): the Schur problems are all-GAVI items of size m -- the
+        // one-wavefront register kernel solves them (same pivot rule), no workgroup barriers, no dictionary in HBM
+        hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, ones, N);
+        AviBatchArgs r{};
+        r.batch = a.batch; r.N = a.nd.m; r.vec_stride = N;
+        r.M = w.S; r.strideM = w.s_stride; r.q = w.c; r.l = w.l2; r.u = w.u2; r.kind = ones; r.stride_kind = 0;
+        r.z = w.lam; r.status = w.st2; r.pivots = w.piv2; r.resid = nullptr; r.active = nullptr;
+        r.check_tol = a.check_tol; r.piv_tol = a.piv_tol; r.feas_tol = a.feas_tol; r.comp_tol = a.comp_tol;
+        r.max_pivots = (a.max_pivots > 0 ? a.max_pivots : 50 * N + 100) - a.nd.n;      // the crash pivots count
+        r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
+        r.only_if = a.status; r.only_if_value = -2;
+        e = qpn_launch_avi_solve_reg(r, stream);
     } else {
         e = qpn_launch_schur_big_lemke(a, w, dict, stream);
     }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
     const double *Mg = a.M + (size_t)b * (size_t)a.strideM;
-    const size_t vo = (size_t)b * (size_t)N;
+    const size_t vo = (size_t)b * (size_t)(a.vec_stride ? a.vec_stride : N);     // vectors of item b (reduced problems keep the parent's stride)
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
 
     // ---- pair k = lane ----------------------------------------------------------------

@@ -112,7 +112,11 @@ __device__ __forceinline__ int sb_block_argbest(double key, int row, SbShared &S
 // ---- stage A ---------------------------------------------------------------------------------------------
 // Outputs per item (workspace): Tt (top half after elimination: W = columns n_pad.., h = column n_pad+m_pad),
 // S (m x m, column-major), c (m), reduced bounds / start, nsplit = n.  status: -2 accepted, -1 declined.
-__global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, SchurBigWs w, int lds_rows)
+// LDS_TT: the whole top half lives in LDS behind the U' panels (small nodes whose sizes the host knows: the node
+// path) instead of the HBM workspace -- every panel step is then a chain of LDS trips, not of HBM round trips; the
+// finished top half is copied to the workspace once, for the finish kernel.
+template <bool LDS_TT>
+__global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, SchurBigWs w, int lds_rows, int tt_off, int tt_cap)
 {
     const int N = a.N;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -146,7 +150,12 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
     const int n_pad = pad16(n), m_pad = pad16(m);
     const int ldc = n_pad + m_pad + 16;                 // H part | C part | one tile whose column 0 is g
     const int xcol = n_pad + m_pad;
-    double *Tt = w.Tt + (size_t)b * (size_t)w.tt_stride;
+    double *const Ttg = w.Tt + (size_t)b * (size_t)w.tt_stride;
+    double *Tt;
+    if constexpr (LDS_TT) {
+        if (n_pad * ldc > tt_cap) { if (tid == 0) a.status[b] = -1; return; }     // not the sizes the launch was made for
+        Tt = sUp + tt_off;
+    } else Tt = Ttg;
 
     // ---- fill the top half (row-major) and take max |M| over the WHOLE item ------------------------------
     for (int i = tid; i < n_pad; i += TPB)
@@ -438,6 +447,10 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
                     if (I < mt && J < mt) { if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = acc[bi][bj][g]; }
                     else if (I < mt && J == mt && lc == 0 && ri < m) cg[ri] = acc[bi][bj][g];
                 }
+    }
+    if constexpr (LDS_TT) {
+        __syncthreads();
+        for (int idx = tid; idx < n_pad * ldc; idx += TPB) Ttg[idx] = Tt[idx];
     }
     // reduced problem data: bounds of the GAVI rows, cold start
     for (int k = tid; k < m; k += TPB) {
@@ -818,16 +831,32 @@ hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBi
     static QpnPerDeviceOnce attr_once;
     const int attr_dev = attr_once.device();
     if (!attr_once.done[attr_dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_stage_a),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_stage_a<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_stage_a<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_finish),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024);
         if (e != hipSuccess) return e;
         attr_once.done[attr_dev] = true;
     }
+    // node path: every item has the record's (n, m), known here -- small nodes keep their top half in LDS
+    if (a.nd.Qd && a.nd.n >= 1 && a.nd.m >= 1 && a.nd.n + a.nd.m == N) {
+        const size_t n_pad = (size_t)((a.nd.n + 15) & ~15), m_pad = (size_t)((a.nd.m + 15) & ~15);
+        const size_t ldc = n_pad + m_pad + 16;
+        const size_t up = 2 * n_pad * LDU + ((2 * n_pad * LDU) & 1);          // two U' panels, then an even offset
+        const size_t bytes = (up + n_pad * ldc) * sizeof(double);
+        if (bytes <= 75 * 1024) {                       // two workgroups per CU (one is no faster than the HBM route)
+            hipLaunchKernelGGL(schur_big_stage_a<true>, dim3((unsigned)batch), dim3(TPB), bytes, stream, a, w,
+                               (int)(2 * n_pad), (int)up, (int)(n_pad * ldc));
+            return hipGetLastError();
+        }
+    }
     const size_t rows_lds = rows < 512 ? rows : 512;
-    hipLaunchKernelGGL(schur_big_stage_a, dim3((unsigned)batch), dim3(TPB), rows_lds * LDU * sizeof(double), stream, a, w, (int)rows_lds);
+    hipLaunchKernelGGL(schur_big_stage_a<false>, dim3((unsigned)batch), dim3(TPB), rows_lds * LDU * sizeof(double), stream, a, w,
+                       (int)rows_lds, 0, 0);
     return hipGetLastError();
 }
 
