@@ -86,6 +86,70 @@ __global__ __launch_bounds__(256) void assemble_nodes_kernel(
     qpn_assemble_item(nd, b, lane, Mout, qout, lout, uout, kind_out);
 }
 
+// Large nodes (N > 64): one workgroup per (node, strip of 32 columns of M) instead of one wave per node -- a node's
+// block is megabytes.  Columns j < n are two contiguous copies ([Qd(:,j); Ad(:,j)]); columns n + c are -Ad(c,:)'
+// over zeros: a transpose, done through a 32 x 33 LDS tile so that both the reads (along c) and the writes (along
+// the rows of M) are contiguous.  Strip 0 also writes q, l, u, kind (same fma order as qpn_assemble_item).
+__global__ __launch_bounds__(256) void assemble_nodes_wide_kernel(
+    int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
+    const double *qd, const double *Ad, const double *B, const double *l, const double *u,
+    const double *w, int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
+    uint8_t *kind_out, const int32_t *only_if, int32_t only_if_value)
+{
+    const int b = blockIdx.x, strip = blockIdx.y, tid = threadIdx.x;
+    if (only_if && only_if[b] != only_if_value) return;
+    const int N = n + m;
+    const double *Q_ = Qd + (size_t)b * n * n;
+    const double *A_ = Ad + (size_t)b * m * n;
+    double *Mo = Mout + (size_t)b * N * N;
+    const int j0 = 32 * strip, j1 = j0 + 32 < N ? j0 + 32 : N;
+    // columns of the x block
+    for (int j = j0; j < (j1 < n ? j1 : n); ++j)
+        for (int i = tid; i < N; i += 256)
+            Mo[(size_t)j * N + i] = i < n ? Q_[(size_t)j * n + i] : A_[(size_t)j * m + (i - n)];
+    // columns of the multiplier block: c in [c0, c1)
+    const int c0 = (j0 > n ? j0 : n) - n, c1 = j1 - n;
+    if (c1 > c0) {
+        __shared__ double tile[32][33];
+        const int tx = tid & 31, ty = tid >> 5;                      // 32 x 8 threads
+        for (int i0 = 0; i0 < n; i0 += 32) {
+            for (int r = ty; r < 32; r += 8) {                       // tile[r][tx] = Ad[c0 + tx][i0 + r], read along c
+                const int i = i0 + r, c = c0 + tx;
+                tile[r][tx] = (i < n && c < c1) ? A_[(size_t)i * m + c] : 0.0;
+            }
+            __syncthreads();
+            for (int cc = ty; cc < 32; cc += 8) {                    // M[i0 + tx][n + c0 + cc] = -tile[tx][cc], written along i
+                const int i = i0 + tx, c = c0 + cc;
+                if (i < n && c < c1) Mo[(size_t)(n + c) * N + i] = -tile[tx][cc];
+            }
+            __syncthreads();
+        }
+        for (int c = c0; c < c1; ++c)
+            for (int i = n + tid; i < N; i += 256) Mo[(size_t)(n + c) * N + i] = 0.0;
+    }
+    if (strip == 0) {
+        const double *R_ = R + (size_t)b * n * p;
+        const double *B_ = B + (size_t)b * m * p;
+        const double *w_ = w + (size_t)b * (size_t)stride_w;
+        const size_t vo = (size_t)b * (size_t)N;
+        for (int i = tid; i < N; i += 256) {
+            double s_;
+            if (i < n) {
+                s_ = qd[(size_t)b * n + i];
+                for (int k = 0; k < p; ++k) s_ = fma(R_[(size_t)k * n + i], w_[k], s_);
+                lout[vo + i] = -__builtin_huge_val(); uout[vo + i] = __builtin_huge_val(); kind_out[vo + i] = QPN_ROW_STD;
+            } else {
+                const int r = i - n;
+                s_ = 0.0;
+                for (int k = 0; k < p; ++k) s_ = fma(B_[(size_t)k * m + r], w_[k], s_);
+                lout[vo + i] = l[(size_t)b * m + r]; uout[vo + i] = u[(size_t)b * m + r];
+                kind_out[vo + i] = QPN_ROW_GAVI;
+            }
+            qout[vo + i] = s_;
+        }
+    }
+}
+
 // ---- schedule hint: permutation of 0..count-1 by descending pivot count (counting sort, ONE workgroup) ----
 // Pivot counts are small integers; bins 0..1023 (larger counts share the last bin).  The order inside a
 // bin is whatever the atomics give -- any order is a valid schedule.
@@ -251,6 +315,12 @@ hipError_t qpn_launch_assemble_nodes(int32_t batch, int32_t n, int32_t m, int32_
                                      int32_t only_if_value)
 {
     if (batch <= 0) return hipSuccess;
+    if (n + m > 64) {
+        hipLaunchKernelGGL(assemble_nodes_wide_kernel, dim3((unsigned)batch, (unsigned)((n + m + 31) / 32)), dim3(256), 0,
+                           stream, batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, Mout, qout,
+                           lout, uout, kind_out, only_if, only_if_value);
+        return hipGetLastError();
+    }
     const int wpb = 4;
     hipLaunchKernelGGL(assemble_nodes_kernel, dim3((batch + wpb - 1) / wpb), dim3(wpb * WAVE), 0,
                        stream, batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, Mout, qout,

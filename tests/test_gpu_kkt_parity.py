@@ -12,8 +12,9 @@ INF = np.inf
 
 def test_assemble_nodes_bit_exact(engine, oracle):
     from qpn_amd.engine import colmajor
-    for n, m, p in [(32, 32, 8), (5, 9, 3), (7, 0, 2), (3, 4, 0)]:
-        cnt = 16
+    # the last three shapes take the one-workgroup-per-column-strip kernel of large nodes (N > 64)
+    for n, m, p in [(32, 32, 8), (5, 9, 3), (7, 0, 2), (3, 4, 0), (40, 33, 3), (97, 130, 2), (130, 31, 1)]:
+        cnt = 16 if n + m <= 64 else 3
         Q, R, qd, A, B, l, u = P.synth_nodes(100, cnt, n, m, p if p else 1)
         if p == 0:
             R = np.zeros((cnt, n, 0)); B = np.zeros((cnt, m, 0)); w = np.zeros(0)
