@@ -302,7 +302,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         TL(1, J) = MFMA(au1, vraw, TL(1, J));                                                       \
     }
 #define M_STEP(KB, JP, GP)                                                                          \
-    if (!fail) {                                                                                    \
+    if (!fail && 4 * (KB) < n) {       /* a block of padded rows is an identity pivot: nothing moves */ \
         constexpr int p0 = 4 * (KB);                                                                \
         constexpr int cq = p0 & 15;                                                                 \
         const int kcol = lc - cq;                                                                   \
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         }
     };
 #define M_SK(I, g, kk)                                                                              \
-    {                                                                                               \
+    if (4 * (kk) < n) {                /* rows of W beyond n are zero */                             \
         const double a0_ = aop(0, kk), a1_ = aop(1, kk);                                            \
         SB(0, 0) = MFMA(a0_, TL(I, 2)[g], SB(0, 0)); SB(0, 1) = MFMA(a0_, TL(I, 3)[g], SB(0, 1));   \
         SB(1, 0) = MFMA(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = MFMA(a1_, TL(I, 3)[g], SB(1, 1));   \
