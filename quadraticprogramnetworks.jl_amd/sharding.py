@@ -104,7 +104,9 @@ class SharedIterate:
         # every rank takes part in both handshakes whatever happens locally, and all ranks raise together
         mine, err = None, None
         try:
-            self.addr, hx = eng.shared_alloc(self.nbytes)
+            # fine-grained: peers store into this buffer while kernels of this GPU read it in later sweeps -- no stale
+            # L2 lines to rely on a kernel-boundary invalidate for
+            self.addr, hx = eng.shared_alloc(self.nbytes, fine_grained=True)
             self.box, hb = eng.shared_alloc(SWEEP_BOX_BYTES, fine_grained=True)
             mine = (hx, hb)
         except Exception as e:                      # noqa: BLE001 -- reported to all ranks below
