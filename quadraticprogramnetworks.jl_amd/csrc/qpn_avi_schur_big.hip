@@ -486,7 +486,15 @@ __global__ __launch_bounds__(TPB) void schur_big_finish(AviBatchArgs a, SchurBig
     double nres = 0.0;
     for (int k = tid; k < N; k += TPB) {
         double rk = a.q[vo + k];
-        for (int j = 0; j < N; ++j) {
+        int j = 0;
+        for (; j + 8 <= N; j += 8) {                       // eight column entries in flight; a zero z_j contributes nothing
+            double mv[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) mv[q8] = Mg[(size_t)(j + q8) * N + k];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) { const double zj = zs[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
+        }
+        for (; j < N; ++j) {
             const double zj = zs[j];
             if (zj != 0.0) rk = fma(Mg[(size_t)j * N + k], zj, rk);
         }
