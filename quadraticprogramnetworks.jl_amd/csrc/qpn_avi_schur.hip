@@ -87,9 +87,34 @@ __device__ __forceinline__ double rcp64(double x)
     return fma(r, e, r);
 }
 
-template <bool NODES>
+constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resident at once: 16 per CU, 256 CUs
+
+template <bool NODES, int STAGGER = 0>
 __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
+    if constexpr (NODES) {
+        // The wavefronts resident from the start of a launch all begin at once: one burst of loads (HBM-bound: the first
+        // round's load phase is 3x a later one's), then four waves per SIMD in lock-step through the same phases.
+        // Those waves therefore start slot by slot: hardware wave slot s of a SIMD waits s x 1.7 us before its first
+        // load (+2.5 % on the 10 000-node launch; later waves are staggered by their predecessors' finishing times).
+        // STAGGER = size of that resident set, a template constant (a kernel argument would cost registers in the loops).
+        // One asm block (scalar only): no control flow for the register allocator to work around.
+        if constexpr (STAGGER > 0) {
+            asm volatile("s_cmp_ge_u32 %[bx], %[lim]\n\t"
+                         "s_cbranch_scc1 .Lstg_end%=\n\t"
+                         "s_getreg_b32 vcc_lo, hwreg(HW_REG_HW_ID, 0, 2)\n"     // wave_id[1:0]: the slot within the SIMD
+                         ".Lstg_loop%=:\n\t"
+                         "s_cmp_eq_u32 vcc_lo, 0\n\t"
+                         "s_cbranch_scc1 .Lstg_end%=\n\t"
+                         "s_sleep 64\n\t"                                       // 64 x 64 clocks
+                         "s_sub_u32 vcc_lo, vcc_lo, 1\n\t"
+                         "s_branch .Lstg_loop%=\n"
+                         ".Lstg_end%=:"
+                         :
+                         : [bx] "s"((unsigned)blockIdx.x), [lim] "n"(STAGGER)
+                         : "scc", "vcc");
+        }
+    }
     const int N = NODES ? a.nd.n + a.nd.m : a.N;
     const int l = threadIdx.x;
     int b = blockIdx.x;
@@ -942,6 +967,21 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
 #else
     const unsigned pad = 0;
 #endif
-    hipLaunchKernelGGL(avi_solve_schur<true>, dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+    // resident wavefronts of this kernel: 16 per CU (LDS- and VGPR-bound, see the kernel header)
+    static int resident[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (resident[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        resident[dev] = 16 * cus;
+    }
+    static const bool no_stagger = [] { const char *e = getenv("QPN_NO_STAGGER"); return e && e[0] == '1'; }();   // A/B switch
+    // a partial round has no burst to spread; other CU counts (partitioned modes) run without the stagger
+    if (!no_stagger && resident[dev] == kResidentMI355X && a.batch > kResidentMI355X)
+        hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+    else
+        hipLaunchKernelGGL((avi_solve_schur<true, 0>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
     return hipGetLastError();
 }
