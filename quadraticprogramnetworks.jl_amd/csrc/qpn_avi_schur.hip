@@ -123,6 +123,9 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         if (a.order) { b = a.order[blockIdx.x]; if ((unsigned)b >= (unsigned)a.batch) return; }
     }
     const int lc = l & 15, lq = l >> 4;
+    // l & 15 recomputed on the spot (one v_and) where the pivot loop compares it: kept in a register for the whole
+    // kernel it is what the allocator spills to scratch first
+    auto lc_now = [&]() -> int { int t_ = l; asm volatile("" : "+v"(t_)); return t_ & 15; };
 
     // Stage A scratch (sU: pivot columns, [row][k]) and Stage B / read-back scratch never live at the
     // same time: one buffer.
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         // ---- entering column -> sucol, permuted so that a lane group reads its 8 rows as 8 consecutive doubles
         // (row r = q + 4 g + 16 Ib sits at q*8 + 4 Ib + g)
         if (c == XC) { if (actb) sucol[(l & 3) * 8 + ((l >> 4) << 2) + ((l >> 2) & 3)] = tcol; }
-        else if (lc == (c & 15)) {
+        else if (lc_now() == (c & 15)) {
             d4 *const dst = reinterpret_cast<d4 *>(sucol + lq * 8);
             if (c < 16) { dst[0] = d4{SD(0, 0, 0), SD(0, 0, 1), SD(0, 0, 2), SD(0, 0, 3)}; dst[1] = d4{SD(1, 0, 0), SD(1, 0, 1), SD(1, 0, 2), SD(1, 0, 3)}; }
             else { dst[0] = d4{SD(0, 1, 0), SD(0, 1, 1), SD(0, 1, 2), SD(0, 1, 3)}; dst[1] = d4{SD(1, 1, 0), SD(1, 1, 1), SD(1, 1, 2), SD(1, 1, 3)}; }
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 double tcn = fma(-cm, vx, tc0);
                 if (l == r) { xbn = enter_val; tcn = -vx; }
                 xb = xbn; tcol = tcn;
-                mcol = __ballot(lc == (c & 15)); mrow = __ballot(lq == rq);
+                mcol = __ballot(lc_now() == (c & 15)); mrow = __ballot(lq == rq);
                 cx = c;
             }
             STAMP(3);   // pivot row through LDS
