@@ -87,6 +87,9 @@ __device__ __forceinline__ double rcp64(double x)
     return fma(r, e, r);
 }
 
+#ifndef QPN_STG_UNIT
+#define QPN_STG_UNIT 64       /* stagger step of the first round: 64 x 64 clocks = 1.7 us per wave slot */
+#endif
 constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resident at once: 16 per CU, 256 CUs
 
 template <bool NODES, int STAGGER = 0>
@@ -106,12 +109,12 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                          ".Lstg_loop%=:\n\t"
                          "s_cmp_eq_u32 vcc_lo, 0\n\t"
                          "s_cbranch_scc1 .Lstg_end%=\n\t"
-                         "s_sleep 64\n\t"                                       // 64 x 64 clocks
+                         "s_sleep %[unit]\n\t"                                  // unit x 64 clocks
                          "s_sub_u32 vcc_lo, vcc_lo, 1\n\t"
                          "s_branch .Lstg_loop%=\n"
                          ".Lstg_end%=:"
                          :
-                         : [bx] "s"((unsigned)blockIdx.x), [lim] "n"(STAGGER)
+                         : [bx] "s"((unsigned)blockIdx.x), [lim] "n"(STAGGER), [unit] "n"(QPN_STG_UNIT)
                          : "scc", "vcc");
         }
     }
