@@ -211,17 +211,18 @@ __global__ __launch_bounds__(1024) void sweep_status_kernel(const int32_t *statu
     const int t = threadIdx.x;
     int bad = 0;
     double mx = 0.0;
-    for (int base = 0; base < count; base += 4096) {                  // 8 loads in flight per thread and pass
-        int st[4];
-        double r[4];
+    constexpr int PER = 12;                                            // 24 loads in flight per thread and pass: one
+    for (int base = 0; base < count; base += PER * 1024) {            // round trip covers 12 288 items
+        int st[PER];
+        double r[PER];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int i = base + k * 1024 + t;
             st[k] = i < count ? status[i] : QPN_SUCCESS;
             r[k] = (resid && i < count) ? resid[i] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PER; ++k) {
             bad += st[k] != QPN_SUCCESS;
             mx = (r[k] > mx || r[k] != r[k]) ? r[k] : mx;              // a NaN residual sticks
         }
