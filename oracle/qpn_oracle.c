@@ -682,7 +682,7 @@ int qpo_verify_solution(int n, int m, int p, const double *Qd, const double *R, 
     }
     {
         /* :98-103 */
-        uint8_t *cls = (uint8_t *)malloc((size_t)m); /* 0 none, 1 pos, 2 neg, 3 both */
+        uint8_t *cls = (uint8_t *)malloc(m > 0 ? (size_t)m : 1); /* 0 none, 1 pos, 2 neg, 3 both */
         int np = 0, nn = 0, nb = 0;
         for (int i = 0; i < m; ++i) {
             int pos = ax[i] < l[i] + 1e-2, neg = ax[i] > u[i] - 1e-2;
