@@ -107,13 +107,16 @@ __global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
     const int myrow = lane < k ? srow[lane] : 0;
     const double mysg = lane < k ? ssg[lane] : 0.0;
     double rhs = 0.0;
+    // the k x k Gram entries are spread over all 64 lanes (k lanes with k entries each would leave most of the wave
+    // idle); every entry is the same ascending fma chain over t as before
+    for (int e = lane; e < k * k; e += WAVE) {
+        const int c1 = e % k, c2 = e / k;
+        const int r1 = srow[c1], r2 = srow[c2];
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s = fma(sA[t * LDV + r1], sA[t * LDV + r2], s);
+        sGa[c2 * LDV + c1] = s * ssg[c1] * ssg[c2];
+    }
     if (lane < k) {
-        for (int c2 = 0; c2 < k; ++c2) {
-            const int r2 = srow[c2];
-            double s = 0.0;
-            for (int t = 0; t < n; ++t) s = fma(sA[t * LDV + myrow], sA[t * LDV + r2], s);
-            sGa[c2 * LDV + lane] = s * mysg * ssg[c2];
-        }
         for (int t = 0; t < n; ++t) rhs = fma(sA[t * LDV + myrow], sqt[t], rhs);
         rhs *= mysg;
     }
