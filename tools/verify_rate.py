@@ -15,7 +15,8 @@ t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=
 args = [t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u)]
 res = eng.solve_nodes(*args, t(w))
 x = res["z"][:, :n].contiguous()
-for tag, xd in (("at the solution", x), ("perturbed 1e-3", x + 1e-3 * torch.randn_like(x))):
+for tag, xd in (("at the solution", x), ("perturbed 1e-3", x + 1e-3 * torch.randn_like(x)),
+                ("perturbed 1e-2 inwards", x * (1.0 - 1e-2))):
     for _ in range(3): sol, lam, path = eng.verify_nodes(*args, xd, t(w))
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
