@@ -269,6 +269,23 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores(omp_threads):
+    """Threads the CPU baseline may really use: OpenMP's count, capped by the affinity mask and by the cgroup CPU quota
+    (on the GPU box the job owns 16 of the host's 256 hardware threads: more threads only burst and get throttled)."""
+    c = omp_threads
+    try:
+        c = min(c, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            c = min(c, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, int(c))
+
+
 def cpu_baseline(Q, R, qd, A, B, l, u, w):
     """The CPU oracle (a port -- NOT Julia+PATH, which cannot run here) on the same node records,
     all host cores, OpenMP over nodes.  Bounded: the 10 000-node batch, best of 3 passes."""
@@ -287,11 +304,11 @@ def cpu_baseline(Q, R, qd, A, B, l, u, w):
     kind = np.concatenate([np.zeros((cnt, n), np.uint8), np.ones((cnt, m), np.uint8)], axis=1)
     z0 = np.zeros((cnt, N))
     Mc = np.ascontiguousarray(Mc.reshape(cnt, N * N))
-    cores = ob.num_threads()
-    # one untimed pass (thread pool, page faults), then whole passes until ~0.25 s of wall time = tens of core-seconds
+    cores = host_cores(ob.num_threads())
+    # one untimed pass (thread pool, page faults), then whole passes until ~1 s of wall time = tens of core-seconds
     ob.solve_avi_batch_colmajor(Mc, N * N, q, lo, hi, z0, np.ascontiguousarray(kind), N, nthreads=cores)
     solved, spent, passes = 0, 0.0, 0
-    while passes < 5 or (spent < 0.25 and passes < 200):
+    while passes < 5 or (spent < 1.0 and passes < 200):
         t0 = time.perf_counter()
         r = ob.solve_avi_batch_colmajor(Mc, N * N, q, lo, hi, z0, np.ascontiguousarray(kind), N, nthreads=cores)
         spent += time.perf_counter() - t0
