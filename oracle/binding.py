@@ -73,7 +73,21 @@ def default_opts() -> Opts:
 
 
 def num_threads() -> int:
-    return int(lib().qpo_num_threads())
+    """Threads the oracle should use: OpenMP's count capped by the affinity mask and the cgroup CPU quota (more
+    threads than the quota only burst and are then throttled)."""
+    import os
+    c = int(lib().qpo_num_threads())
+    try:
+        c = min(c, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            c = min(c, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, c)
 
 
 def check_avi_solution(M, q, l, u, z, kind=None, tol=1e-6):
@@ -138,7 +152,7 @@ def solve_avi_batch(M, q, l, u, z0=None, kind=None, opts=None, nthreads=0):
     nfail = lib().qpo_solve_avi_batch(batch, N, _p(Mc), C.c_long(strideM), _p(q), _p(l), _p(u),
                                       _p(k, C.c_uint8), C.c_long(sk), _p(z), C.byref(o),
                                       _p(status, C.c_int32), _p(resid), _p(pivots, C.c_int32),
-                                      _p(active, C.c_uint8), int(nthreads))
+                                      _p(active, C.c_uint8), int(nthreads) or num_threads())
     return dict(z=z, status=status, resid=resid, pivots=pivots, active=active, nfail=int(nfail))
 
 
@@ -153,7 +167,7 @@ def solve_avi_batch_colmajor(Mc, strideM, q, l, u, z0, kind, stride_kind, nthrea
     nfail = lib().qpo_solve_avi_batch(batch, N, _p(Mc), C.c_long(strideM), _p(q), _p(l), _p(u),
                                       _p(kind, C.c_uint8), C.c_long(stride_kind), _p(z),
                                       C.byref(o), _p(status, C.c_int32), _p(resid),
-                                      _p(pivots, C.c_int32), None, int(nthreads))
+                                      _p(pivots, C.c_int32), None, int(nthreads) or num_threads())
     return dict(z=z, status=status, resid=resid, pivots=pivots, nfail=int(nfail))
 
 
