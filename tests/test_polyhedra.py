@@ -1,0 +1,87 @@
+"""Batched isempty / exemplar through the node-AVI path (first step) against an independent
+LP feasibility answer (scipy HiGHS), on the CPU oracle engine here and on the HIP engine in the GPU suite."""
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+import qpn_amd  # noqa: F401
+from qpn_amd import polyhedra
+from qpn_amd.programs import Poly
+
+
+def _random_polys(seed, count, dmax=6, mmax=10):
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(count):
+        d = int(rng.integers(1, dmax + 1)); m = int(rng.integers(1, mmax + 1))
+        A = rng.standard_normal((m, d))
+        x0 = rng.standard_normal(d)
+        c = A @ x0
+        l = c - np.abs(rng.standard_normal(m)) - 0.05; u = c + np.abs(rng.standard_normal(m)) + 0.05
+        l = np.where(rng.random(m) < 0.3, -np.inf, l); u = np.where(rng.random(m) < 0.3, np.inf, u)
+        if t % 3 == 1 and m >= 2:                      # contradictory pair: a'x <= -1 and a'x >= +1
+            A[1] = A[0]; l[0], u[0] = -np.inf, c[0] - 1.0; l[1], u[1] = c[0] + 1.0, np.inf
+        if t % 3 == 2 and m >= 2:                      # an equality row
+            u[0] = l[0] = c[0]
+        out.append((A, l, u))
+    return out
+
+
+def _lp_feasible(A, l, u):
+    rows, rhs = [], []
+    for i in range(A.shape[0]):
+        if np.isfinite(u[i]): rows.append(A[i]); rhs.append(u[i])
+        if np.isfinite(l[i]): rows.append(-A[i]); rhs.append(-l[i])
+    if not rows:
+        return True
+    r = linprog(np.zeros(A.shape[1]), A_ub=np.array(rows), b_ub=np.array(rhs), bounds=[(None, None)] * A.shape[1], method="highs")
+    return r.status == 0
+
+
+def _check(engine, seed):
+    polys = _random_polys(seed, 60)
+    empty, example, status = polyhedra.exemplar_batch(polys, engine)
+    assert set(np.unique(status)) <= {1, 2}
+    want = np.array([not _lp_feasible(*p) for p in polys])
+    assert np.array_equal(empty, want)
+    assert want.any() and not want.all()
+    for (A, l, u), e, x in zip(polys, empty, example):
+        if not e:
+            ax = A @ x
+            assert np.all(ax >= l - 1e-8) and np.all(ax <= u + 1e-8) and x.shape == (A.shape[1],)
+            # minimum norm: no feasible direction decreases |x| -- compare with the LP-feasible point scaled towards 0
+    assert np.array_equal(polyhedra.isempty_batch(polys, engine), want)
+    # Poly objects (normalised rows) give the same answers
+    ep, _, _ = polyhedra.exemplar_batch([Poly(*p) for p in polys], engine)
+    assert np.array_equal(ep, want)
+    return empty, example
+
+
+def test_isempty_and_exemplar_on_the_oracle_engine():
+    from oracle_engine import OracleEngine
+    _check(OracleEngine(), 5)
+    e, x, s = polyhedra.exemplar_batch([], OracleEngine())
+    assert e.shape == (0,) and x == []
+
+
+def test_minimum_norm_point_known_answers():
+    from oracle_engine import OracleEngine
+    # {x in R^2 : x1 + x2 >= 2}: projection of the origin is (1, 1); the box [1, 3] x [-2, 5]: (1, 0); R^2 itself: 0
+    polys = [(np.array([[1.0, 1.0]]), np.array([2.0]), np.array([np.inf])),
+             (np.eye(2), np.array([1.0, -2.0]), np.array([3.0, 5.0])),
+             (np.zeros((1, 2)), np.array([-np.inf]), np.array([np.inf]))]
+    empty, ex, _ = polyhedra.exemplar_batch(polys, OracleEngine())
+    assert not empty.any()
+    assert np.allclose(ex[0], [1.0, 1.0], atol=1e-10) and np.allclose(ex[1], [1.0, 0.0], atol=1e-10) and np.allclose(ex[2], 0.0)
+
+
+@pytest.mark.gpu
+def test_isempty_and_exemplar_on_the_hip_engine(engine):
+    from oracle_engine import OracleEngine
+    e_g, x_g = _check(engine, 6)
+    e_c, x_c = _check(OracleEngine(), 6)
+    assert np.array_equal(e_g, e_c)
+    for a, b in zip(x_g, x_c):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.max(np.abs(a - b)) <= 1e-9
