@@ -68,3 +68,48 @@ def isempty_batch(polys, engine):
     if bad.size:
         raise RuntimeError(f"isempty_batch: solver status {status[bad[0]]} on item {int(bad[0])}")
     return empty
+
+
+def issubset_batch(pairs, engine, tol=1e-6):
+    """`P1 ⊆ P2` (src/sets.jl:376-407) for a batch of pairs -> bool [len(pairs)].
+
+    The reference minimises +-a'x over P1 for every finite bound of P2 (one OSQP LP each) and answers false when a
+    minimum falls below the bound by more than `tol` or the LP is unbounded.  Equivalently: P1 ⊆ P2 iff, for every
+    finite bound of P2, P1 intersected with the closed half-space beyond that bound (moved out by `tol`) is EMPTY --
+    one emptiness query per bound, all pairs and bounds in one `isempty_batch` call.  An empty P1 is a subset of
+    anything (the reference's LP is infeasible there and it answers false; noted, not mirrored)."""
+    queries, owner = [], []
+    for k, (P1, P2) in enumerate(pairs):
+        A1, l1, u1 = (P1.vectorize() if hasattr(P1, "vectorize") else P1)
+        A2, l2, u2 = (P2.vectorize() if hasattr(P2, "vectorize") else P2)
+        A1 = np.atleast_2d(np.asarray(A1, dtype=np.float64)); A2 = np.atleast_2d(np.asarray(A2, dtype=np.float64))
+        for i in range(A2.shape[0]):
+            if np.isfinite(l2[i]):          # a violation is a point of P1 with a'x <= l2 - tol
+                queries.append((np.vstack([A1, A2[i:i + 1]]), np.append(l1, -INF), np.append(u1, l2[i] - tol))); owner.append(k)
+            if np.isfinite(u2[i]):          # ... or with a'x >= u2 + tol
+                queries.append((np.vstack([A1, A2[i:i + 1]]), np.append(l1, u2[i] + tol), np.append(u1, INF))); owner.append(k)
+    out = np.ones(len(pairs), bool)
+    if queries:
+        empty = isempty_batch(queries, engine)
+        for e, k in zip(empty, owner):
+            if not e:
+                out[k] = False
+    return out
+
+
+def remove_subsets(polys, engine, tol=1e-6):
+    """`remove_subsets(pu::PolyUnion)` (src/sets.jl:889-902): drop every polyhedron that is a subset of another one
+    still kept, scanning in order like the reference; all k (k - 1) subset tests run as one batch first.
+    -> (kept polys, is_subset mask)."""
+    k = len(polys)
+    idx = [(i, j) for i in range(k) for j in range(k) if i != j]
+    sub = np.zeros((k, k), bool)
+    if idx:
+        res = issubset_batch([(polys[i], polys[j]) for i, j in idx], engine, tol=tol)
+        for (i, j), r in zip(idx, res):
+            sub[i, j] = r
+    is_subset = np.zeros(k, bool)
+    for i in range(k):
+        if any(j != i and not is_subset[j] and sub[i, j] for j in range(k)):
+            is_subset[i] = True
+    return [p for p, s in zip(polys, is_subset) if not s], is_subset

@@ -85,3 +85,61 @@ def test_isempty_and_exemplar_on_the_hip_engine(engine):
         assert (a is None) == (b is None)
         if a is not None:
             assert np.max(np.abs(a - b)) <= 1e-9
+
+
+def _subset_by_lp(P1, P2, tol=1e-6):
+    """The reference's definition (src/sets.jl:376-407) with scipy-HiGHS as the LP solver; P1 assumed non-empty."""
+    A1, l1, u1 = P1; A2, l2, u2 = P2
+    rows, rhs = [], []
+    for i in range(A1.shape[0]):
+        if np.isfinite(u1[i]): rows.append(A1[i]); rhs.append(u1[i])
+        if np.isfinite(l1[i]): rows.append(-A1[i]); rhs.append(-l1[i])
+    kw = dict(A_ub=np.array(rows), b_ub=np.array(rhs)) if rows else {}
+    for i in range(A2.shape[0]):
+        for bound, dirn in ((l2[i], 1.0), (u2[i], -1.0)):
+            if np.isfinite(bound):
+                r = linprog(dirn * A2[i], bounds=[(None, None)] * A1.shape[1], method="highs", **kw)
+                if r.status != 0 or r.fun < dirn * bound - tol:
+                    return False
+    return True
+
+
+def _boxes_and_slabs(seed, count, d=3):
+    rng = np.random.default_rng(seed)
+    polys = []
+    for t in range(count):
+        c = rng.standard_normal(d); h = 0.2 + rng.random(d) * (2.0 if t % 2 else 0.6)
+        G = np.eye(d) if t % 3 else np.linalg.qr(rng.standard_normal((d, d)))[0]
+        l = G @ c - h; u = G @ c + h
+        if t % 4 == 3: u[0] = np.inf                     # an unbounded slab
+        polys.append((G, l, u))
+    return polys
+
+
+def test_issubset_and_remove_subsets_match_the_lp_definition():
+    from oracle_engine import OracleEngine
+    eng = OracleEngine()
+    polys = _boxes_and_slabs(3, 9)
+    big = (np.eye(3), np.full(3, -50.0), np.full(3, 50.0))          # contains every bounded one
+    polys.append(big)
+    pairs = [(polys[i], polys[j]) for i in range(len(polys)) for j in range(len(polys)) if i != j]
+    got = polyhedra.issubset_batch(pairs, eng)
+    want = np.array([_subset_by_lp(a, b) for a, b in pairs])
+    assert np.array_equal(got, want) and want.any() and not want.all()
+    kept, mask = polyhedra.remove_subsets(polys, eng)
+    # replay of the reference's loop on the LP answers
+    k = len(polys); ref = np.zeros(k, bool)
+    for i in range(k):
+        if any(j != i and not ref[j] and _subset_by_lp(polys[i], polys[j]) for j in range(k)):
+            ref[i] = True
+    assert np.array_equal(mask, ref) and len(kept) == k - int(ref.sum()) and not mask[-1]
+
+
+@pytest.mark.gpu
+def test_issubset_on_the_hip_engine(engine):
+    from oracle_engine import OracleEngine
+    polys = _boxes_and_slabs(4, 12) + [(np.eye(3), np.full(3, -50.0), np.full(3, 50.0))]
+    pairs = [(polys[i], polys[j]) for i in range(len(polys)) for j in range(len(polys)) if i != j]
+    g = polyhedra.issubset_batch(pairs, engine)
+    c = polyhedra.issubset_batch(pairs, OracleEngine())
+    assert np.array_equal(g, c) and np.array_equal(g, np.array([_subset_by_lp(a, b) for a, b in pairs]))
