@@ -142,6 +142,8 @@ def main():
     # device every REFRESH steps, INSIDE the timed region; it changes which wavefront solves which node, nothing else.
     REFRESH = 16
     use_sched = not (args.no_schedule or args.unfused)
+    if not use_sched:
+        eng.set_auto_schedule(0)               # natural node order: also switch the context's own refresh off
 
     def maybe_refresh(i, res):
         if use_sched and res is not None and (i == 1 or i % REFRESH == 0):      # first sweep's counts, then periodically

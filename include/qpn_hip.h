@@ -162,6 +162,12 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
  * NULL, clears the hint.  The hint is ignored whenever batch != count. */
 int qpn_order_nodes_by_pivots(qpn_ctx *ctx, const int32_t *pivots, int32_t count, int mem);
 int qpn_set_node_order(qpn_ctx *ctx, const int32_t *order, int32_t count, int mem);
+/* By default the context does this by itself: a qpn_solve_nodes[_into] call that fills the GPU (batch > 4096, n, m <= 32)
+ * and returns pivot counts refreshes the hint from them every `period`-th call of the same batch size (default 16; the
+ * first call of a batch size installs it), one 8 us launch behind the solve.  A hint installed through the two
+ * functions above takes precedence until qpn_set_node_order(ctx, NULL, ...) clears it; period = 0 switches the
+ * mechanism off.  Results never depend on any of this. */
+int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period);
 
 /* ---- multi-GPU: replicas of the iterate on peer GPUs, written by the solve itself -----------------------
  * One process per GPU; rank g solves its own node range and every rank needs the whole iterate x for the

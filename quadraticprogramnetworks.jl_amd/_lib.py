@@ -17,7 +17,7 @@ ABI_SYMBOLS = (
     "qpn_assemble_nodes", "qpn_solve_nodes", "qpn_solve_nodes_into", "qpn_order_nodes_by_pivots",
     "qpn_set_node_order", "qpn_verify_nodes",
     "qpn_shared_alloc", "qpn_shared_open", "qpn_shared_close", "qpn_shared_free", "qpn_set_primal_mirrors",
-    "qpn_sweep_status",
+    "qpn_sweep_status", "qpn_ctx_set_auto_schedule",
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -85,6 +85,7 @@ def load_library():
                                          vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(AviOpts), C.c_int, vp, C.c_int64]
     lib.qpn_order_nodes_by_pivots.argtypes = [vp, vp, C.c_int32, C.c_int]
     lib.qpn_set_node_order.argtypes = [vp, vp, C.c_int32, C.c_int]
+    lib.qpn_ctx_set_auto_schedule.argtypes = [vp, C.c_int32]
     lib.qpn_verify_nodes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
     lib.qpn_shared_alloc.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp), vp]

@@ -21,6 +21,12 @@ struct qpn_ctx {
     int32_t *order = nullptr;
     int32_t order_count = 0;      // 0 = no hint installed
     int32_t order_cap = 0;
+    // automatic schedule hint (qpn_ctx_set_auto_schedule): refreshed from a call's own pivot counts every `period`
+    // calls of the same batch size, unless the caller has installed a hint of their own
+    int32_t auto_period = 16;
+    int32_t auto_calls = 0;
+    int32_t auto_batch = 0;
+    bool order_user = false;
     // replicas of the iterate on peer GPUs (qpn_set_primal_mirrors)
     const double *mirror_own = nullptr;
     size_t mirror_bytes = 0;
@@ -48,6 +54,8 @@ int fail_arg(qpn_ctx *ctx, const char *msg)
         hipError_t e__ = (call);                                 \
         if (e__ != hipSuccess) return fail_hip(ctx, e__, #call); \
     } while (0)
+
+int order_reserve(qpn_ctx *ctx, int32_t count);
 
 // carve `bytes` (256-B aligned) out of the ctx workspace; grows it when needed
 struct Carver {
@@ -512,6 +520,17 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
         g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
         g.only_if = dst; g.only_if_value = -1; g.scan = 1; g.assemble_first = 1;
         HIPCHK(ctx, qpn_launch_avi_solve_reg(g, s));
+        // automatic longest-first schedule for the NEXT calls over this batch (launches that fill the GPU only)
+        if (ctx->auto_period > 0 && !ctx->order_user && dpv && batch > 4096) {
+            if (ctx->auto_batch != batch) { ctx->auto_batch = batch; ctx->auto_calls = 0; }
+            if (ctx->auto_calls % ctx->auto_period == 0) {
+                rc = order_reserve(ctx, batch);
+                if (rc != QPN_OK) return rc;
+                HIPCHK(ctx, qpn_launch_order_by_pivots(dpv, batch, ctx->order, s));
+                ctx->order_count = batch;
+            }
+            ctx->auto_calls++;
+        }
     } else {
         HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, wM, wq, wl,
                                               wu, wk, s));
@@ -671,13 +690,14 @@ int qpn_order_nodes_by_pivots(qpn_ctx *ctx, const int32_t *pivots, int32_t count
     HIPCHK(ctx, qpn_launch_order_by_pivots(dp, count, ctx->order, ctx->stream));
     if (mem == QPN_MEM_HOST) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->order_count = count;
+    ctx->order_user = true;
     return QPN_OK;
 }
 
 int qpn_set_node_order(qpn_ctx *ctx, const int32_t *order, int32_t count, int mem)
 {
     if (!ctx) return QPN_ERR_ARG;
-    if (!order) { ctx->order_count = 0; return QPN_OK; }
+    if (!order) { ctx->order_count = 0; ctx->order_user = false; ctx->auto_calls = 0; return QPN_OK; }
     if (count <= 0) return fail_arg(ctx, "qpn_set_node_order: bad count");
     if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_set_node_order: bad mem kind");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -687,6 +707,17 @@ int qpn_set_node_order(qpn_ctx *ctx, const int32_t *order, int32_t count, int me
                                mem == QPN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     if (mem == QPN_MEM_HOST) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->order_count = count;
+    ctx->order_user = true;
+    return QPN_OK;
+}
+
+int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (period < 0) return fail_arg(ctx, "qpn_ctx_set_auto_schedule: negative period");
+    ctx->auto_period = period;
+    ctx->auto_calls = 0;
+    if (period == 0 && !ctx->order_user) ctx->order_count = 0;      // drop a hint this mechanism installed
     return QPN_OK;
 }
 

@@ -297,6 +297,11 @@ class Engine:
                                                 MEM_DEVICE if dev else MEM_HOST)
         self._chk(rc, "qpn_order_nodes_by_pivots")
 
+    def set_auto_schedule(self, period=16):
+        """Period (in calls) of the context's own longest-first schedule refresh for solve_nodes batches that fill the
+        GPU; 0 switches it off.  An explicit hint (order_nodes_by_pivots / set_node_order) takes precedence."""
+        self._chk(self.lib.qpn_ctx_set_auto_schedule(self.ctx, int(period)), "qpn_ctx_set_auto_schedule")
+
     def set_node_order(self, order=None):
         """Install a caller-made permutation of the nodes as the schedule (None clears the hint)."""
         if order is None:

@@ -184,3 +184,24 @@ def test_order_by_pivots_is_a_sorted_permutation(engine):
         assert np.array_equal(r["z"], ref["z"]) and np.all(r["status"] == 1)
     finally:
         engine.set_node_order(None)
+
+
+def test_automatic_schedule_changes_nothing_in_the_results(engine, full):
+    """The context refreshes a longest-first hint by itself for batches that fill the GPU (qpn_ctx_set_auto_schedule):
+    consecutive calls -- natural order first, hinted afterwards -- and a run with the mechanism off agree bit for bit."""
+    import torch
+    _, dev, res, _ = full
+    try:
+        engine.set_node_order(None)
+        engine.set_auto_schedule(2)
+        for _ in range(4):
+            r = engine.solve_nodes(*dev)
+            torch.cuda.synchronize()
+            for k in ("z", "status", "active", "pivots"):
+                assert np.array_equal(r[k].cpu().numpy(), res[k]), k
+        engine.set_auto_schedule(0)
+        r = engine.solve_nodes(*dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["z"].cpu().numpy(), res["z"])
+    finally:
+        engine.set_auto_schedule(16)
