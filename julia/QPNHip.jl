@@ -134,6 +134,8 @@ function order_nodes_by_pivots!(pivots::Vector{Int32})
     rc == 0 || error("qpn_order_nodes_by_pivots failed ($rc)")
     nothing
 end
+# period (in calls) of the context's own refresh of that hint; 0 = off (default 16)
+set_auto_schedule!(period::Integer) = (ccall((:qpn_ctx_set_auto_schedule, LIB), Cint, (Ptr{Cvoid}, Int32), ctx(), Int32(period)); nothing)
 clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), C_NULL, Int32(0), QPN_MEM_HOST); nothing)
 
 # ---- multi-GPU (one Julia process per GPU, e.g. under MPI.jl / Distributed): replicas of the iterate ----
