@@ -43,8 +43,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: 0.12 s of timed region -- runs of a few ms read 3 % low (the first tens of ms after an idle period)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--nodes", type=int, default=NODES, help="nodes per GPU (weak) / in the whole net (strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--exchange", choices=("p2p", "rccl"), default="p2p", help="N > 1: how the iterate is replicated")
