@@ -158,17 +158,50 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
     } else Tt = Ttg;
 
     // ---- fill the top half (row-major) and take max |M| over the WHOLE item ------------------------------
-    for (int i = tid; i < n_pad; i += TPB)
-        for (int j = 0; j < ldc; ++j) Tt[(size_t)i * ldc + j] = (i >= n && j == i) ? 1.0 : 0.0;
-    __syncthreads();
     double mabs = 0.0;
-    for (int j = 0; j < N; ++j) {
-        const int jj = j < n ? j : n_pad + (j - n);
-        for (int i = tid; i < N; i += TPB) {
-            const double v = Mg[(size_t)j * N + i];            // coalesced over i
-            mabs = fmax(mabs, fabs(v));
-            if (i < n) Tt[(size_t)i * ldc + jj] = v;
+    if constexpr (LDS_TT) {
+        for (int i = tid; i < n_pad; i += TPB)
+            for (int j = 0; j < ldc; ++j) Tt[(size_t)i * ldc + j] = (i >= n && j == i) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int j = 0; j < N; ++j) {
+            const int jj = j < n ? j : n_pad + (j - n);
+            for (int i = tid; i < N; i += TPB) {
+                const double v = Mg[(size_t)j * N + i];            // coalesced over i
+                mabs = fmax(mabs, fabs(v));
+                if (i < n) Tt[(size_t)i * ldc + jj] = v;
+            }
         }
+    } else {
+        // M is column-major, the workspace row-major: a transpose.  Zeros / identity padding first, coalesced along
+        // the rows of the workspace; then the top half in 32 x 32 tiles through LDS (the U' area is free here), read
+        // along the columns of M and written along the rows of the workspace -- both sides in 256-byte runs (the
+        // element-wise version wrote every double of a 1 MB block to its own cache line: 1.8 of stage A's 4.0 ms).
+        for (int idx = tid; idx < n_pad * ldc; idx += TPB) {
+            const int i = idx / ldc, j = idx - i * ldc;
+            Tt[idx] = (i >= n && j == i) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        double *const tile = sUp;                               // [32][33]
+        const int tx = tid & 31, ty = tid >> 5;
+        for (int i0 = 0; i0 < n; i0 += 32)
+            for (int j0 = 0; j0 < N; j0 += 32) {
+#pragma unroll
+                for (int r = ty; r < 32; r += TPB / 32) {       // tile[col r][row tx] <- M[i0 + tx][j0 + r]
+                    const int i = i0 + tx, j = j0 + r;
+                    const double v = (i < N && j < N) ? Mg[(size_t)j * N + i] : 0.0;
+                    if (i < n) mabs = fmax(mabs, fabs(v));       // rows >= n are covered by the sweep below
+                    tile[r * 33 + tx] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = ty; r < 32; r += TPB / 32) {       // workspace row i0 + r, columns j0 + tx
+                    const int i = i0 + r, j = j0 + tx;
+                    if (i < n && j < N) Tt[(size_t)i * ldc + (j < n ? j : n_pad + (j - n))] = tile[tx * 33 + r];
+                }
+                __syncthreads();
+            }
+        for (int j = 0; j < N; ++j)                             // max |M| over the bottom half too
+            for (int i = n + tid; i < N; i += TPB) mabs = fmax(mabs, fabs(Mg[(size_t)j * N + i]));
     }
     for (int i = tid; i < n; i += TPB) Tt[(size_t)i * ldc + xcol] = a.q[vo + i];
     const double mscale = sb_block_max(mabs, S, tid);
@@ -384,6 +417,90 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
     double *Sg = w.S + (size_t)b * (size_t)w.s_stride;
     double *cg = w.c + vo;
     const int mt = m_pad / 16;
+    // Large items (the HBM-workspace variant, with the U' panels' LDS free again): the four waves share ONE 8 x 8
+    // super-block of output tiles (a 4 x 4 quadrant each) and the operand slabs of 16 k-values are staged through
+    // LDS by the whole workgroup, coalesced -- an operand byte then feeds four waves instead of one: 2.1 MB of
+    // operand traffic per item at n = m = 256 instead of 5 MB.  The extra column c = b - A h is a separate pass.
+    constexpr int SBK = 16, SBW = 128, SBLD = SBW + 4;               // slab depth, super-block width (rows / cols), padded ld
+    const bool staged = !LDS_TT && (size_t)lds_rows * LDU >= (size_t)2 * SBK * SBLD && mt >= 8;
+    if (staged) {
+        double *const As = sUp, *const Ws = sUp + SBK * SBLD;        // As[k][row], Ws[k][col]
+        const int rsb = (mt + 7) / 8, csb = (mt + 7) / 8;
+        const int qi = wave >> 1, qj = wave & 1;
+        for (int sb = 0; sb < rsb * csb; ++sb) {
+            const int I00 = 8 * (sb / csb), J00 = 8 * (sb % csb);
+            const int I0 = I00 + 4 * qi, J0 = J00 + 4 * qj;
+            d4 acc[4][4];
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ri = 16 * (I0 + bi) + 4 * g + lq, cj = 16 * (J0 + bj) + lc;
+                        acc[bi][bj][g] = (ri < m && cj < m) ? Mg[(size_t)(n + cj) * N + n + ri] : 0.0;
+                    }
+            for (int k0 = 0; k0 < n_pad; k0 += SBK) {
+                __syncthreads();                                     // the previous slab has been consumed
+                {
+                    const int r = tid & (SBW - 1), kq = tid >> 7;    // 256 threads: 128 rows (cols) x 2 k-phases
+                    double va[SBK / 2], vw[SBK / 2];
+#pragma unroll
+                    for (int i2 = 0; i2 < SBK / 2; ++i2) {
+                        const int k = k0 + kq + 2 * i2;
+                        const int ar = 16 * I00 + r, wc = 16 * J00 + r;
+                        const bool oka = k < n && ar < m;
+                        va[i2] = oka ? -Mg[(size_t)k * N + n + ar] : 0.0;
+                        vw[i2] = (k < n_pad && wc < m_pad) ? Tt[(size_t)k * ldc + n_pad + wc] : 0.0;
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < SBK / 2; ++i2) {
+                        As[(kq + 2 * i2) * SBLD + r] = va[i2];
+                        Ws[(kq + 2 * i2) * SBLD + r] = vw[i2];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < SBK / 4; ++kk) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int bi = 0; bi < 4; ++bi) av[bi] = As[(4 * kk + lq) * SBLD + 16 * (4 * qi + bi) + lc];
+#pragma unroll
+                    for (int bj = 0; bj < 4; ++bj) bv[bj] = Ws[(4 * kk + lq) * SBLD + 16 * (4 * qj + bj) + lc];
+#pragma unroll
+                    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+                        for (int bj = 0; bj < 4; ++bj) acc[bi][bj] = MFMA(av[bi], bv[bj], acc[bi][bj]);
+                }
+            }
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ri = 16 * (I0 + bi) + 4 * g + lq, cj = 16 * (J0 + bj) + lc;
+                        if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = acc[bi][bj][g];
+                    }
+        }
+        // c = b - A h, one row per thread, k ascending (h = column xcol of the top half)
+        __syncthreads();
+        for (int k = tid; k < n; k += TPB) As[k] = Tt[(size_t)k * ldc + xcol];
+        __syncthreads();
+        for (int ri = tid; ri < m; ri += TPB) {
+            double acc_c = a.q[vo + n + ri];
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {                              // eight column entries in flight
+                double mv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = Mg[(size_t)(k + q8) * N + n + ri];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) acc_c = fma(-mv[q8], As[k + q8], acc_c);
+            }
+            for (; k < n; ++k) acc_c = fma(-Mg[(size_t)k * N + n + ri], As[k], acc_c);
+            cg[ri] = acc_c;
+        }
+    } else {
     // Register-blocked: a wave owns a block of GB x GB output tiles and streams k -- per k-step GB + GB operand
     // loads feed GB * GB MFMAs (one operand load per 2 MFMAs instead of 2 per MFMA), two k-steps of operands in
     // flight.  Tiles outside the item multiply zeros on clamped addresses and are not stored.
@@ -447,6 +564,7 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
                     if (I < mt && J < mt) { if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = acc[bi][bj][g]; }
                     else if (I < mt && J == mt && lc == 0 && ri < m) cg[ri] = acc[bi][bj][g];
                 }
+    }
     }
     if constexpr (LDS_TT) {
         __syncthreads();
