@@ -181,27 +181,44 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
             Tt[idx] = (i >= n && j == i) ? 1.0 : 0.0;
         }
         __syncthreads();
-        double *const tile = sUp;                               // [32][33]
+        double *const tile = sUp;                               // 4 tiles of [32][33]: 16 loads per thread in flight
         const int tx = tid & 31, ty = tid >> 5;
         for (int i0 = 0; i0 < n; i0 += 32)
-            for (int j0 = 0; j0 < N; j0 += 32) {
+            for (int j0 = 0; j0 < N; j0 += 128) {
+                double v[4][4];
 #pragma unroll
-                for (int r = ty; r < 32; r += TPB / 32) {       // tile[col r][row tx] <- M[i0 + tx][j0 + r]
-                    const int i = i0 + tx, j = j0 + r;
-                    const double v = (i < N && j < N) ? Mg[(size_t)j * N + i] : 0.0;
-                    if (i < n) mabs = fmax(mabs, fabs(v));       // rows >= n are covered by the sweep below
-                    tile[r * 33 + tx] = v;
-                }
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {            // tile q4 [col r][row tx] <- M[i0 + tx][j0 + 32 q4 + r]
+                        const int i = i0 + tx, j = j0 + 32 * q4 + ty + 8 * rr;
+                        v[q4][rr] = (i < N && j < N) ? Mg[(size_t)j * N + i] : 0.0;
+                    }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        if (i0 + tx < n) mabs = fmax(mabs, fabs(v[q4][rr]));    // rows >= n are covered by the sweep below
+                        tile[q4 * 1056 + (ty + 8 * rr) * 33 + tx] = v[q4][rr];
+                    }
                 __syncthreads();
 #pragma unroll
-                for (int r = ty; r < 32; r += TPB / 32) {       // workspace row i0 + r, columns j0 + tx
-                    const int i = i0 + r, j = j0 + tx;
-                    if (i < n && j < N) Tt[(size_t)i * ldc + (j < n ? j : n_pad + (j - n))] = tile[tx * 33 + r];
-                }
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {            // workspace row i0 + r, columns j0 + 32 q4 + tx
+                        const int r = ty + 8 * rr, i = i0 + r, j = j0 + 32 * q4 + tx;
+                        if (i < n && j < N) Tt[(size_t)i * ldc + (j < n ? j : n_pad + (j - n))] = tile[q4 * 1056 + tx * 33 + r];
+                    }
                 __syncthreads();
             }
-        for (int j = 0; j < N; ++j)                             // max |M| over the bottom half too
-            for (int i = n + tid; i < N; i += TPB) mabs = fmax(mabs, fabs(Mg[(size_t)j * N + i]));
+        for (int j = 0; j < N; j += 8) {                        // max |M| over the bottom half too, 8 columns in flight
+            for (int i = n + tid; i < N; i += TPB) {
+                double mv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = (j + q8 < N) ? Mg[(size_t)(j + q8) * N + i] : 0.0;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mabs = fmax(mabs, fabs(mv[q8]));
+            }
+        }
     }
     for (int i = tid; i < n; i += TPB) Tt[(size_t)i * ldc + xcol] = a.q[vo + i];
     const double mscale = sb_block_max(mabs, S, tid);
@@ -981,7 +998,9 @@ hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBi
         }
     }
     const size_t rows_lds = rows < 512 ? rows : 512;
-    hipLaunchKernelGGL(schur_big_stage_a<false>, dim3((unsigned)batch), dim3(TPB), rows_lds * LDU * sizeof(double), stream, a, w,
+    size_t lds_dbl = rows_lds * LDU;
+    if (lds_dbl < 4 * 1056) lds_dbl = 4 * 1056;          // the fill's four transpose tiles
+    hipLaunchKernelGGL(schur_big_stage_a<false>, dim3((unsigned)batch), dim3(TPB), lds_dbl * sizeof(double), stream, a, w,
                        (int)rows_lds, 0, 0);
     return hipGetLastError();
 }
