@@ -636,9 +636,12 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
     void *sb = workspace + (size_t)a.batch * (size_t)N * (size_t)(N + 1);
     uint8_t *ones = reinterpret_cast<uint8_t *>(static_cast<char *>(sb) + qpn_schur_big_workspace_bytes(a.batch, N));
     SchurBigWs w{};
-    hipError_t e = qpn_launch_schur_big_stage_a(a, sb, &w, stream);
-    if (e != hipSuccess) return e;
     static const bool lemke_general = [] { const char *e = getenv("QPN_AVI_BIG_LEMKE"); return e && e[0] == 'g'; }();
+    // node path with m <= 64 (uniform, known here): the Schur problems go to the one-wavefront register kernel
+    const bool lemke_reg = !lemke_general && a.nd.Qd && a.nd.m >= 1 && a.nd.m <= 64 && a.nd.n + a.nd.m == N &&
+                           (a.max_pivots <= 0 || a.max_pivots - a.nd.n >= 1);
+    hipError_t e = qpn_launch_schur_big_stage_a(a, sb, &w, !(lemke_general || lemke_reg), stream);
+    if (e != hipSuccess) return e;
     if (lemke_general) {
         // A/B path: the general large-item kernel on the Schur problem (per-item sizes), one full dictionary pass per pivot
         hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, ones, N);
@@ -650,10 +653,9 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
         r.max_pivots = a.max_pivots; r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
         r.only_if = a.status; r.only_if_value = -2;
         e = launch_big_kernel(r, dict, stream);
-    } else if (a.nd.Qd && a.nd.m >= 1 && a.nd.m <= 64 && a.nd.n + a.nd.m == N &&
-               (a.max_pivots <= 0 || a.max_pivots - a.nd.n >= 1)) {
-        // node path with m <= 64 (uniform, known here): the Schur problems are all-GAVI items of size m -- the
-        // one-wavefront register kernel solves them (same pivot rule), no workgroup barriers, no dictionary in HBM
+    } else if (lemke_reg) {
+        // the Schur problems are all-GAVI items of size m -- the one-wavefront register kernel solves them (same pivot
+        // rule), no workgroup barriers, no dictionary in HBM
         hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, ones, N);
         AviBatchArgs r{};
         r.batch = a.batch; r.N = a.nd.m; r.vec_stride = N;

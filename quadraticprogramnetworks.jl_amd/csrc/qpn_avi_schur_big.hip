@@ -497,7 +497,7 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int ri = 16 * (I0 + bi) + 4 * g + lq, cj = 16 * (J0 + bj) + lc;
-                        if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = acc[bi][bj][g];
+                        if (ri < m && cj < m) Sg[w.s_rowmajor ? (size_t)ri * m + cj : (size_t)cj * m + ri] = acc[bi][bj][g];
                     }
         }
         // c = b - A h, one row per thread, k ascending (h = column xcol of the top half)
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
                 for (int g = 0; g < 4; ++g) {
                     const int I = I0 + bi, J = J0 + bj;
                     const int ri = 16 * I + 4 * g + lq, cj = 16 * J + lc;
-                    if (I < mt && J < mt) { if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = acc[bi][bj][g]; }
+                    if (I < mt && J < mt) { if (ri < m && cj < m) Sg[w.s_rowmajor ? (size_t)ri * m + cj : (size_t)cj * m + ri] = acc[bi][bj][g]; }
                     else if (I < mt && J == mt && lc == 0 && ri < m) cg[ri] = acc[bi][bj][g];
                 }
     }
@@ -719,8 +719,12 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
     }
     if (tid == 0) { colvar[m] = VTH; cnb[m] = 0.0; }
     // T_base = [S | 0]: S is column-major, read coalesced over rows
-    for (int j = 0; j < m; ++j)
-        for (int i = tid; i < m; i += TPB) Tb[(size_t)i * ld + j] = Sg[(size_t)j * m + i];
+    if (w.s_rowmajor) {
+        for (int idx = tid; idx < m * m; idx += TPB) { const int i = idx / m, j = idx - i * m; Tb[(size_t)i * ld + j] = Sg[idx]; }
+    } else {
+        for (int j = 0; j < m; ++j)
+            for (int i = tid; i < m; i += TPB) Tb[(size_t)i * ld + j] = Sg[(size_t)j * m + i];
+    }
     __syncthreads();
 
     int pivots = 0, status = QPN_FAILURE, npend = 0;
@@ -954,13 +958,14 @@ size_t qpn_schur_big_workspace_bytes(int batch, int N)
 }
 
 // Carves `ws` (qpn_schur_big_workspace_bytes) and runs stage A; fills `out` for the later launches.
-hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, hipStream_t stream)
+hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, int s_rowmajor, hipStream_t stream)
 {
     const int N = a.N, batch = a.batch;
     const size_t rows = (size_t)((N + 15) & ~15);
     SchurBigWs w{};
     w.tt_stride = (int64_t)((rows < 512 ? rows : 512) * (size_t)(((N + 15) & ~15) + 48));
     w.s_stride = (int64_t)N * N;
+    w.s_rowmajor = s_rowmajor ? 1 : 0;
     double *p = static_cast<double *>(ws);
     w.Tt = p; p += (size_t)batch * w.tt_stride;
     w.S = p; p += (size_t)batch * w.s_stride;

@@ -80,9 +80,11 @@ struct SchurBigWs {
     double *Tt, *S, *c, *l2, *u2, *lam;
     int32_t *st2, *piv2, *nsplit, *nred;
     int64_t tt_stride, s_stride;
+    int32_t s_rowmajor;      // layout of S: row-major for the workgroup Lemke kernel (its dictionary is row-major: no
+                             // transposition anywhere), column-major for the kernels that take S as an ABI-layout M
 };
 size_t qpn_schur_big_workspace_bytes(int batch, int N);
-hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, hipStream_t stream);
+hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, int s_rowmajor, hipStream_t stream);
 hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
 hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream);
 
