@@ -160,17 +160,23 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
     // ---- fill the top half (row-major) and take max |M| over the WHOLE item ------------------------------
     double mabs = 0.0;
     if constexpr (LDS_TT) {
-        for (int i = tid; i < n_pad; i += TPB)
-            for (int j = 0; j < ldc; ++j) Tt[(size_t)i * ldc + j] = (i >= n && j == i) ? 1.0 : 0.0;
-        __syncthreads();
-        for (int j = 0; j < N; ++j) {
-            const int jj = j < n ? j : n_pad + (j - n);
-            for (int i = tid; i < N; i += TPB) {
-                const double v = Mg[(size_t)j * N + i];            // coalesced over i
-                mabs = fmax(mabs, fabs(v));
-                if (i < n) Tt[(size_t)i * ldc + jj] = v;
-            }
+        for (int idx = tid; idx < n_pad * ldc; idx += TPB) {
+            const int i = idx / ldc, j = idx - i * ldc;
+            Tt[idx] = (i >= n && j == i) ? 1.0 : 0.0;
         }
+        __syncthreads();
+        for (int j0 = 0; j0 < N; j0 += 8)                          // eight columns in flight (a column is one load per thread:
+            for (int i = tid; i < N; i += TPB) {                   // one at a time is a chain of N memory round trips)
+                double v[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) v[q8] = (j0 + q8 < N) ? Mg[(size_t)(j0 + q8) * N + i] : 0.0;   // coalesced over i
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    const int j = j0 + q8;
+                    mabs = fmax(mabs, fabs(v[q8]));
+                    if (i < n && j < N) Tt[(size_t)i * ldc + (j < n ? j : n_pad + (j - n))] = v[q8];
+                }
+            }
     } else {
         // M is column-major, the workspace row-major: a transpose.  Zeros / identity padding first, coalesced along
         // the rows of the workspace; then the top half in 32 x 32 tiles through LDS (the U' area is free here), read
