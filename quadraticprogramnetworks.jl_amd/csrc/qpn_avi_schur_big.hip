@@ -165,18 +165,19 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
             Tt[idx] = (i >= n && j == i) ? 1.0 : 0.0;
         }
         __syncthreads();
-        for (int j0 = 0; j0 < N; j0 += 8)                          // eight columns in flight (a column is one load per thread:
-            for (int i = tid; i < N; i += TPB) {                   // one at a time is a chain of N memory round trips)
-                double v[8];
+        // all N x N entries spread over the 256 threads (a column is only N <= ~100 long here), eight loads in flight each
+        for (int e0 = 0; e0 < N * N; e0 += 8 * TPB) {
+            double v[8];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) v[q8] = (j0 + q8 < N) ? Mg[(size_t)(j0 + q8) * N + i] : 0.0;   // coalesced over i
+            for (int q8 = 0; q8 < 8; ++q8) { const int e = e0 + q8 * TPB + tid; v[q8] = e < N * N ? Mg[e] : 0.0; }   // coalesced
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) {
-                    const int j = j0 + q8;
-                    mabs = fmax(mabs, fabs(v[q8]));
-                    if (i < n && j < N) Tt[(size_t)i * ldc + (j < n ? j : n_pad + (j - n))] = v[q8];
-                }
+            for (int q8 = 0; q8 < 8; ++q8) {
+                const int e = e0 + q8 * TPB + tid;
+                const int j = e / N, i = e - j * N;
+                mabs = fmax(mabs, fabs(v[q8]));
+                if (e < N * N && i < n) Tt[(size_t)i * ldc + (j < n ? j : n_pad + (j - n))] = v[q8];
             }
+        }
     } else {
         // M is column-major, the workspace row-major: a transpose.  Zeros / identity padding first, coalesced along
         // the rows of the workspace; then the top half in 32 x 32 tiles through LDS (the U' area is free here), read
@@ -216,14 +217,18 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_stage_a(AviBatchArgs a, Schu
                     }
                 __syncthreads();
             }
-        for (int j = 0; j < N; j += 8) {                        // max |M| over the bottom half too, 8 columns in flight
-            for (int i = n + tid; i < N; i += TPB) {
-                double mv[8];
+        // max |M| over the bottom half too: its (N - n) x N entries spread over all threads, eight loads in flight each
+        const int mb_ = N - n;
+        for (int e0 = 0; e0 < mb_ * N; e0 += 8 * TPB) {
+            double mv[8];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = (j + q8 < N) ? Mg[(size_t)(j + q8) * N + i] : 0.0;
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mabs = fmax(mabs, fabs(mv[q8]));
+            for (int q8 = 0; q8 < 8; ++q8) {
+                const int e = e0 + q8 * TPB + tid;
+                const int j = e / mb_, i = n + (e - j * mb_);
+                mv[q8] = e < mb_ * N ? Mg[(size_t)j * N + i] : 0.0;
             }
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) mabs = fmax(mabs, fabs(mv[q8]));
         }
     }
     for (int i = tid; i < n; i += TPB) Tt[(size_t)i * ldc + xcol] = a.q[vo + i];
