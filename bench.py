@@ -1,64 +1,96 @@
 #!/usr/bin/env python3
-"""bench.py -- node-AVI solves/sec (fp64) on the synthetic 10 000-node x 32-var QPNet.
+"""bench.py -- node-AVI solves/sec (fp64) on the synthetic 10 000-node x 32-var QPNet (BASELINE.json configs[3]).
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 under torch.distributed.run,
-one rank per GPU, RCCL).  One STEP = one pass of the hot path over the whole net:
-    per rank, for its contiguous node range:
-        (A5+A6) qpn_assemble_nodes   per-node KKT blocks from the node records and the parameters w
-        (A2+A3+A9) qpn_solve_avi_batch   every node-AVI from cold duals, post-check + active sets
-    N > 1 only: every rank needs the whole iterate x for the next sweep.  Default exchange "p2p": the solve
-    kernel itself stores each primal block into every rank's replica of x over xGMI (IPC-shared buffers,
-    qpn_set_primal_mirrors) and the sweep ends with qpn_sweep_status -- a 24-byte mailbox exchange that is the
-    stop/raise decision and the barrier; no collective on the data path.  "--exchange rccl" (and the automatic
-    fallback when buffers cannot be shared or the warm-up self-check against an RCCL all-gather fails):
-    all-gather of the primal blocks + a 2-double all-reduce.
-Before the W warm-up steps the bench runs 800 untimed steps (~0.1 s; `--no-prewarm` skips them): the GPU leaves its idle
-power state only after ~0.1 s of work, and a timed region that starts earlier reads 3-10 % low whatever the code does.
-Inputs (node records) are resident in HBM before the timed region.  Independent node-AVIs partition over the
-ranks, so per-GPU work is fixed at 10 000 nodes (BASELINE.json configs[3] on every GPU; the N-GPU net has
-N x 10 000 nodes) => "scaling": "weak"; "--scaling strong" shards ONE 10 000-node net instead (latency-bound:
-a node-AVI is a ~40 us dependent pivot chain whatever the batch).  value = solved
-node-AVIs / second over all ranks (failed items do not count; there are none on this workload).
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1: one rank per GPU under torch.distributed.run, RCCL;
+started without a launcher, ``--gpus N`` starts the N ranks itself as child processes before anything touches the GPU).
 
-Extra objects on the JSON line: "roofline" (HBM bound; achieved = algorithmic bytes of SURVEY.md
-section 8(d) per solve-kernel launch / mean launch duration, measured with HIP events on the launch
-stream) and "cpu_baseline" (the CPU oracle -- a port, not PATH -- on the host cores, rank 0, N = 1).
+One STEP = one sweep of the hot path over the whole net.  Per rank, for its contiguous node range, ONE launch:
+    (A5+A6) per-node KKT blocks from the resident node records and this sweep's parameters w   } fused kernel
+    (A2+A3+A9) every node-AVI from cold duals, post-check, active sets, primal write-back      } avi_solve_schur<nodes>
+The node records are resident (qpn_nodes_upload, include/qpn_hip.h): between two sweeps of the outer loop
+(src/algorithm.jl:13-117) only the parameters change.  Every step takes the NEXT parameter vector of a ring of 64
+(w_k = w + 0.25 N(0,1), fixed seed): consecutive sweeps solve different problems (other right-hand sides, active sets and
+pivot counts), as consecutive outer iterations do, so that nothing -- the longest-first schedule hint in particular, which is
+refreshed from a sweep's own pivot counts every 16 sweeps inside the timed region -- is tuned to one repeated problem.
+N > 1: every rank needs the whole iterate x for the next sweep.  Default exchange "rccl": ONE in-place RCCL all-gather per
+sweep of [primal blocks | sweep status] (the stop/raise pair rides in the same message).  "--exchange p2p": the solve kernel
+stores each primal block into every rank's replica over xGMI and a mailbox kernel ends the sweep (no collective; checked
+against an all-gather after warm-up, and the run aborts on the first missed barrier).
+Default N > 1 mode is STRONG scaling: the ONE 10 000-node net of BASELINE configs[3] sharded over the ranks; a second,
+shorter measurement with 10 000 nodes per GPU (weak scaling) is reported in the "weak_scaling" object of the same line.
+Before the W warm-up steps the bench runs `prewarm_steps` untimed steps (~0.1 s, reported in the JSON; `--no-prewarm` skips
+them): the GPU leaves its idle power state only after ~0.1 s of work.
+value = solved node-AVIs / second over all ranks (failed items do not count; there are none on this workload).
+
+Extra objects on the JSON line: "roofline" (HBM bound; achieved = algorithmic bytes of SURVEY.md section 8(d) per launch /
+mean launch duration, measured live with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle -- a port, not
+PATH -- on the host cores, rank 0, N = 1).  ``--config 5`` measures BASELINE configs[4] (512 nodes x 256 variables) instead.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 NODES, NVAR, NCON, NPAR = 10_000, 32, 32, 8
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+FP64_PEAK_TFLOPS = 78.6   # vector = matrix fp64 (datasheet; confirmed here: 64 cycles per v_mfma_f64_16x16x4, tools/mfma_rate)
+PREWARM_STEPS = 800
+RING = 64
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 0.12 s of timed region -- runs of a few ms read 3 % low (the first tens of ms after an idle period)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--nodes", type=int, default=NODES, help="nodes per GPU (weak) / in the whole net (strong)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--exchange", choices=("p2p", "rccl"), default="p2p", help="N > 1: how the iterate is replicated")
+    ap.add_argument("--config", type=int, choices=(4, 5), default=4,
+                    help="4: 10 000 nodes x 32 variables (BASELINE configs[3], the metric's config); 5: 512 nodes x 256 variables")
+    ap.add_argument("--nodes", type=int, default=None, help="nodes in the whole net (strong) / per GPU (weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: shard ONE net (strong, BASELINE configs[3]) or give every GPU its own (weak)")
+    ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl", help="N > 1: how the iterate is replicated")
+    ap.add_argument("--no-second-scaling", action="store_true", help="N > 1: skip the second (other-mode) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="assemble M in HBM, then solve (two kernels) instead of the fused pass")
-    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL path even with one rank (testing)")
+    ap.add_argument("--per-call-records", action="store_true",
+                    help="pass the node records with every call (qpn_solve_nodes_into) instead of the resident handle")
+    ap.add_argument("--fixed-w", action="store_true", help="the same parameter vector every step (default: ring of 64)")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the distributed path even with one rank (testing)")
     ap.add_argument("--no-prewarm", action="store_true",
-                    help="skip the 800 untimed steps (~0.1 s) that bring the GPU out of its idle power state before the W warm-up steps")
+                    help=f"skip the {PREWARM_STEPS} untimed steps (~0.1 s) that bring the GPU out of its idle power state")
     ap.add_argument("--no-schedule", action="store_true",
-                    help="natural node order (default: longest-first schedule hint, refreshed from the pivot counts every 16 steps)")
-    args = ap.parse_args()
+                    help="natural node order (default: longest-first schedule refreshed from the pivot counts every 16 steps)")
+    return ap.parse_args()
+
+
+def maybe_spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (nothing here has touched the GPU yet)."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is None and args.gpus > 1:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+    if ws is not None and int(ws) != args.gpus and not args.force_dist:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+
+
+def main():
+    args = parse_args()
+    maybe_spawn_ranks(args)
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,16 +112,41 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device(f"cuda:{local_rank}")
 
     import qpn_amd
+    eng = qpn_amd.Engine(local_rank)
+    env = dict(eng=eng, dist=dist, use_dist=use_dist, world=world, rank=rank, dev=torch.device(f"cuda:{local_rank}"),
+               np=np, torch=torch)
+    if args.config == 5:
+        out = run_config5(env, args)
+    else:
+        nodes = args.nodes if args.nodes is not None else NODES
+        first = run_case(env, args, nodes, args.scaling, args.steps, args.warmup, prewarm=not args.no_prewarm,
+                         with_cpu=(world == 1 and not args.no_cpu_baseline))
+        out = first
+        if world > 1 and not args.no_second_scaling:
+            other = "weak" if args.scaling == "strong" else "strong"
+            second = run_case(env, args, nodes, other, min(args.steps, 200), min(args.warmup, 20), prewarm=False, with_cpu=False)
+            if rank == 0:
+                out[f"{other}_scaling"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")} | {
+                    "nodes": second["config"]["nodes"], "nodes_per_gpu": second["config"]["nodes_per_gpu"],
+                    "exchange": second["config"]["exchange"], "frac": second["roofline"]["frac"]}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
+    """One measurement of the config-4 sweep; returns the JSON object (on every rank; rank 0's is printed)."""
+    np, torch = env["np"], env["torch"]
+    eng, dist, use_dist, world, rank, dev = env["eng"], env["dist"], env["use_dist"], env["world"], env["rank"], env["dev"]
     from qpn_amd import sharding, synthetic
     from qpn_amd.engine import colmajor
 
-    eng = qpn_amd.Engine(local_rank)
     n, m, p = NVAR, NCON, NPAR
     N = n + m
-    total = args.nodes * world if args.scaling == "weak" else args.nodes
+    total = nodes * world if scaling == "weak" else nodes
     lo_id, hi_id = sharding.node_range(total, world, rank)
     cnt = hi_id - lo_id
 
@@ -97,11 +154,26 @@ def main():
     Q, R, qd, A, B, l, u = synthetic.synth_nodes(lo_id, cnt, n, m, p)
     w_host = synthetic.shared_params(p)
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
-    dQ, dR, dqd, dA, dB, dl, du, dw = (t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)),
-                                       t(colmajor(B)), t(l), t(u), t(w_host))
+    drec = (t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u))
+    ring_host = np.repeat(w_host[None, :], RING, axis=0)
+    if not args.fixed_w:
+        ring_host = ring_host + 0.25 * np.random.Generator(np.random.Philox(key=[synthetic.SEED, 2 ** 41])).standard_normal((RING, p))
+    ring = t(ring_host)
+    use_handle = not (args.unfused or args.per_call_records)
+    handle = eng.upload_nodes(*drec) if use_handle else None
+    use_sched = not (args.no_schedule or args.unfused)
+    REFRESH = 16
+    if handle is not None:
+        handle.set_schedule(REFRESH if use_sched else 0)     # the handle refreshes its own longest-first schedule
+    elif not use_sched:
+        eng.set_auto_schedule(0)
+    else:
+        eng.set_auto_schedule(REFRESH)
+
     counts = [sharding.node_range(total, world, r) for r in range(world)]
-    shared = None
+    shared = gathered = None
     exchange = "none"
+    x_all = None
     if use_dist:
         exchange = "rccl" if args.unfused else args.exchange      # the replica stores belong to the fused kernel
         if exchange == "p2p":
@@ -109,28 +181,43 @@ def main():
                 shared = sharding.SharedIterate(eng, dist, total, n, dev, timeout_ms=10_000)
             except RuntimeError as e:              # raised on ALL ranks together
                 if rank == 0:
-                    print(f"[bench] p2p exchange unavailable ({e}); using RCCL collectives", file=sys.stderr, flush=True)
+                    print(f"[bench] p2p exchange unavailable ({e}); using the RCCL all-gather", file=sys.stderr, flush=True)
                 exchange = "rccl (p2p setup failed)"
-    x_all = torch.zeros((total, n), dtype=torch.float64, device=dev) if shared is None else None
+        if shared is None:
+            if len({hi - lo for lo, hi in counts}) == 1:
+                gathered = sharding.GatheredIterate(eng, dist, total, n, dev)
+            else:
+                x_all = torch.zeros((total, n), dtype=torch.float64, device=dev)
+    else:
+        x_all = torch.zeros((total, n), dtype=torch.float64, device=dev)
     sweep_out = torch.zeros(4, dtype=torch.float64, device=dev)
-    ev_pairs = []
     bufs = {"asm": None, "sol": None}      # output buffers are allocated once and reused
+    kstep = [0]
 
-    def step(record):
+    def step():
+        w = ring[kstep[0] % RING]
+        kstep[0] += 1
+        if shared is not None:
+            xloc = shared.x[lo_id:hi_id]
+        elif gathered is not None:
+            xloc = gathered.x_local
+        else:
+            xloc = x_all[lo_id:hi_id]
         if args.unfused:
-            bufs["asm"] = eng.assemble_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["asm"])
+            bufs["asm"] = eng.assemble_nodes(*drec, w, out=bufs["asm"])
             Mc, q, lo, hi, kind = bufs["asm"]
             res = bufs["sol"] = eng.solve_avi_batch(Mc, q, lo, hi, kind=kind, out=bufs["sol"])   # cold start
-            xloc = res["z"][:, :n].contiguous()
-            if not use_dist:
-                x_all[lo_id:hi_id].copy_(xloc)
+            xloc.copy_(res["z"][:, :n])
+        elif handle is not None:
+            # (A5+A6+A2+A3+A9) one fused pass over the resident records: KKT blocks assembled on the fly inside the solve
+            # kernel, primal blocks written straight into this rank's rows of the iterate x
+            res = bufs["sol"] = handle.solve(w, out=bufs["sol"], x_out=xloc)
         else:
-            # (A5+A6+A2+A3+A9) one fused pass: KKT blocks assembled on the fly inside the solve kernel,
-            # primal blocks written straight into this rank's rows of the iterate x
-            xloc = (shared.x if shared is not None else x_all)[lo_id:hi_id]
-            res = bufs["sol"] = eng.solve_nodes(dQ, dR, dqd, dA, dB, dl, du, dw, out=bufs["sol"], x_out=xloc)
+            res = bufs["sol"] = eng.solve_nodes(*drec, w, out=bufs["sol"], x_out=xloc)
         if shared is not None:
             shared.finish_sweep(res["status"], res["resid"])       # mailbox exchange: status pair + barrier
+        elif gathered is not None:
+            gathered.finish_sweep(res["status"], res["resid"])     # ONE all-gather: primal blocks + status pair
         elif use_dist:
             sharding.all_gather_primal(x_all, xloc, counts, dist)
             eng.sweep_status(res["status"], res["resid"], sweep_out)
@@ -141,18 +228,6 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-
-    # Schedule hint (qpn_order_nodes_by_pivots): the outer loop sweeps the same nodes again and again, so the
-    # pivot counts of one sweep order the next ones longest-first (shorter launch tail).  It is refreshed on the
-    # device every REFRESH steps, INSIDE the timed region; it changes which wavefront solves which node, nothing else.
-    REFRESH = 16
-    use_sched = not (args.no_schedule or args.unfused)
-    if not use_sched:
-        eng.set_auto_schedule(0)               # natural node order: also switch the context's own refresh off
-
-    def maybe_refresh(i, res):
-        if use_sched and res is not None and (i == 1 or i % REFRESH == 0):      # first sweep's counts, then periodically
-            eng.order_nodes_by_pivots(res["pivots"])
 
     def p2p_ok():
         """Self-check of the p2p route (outside the timed region): every replica equals what a collective all-gather of
@@ -165,58 +240,69 @@ def main():
         return float(okv) == 1.0 and not os.environ.get("QPN_BENCH_FORCE_FALLBACK")      # (the env: fallback rehearsal)
 
     def drop_p2p(why):
-        nonlocal shared, exchange, x_all
+        nonlocal shared, exchange, gathered, x_all
         if rank == 0:
-            print(f"[bench] p2p exchange failed its self-check ({why}); using RCCL collectives", file=sys.stderr, flush=True)
+            print(f"[bench] p2p exchange failed its self-check ({why}); using the RCCL all-gather", file=sys.stderr, flush=True)
         shared.close(); shared = None
         exchange = f"rccl (p2p self-check failed: {why})"
-        x_all = torch.zeros((total, n), dtype=torch.float64, device=dev)
+        if len({hi - lo for lo, hi in counts}) == 1:
+            gathered = sharding.GatheredIterate(eng, dist, total, n, dev)
+        else:
+            x_all = torch.zeros((total, n), dtype=torch.float64, device=dev)
+
+    def p2p_poll(where):
+        """The mailbox waits are bounded (10 s each): a lost peer must end the run at once, not after steps x 10 s."""
+        if shared is not None and float(shared.out[3]) != 0.0:
+            print(f"[bench] rank {rank}: a sweep barrier of the p2p exchange was missed ({where}); aborting", file=sys.stderr, flush=True)
+            os._exit(3)
 
     res = None
     if shared is not None:
         # probe first, with a short mailbox timeout: a route that does not work must cost seconds, not the warm-up
         barrier()
         shared.timeout_ms = 2_000
-        res = step(False); res = step(False)
+        res = step(); res = step()
         barrier()
         if p2p_ok():
             shared.timeout_ms = 10_000
+            shared.out[3] = 0.0
         else:
             drop_p2p("probe")
-    if not args.no_prewarm:
+    prewarm_steps = 0
+    if prewarm:
         # Power state, not warm-up of the code: a timed region that starts less than ~0.1 s after the GPU's first launch
-        # reads 3-4 % low whatever W is (200 steps after 20: 81.5 M, after 1 000: 84.9 M -- same binary).  These
-        # steps are not counted in W or K and nothing of them is kept.
-        for _ in range(800):                   # ~0.1 s; a fixed count: every rank runs the same number of sweeps (mailbox epochs)
-            res = step(False)
+        # reads 3-4 % low whatever W is.  These steps are not counted in W or K and nothing of them is kept.
+        for i in range(PREWARM_STEPS):            # a fixed count: every rank runs the same number of sweeps (mailbox epochs)
+            res = step()
+            if shared is not None and i % 100 == 99:
+                p2p_poll("pre-warm")
         torch.cuda.synchronize()
-        res = None
-    for i in range(args.warmup):
-        maybe_refresh(i, res)
-        res = step(False)
+        prewarm_steps = PREWARM_STEPS
+    for i in range(warmup):
+        res = step()
     barrier()
     if shared is not None:
-        if args.warmup > 0 and not p2p_ok():
+        p2p_poll("warm-up")
+        if warmup > 0 and not p2p_ok():
             drop_p2p("after warm-up")
-            for i in range(min(args.warmup, 5)):
-                res = step(False)
+            for i in range(min(warmup, 5)):
+                res = step()
             barrier()
-        else:
-            shared.out[3] = 0.0                # start-up skew may have cost a wait before; the timed region may not miss one
-    # ONE pair of HIP events brackets the whole timed region on the launch stream (a pair per step costs two
-    # barrier packets per step, ~10 us of pipeline bubbles -- measured); the per-launch duration reported in
-    # "roofline" is elapsed / steps, i.e. it also carries the near-empty fallback launch and the launch gaps
-    # (and, for N > 1, the all-gather): an upper bound of the solve kernel's own duration.
+    # ONE pair of HIP events brackets the whole timed region on the launch stream (a pair per step costs two barrier packets
+    # per step, ~10 us of pipeline bubbles -- measured); the per-launch duration reported in "roofline" is elapsed / steps,
+    # i.e. it also carries the launch gaps, the schedule refresh every 16th step (and, for N > 1, the exchange): an upper
+    # bound of the solve kernel's own duration.
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(args.steps):
-        maybe_refresh(i + args.warmup, res)
-        res = step(True)
+    for i in range(steps):
+        res = step()
+        if shared is not None and i % REFRESH == REFRESH - 1:
+            p2p_poll("timed region")
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    ev_pairs.append((ev0, ev1))
+    kern_ms = ev0.elapsed_time(ev1) / max(steps, 1)
 
     sweep_ok = shared is None or float(shared.out[3]) == 0.0        # no barrier of the timed region was missed
     solved_local = int((res["status"] == 1).sum().item()) if sweep_ok else 0      # a missed barrier voids the run
@@ -228,60 +314,76 @@ def main():
         dt, solved, max_resid = float(mx[0]), int(sm[1]), float(mx[2])
     else:
         solved = solved_local
-    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev_pairs])) / max(args.steps, 1) if ev_pairs else float("nan")
+    info = handle.info() if handle is not None else None
 
-    if rank == 0:
-        per_solve = synthetic.algorithmic_bytes(n, m)
-        achieved = per_solve * cnt / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get("avi_solve_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # fp64 pipe utilisation of the dominant kernel from the committed PMC pass (rocprofv3 --pmc, own run):
-        # (VALU-active + MFMA-busy cycles) / wall cycles per SIMD; SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in
-        # units of 4 cycles, 4 waves share a SIMD
-        pipe = None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pj):
-            try:
-                sq = json.load(open(pj)).get("avi_solve_schur_sq_per_launch", {})
-                pipe = (4.0 * sq["SQ_ACTIVE_INST_VALU"] + sq["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * sq["SQ_WAVE_CYCLES"] / 4.0)
-            except Exception:
-                pipe = None
-        out = {
-            "metric": baseline_metric(),
-            "value": solved * args.steps / dt / 1.0,
-            "unit": "solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {total}-node x {n}-var two-level QPNet "
-                                   f"(n=m={n}, N_red={N}, p={p}; BASELINE.json configs[3]); step = "
-                                   "KKT assembly + cold-start AVI solve + check + active sets ("
-                                   + ("two kernels" if args.unfused else "one fused kernel") + ")"
-                                   + ((" + primal blocks stored into every rank's replica of x by the solve kernel (xGMI p2p) + mailbox status/barrier kernel"
-                                       if shared is not None else " + RCCL all-gather of primals + 2-double all-reduce") if use_dist else "")
-                                   + ("; longest-first node schedule refreshed from the previous sweep's pivot counts every 16 steps" if use_sched else ""),
-                       "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p,
-                       "sharding": f"node ranges over {world} GPU(s)", "exchange": exchange,
-                       "max_resid": max_resid, "solved": solved},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "avi_solve_schur<nodes> (+ gated fallback launches)" if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt,
-                         "fp64_pipe_busy_frac": pipe},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Q, R, qd, A, B, l, u, w_host)
-        print(json.dumps(out), flush=True)
+    per_solve = synthetic.algorithmic_bytes(n, m)
+    achieved = per_solve * cnt / (kern_ms * 1e-3) / 1e9
+    route = ("two kernels (assemble, solve)" if args.unfused else
+             "one fused kernel over resident node records (qpn_solve_nodes_h)" if handle is not None else
+             "one fused kernel + one gated general-kernel launch, records passed per call (qpn_solve_nodes_into)")
     if use_dist:
-        if shared is not None:
-            shared.close()
-        dist.destroy_process_group()
+        xch = (" + primal blocks stored into every rank's replica of x by the solve kernel (xGMI p2p) + mailbox status/barrier kernel"
+               if shared is not None else
+               " + ONE in-place RCCL all-gather of [primal blocks | sweep status]" if gathered is not None else
+               " + RCCL all-gather of primals + 4-double all-reduce")
+    else:
+        xch = ""
+    out = {
+        "metric": baseline_metric(),
+        "value": solved * steps / dt,
+        "unit": "solves/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "prewarm_steps": prewarm_steps,
+        "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {total}-node x {n}-var two-level QPNet (n=m={n}, N_red={N}, p={p}; BASELINE.json "
+                               f"configs[3]); step = KKT assembly + cold-start AVI solve + check + active sets + primal "
+                               f"write-back, {route}{xch}; parameters: "
+                               + ("the same vector every step" if args.fixed_w else f"ring of {RING} vectors, the next one every step")
+                               + ("; longest-first node schedule refreshed from a sweep's own pivot counts every 16 steps" if use_sched else "; natural node order"),
+                   "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p,
+                   "sharding": f"node ranges over {world} GPU(s)", "scaling": scaling, "exchange": exchange,
+                   "w_ring": 1 if args.fixed_w else RING, "schedule": "longest-first/16" if use_sched else "natural",
+                   "nodes_needing_general_kernel": (info["declined"] if info and info["decline_state"] >= 2 else None),
+                   "max_resid": max_resid, "solved": solved},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "kernel": "avi_solve_schur<nodes>" if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt} | committed_counters(),
+    }
+    if with_cpu and rank == 0:
+        out["cpu_baseline"] = cpu_baseline(np, Q, R, qd, A, B, l, u, w_host)
+    if handle is not None:
+        handle.close()
+    if shared is not None:
+        shared.close()
+    return out
+
+
+def committed_counters():
+    """HBM traffic and fp64-pipe occupancy of the dominant kernel come from rocprofv3 --pmc passes (own runs: counters cannot
+    be collected inside a timed run) -- the committed summary of the latest one, tagged with where it came from.  They
+    describe the build they were measured on, not necessarily this run's."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        pj = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pj):
+            continue
+        try:
+            d = json.load(open(pj))
+            sq = d.get("avi_solve_schur_sq_per_launch", {})
+            # (VALU-active + MFMA-busy cycles) / wall cycles per SIMD; SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in
+            # units of 4 cycles, 4 waves share a SIMD
+            pipe = (4.0 * sq["SQ_ACTIVE_INST_VALU"] + sq["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * sq["SQ_WAVE_CYCLES"] / 4.0)
+            traffic = d.get("avi_solve_hbm_bytes_per_launch")
+            if traffic is None:
+                tj = os.path.join(ROOT, "profiles", "traffic.json")
+                traffic = json.load(open(tj)).get("avi_solve_hbm_bytes_per_launch") if os.path.exists(tj) else None
+            return {"traffic": traffic, "fp64_pipe_busy_frac": pipe,
+                    "counters_source": f"profiles/{name} (committed rocprofv3 --pmc summary"
+                                       + (f", measured at commit {d['commit']}" if d.get("commit") else "") + "; not measured by this run)"}
+        except Exception:
+            continue
+    return {"traffic": None}
 
 
 def baseline_metric():
@@ -309,9 +411,9 @@ def host_cores(omp_threads):
     return max(1, int(c))
 
 
-def cpu_baseline(Q, R, qd, A, B, l, u, w):
-    """The CPU oracle (a port -- NOT Julia+PATH, which cannot run here) on the same node records,
-    all host cores, OpenMP over nodes.  Bounded: the 10 000-node batch, best of 3 passes."""
+def cpu_baseline(np, Q, R, qd, A, B, l, u, w, budget_s=1.0):
+    """The CPU oracle (a port -- NOT Julia+PATH, which cannot run here) on the same node records, the host cores of the
+    job's CPU quota, OpenMP over nodes.  Bounded: whole passes over the batch until ~1 s of wall time."""
     from oracle import binding as ob
     ob.build()
     cnt, n = qd.shape
@@ -331,17 +433,81 @@ def cpu_baseline(Q, R, qd, A, B, l, u, w):
     # one untimed pass (thread pool, page faults), then whole passes until ~1 s of wall time = tens of core-seconds
     ob.solve_avi_batch_colmajor(Mc, N * N, q, lo, hi, z0, np.ascontiguousarray(kind), N, nthreads=cores)
     solved, spent, passes = 0, 0.0, 0
-    while passes < 5 or (spent < 1.0 and passes < 200):
+    while passes < 3 or (spent < budget_s and passes < 200):
         t0 = time.perf_counter()
         r = ob.solve_avi_batch_colmajor(Mc, N * N, q, lo, hi, z0, np.ascontiguousarray(kind), N, nthreads=cores)
         spent += time.perf_counter() - t0
         solved += cnt - r["nfail"]
         passes += 1
-    best = solved / spent
-    return {"value": best, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"the same {cnt}-node batch (solve only, blocks pre-assembled), {passes} passes = {spent:.2f} s "
+    return {"value": solved / spent, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"the same {cnt}-node batch (n=m={n}; solve only, blocks pre-assembled), {passes} passes = {spent:.2f} s "
                       f"wall on {cores} threads after one untimed pass, CPU restatement oracle/qpn_oracle.c with OpenMP "
                       "-- not Julia+PATH"}
+
+
+def run_config5(env, args):
+    """BASELINE configs[4]: 512 nodes x 256 variables (n = m = 256, N_red = 512), the large per-node KKT path (blocked MFMA
+    crash + delayed-update Lemke, csrc/qpn_avi_schur_big.hip).  Bound: fp64 matrix/vector pipe; flops per solve =
+    N^3/3 (one factorisation) + 2 N^2 per pivot, pivots from the kernel's own counter."""
+    np, torch = env["np"], env["torch"]
+    eng, world, rank, dev = env["eng"], env["world"], env["rank"], env["dev"]
+    from qpn_amd import sharding, synthetic
+    from qpn_amd.engine import colmajor
+    n = m = 256
+    p = NPAR
+    N = n + m
+    total = args.nodes if args.nodes is not None else 512
+    lo_id, hi_id = sharding.node_range(total, world, rank)
+    cnt = hi_id - lo_id
+    Q, R, qd, A, B, l, u = synthetic.synth_nodes(lo_id, cnt, n, m, p)
+    w_host = synthetic.shared_params(p)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    drec = (t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u))
+    ring_host = np.repeat(w_host[None, :], RING, axis=0)
+    if not args.fixed_w:
+        ring_host = ring_host + 0.25 * np.random.Generator(np.random.Philox(key=[synthetic.SEED, 2 ** 41])).standard_normal((RING, p))
+    ring = t(ring_host)
+    handle = eng.upload_nodes(*drec)
+    steps = min(args.steps, 50)
+    warmup = min(args.warmup, 5)
+    out = None
+    x = torch.zeros((cnt, n), dtype=torch.float64, device=dev)
+    for i in range(warmup):
+        out = handle.solve(ring[i % RING], out=out, x_out=x)
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    piv_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    for i in range(steps):
+        out = handle.solve(ring[(warmup + i) % RING], out=out, x_out=x)
+        piv_sum += out["pivots"].sum()
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = ev0.elapsed_time(ev1) / steps
+    solved = int((out["status"] == 1).sum().item())
+    mean_piv = float(piv_sum.item()) / (steps * cnt)
+    flops = N ** 3 / 3.0 + 2.0 * N * N * mean_piv
+    achieved = flops * cnt / (ms * 1e-3) / 1e12
+    res = {
+        "metric": baseline_metric(), "value": solved * steps / dt, "unit": "solves/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "prewarm_steps": 0, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {total}-node x {n}-var QPNet (n=m={n}, N_red={N}, p={p}; BASELINE.json configs[4]); step = "
+                               "KKT assembly + cold-start AVI solve + check + active sets + primal write-back over resident node "
+                               f"records (qpn_solve_nodes_h -> blocked MFMA crash + delayed-update Lemke); ring of {RING} parameter vectors",
+                   "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p, "mean_pivots": mean_piv,
+                   "max_resid": float(out["resid"].max().item()), "solved": solved},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                     "traffic": None, "kernel": "schur_big_stage_a + schur_big_lemke + schur_big_finish (per step)", "kernel_ms": ms,
+                     "flops_per_solve": flops, "solves_per_launch": cnt},
+    }
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        k = min(cnt, 16)
+        res["cpu_baseline"] = cpu_baseline(np, Q[:k], R[:k], qd[:k], A[:k], B[:k], l[:k], u[:k], w_host, budget_s=5.0)
+    handle.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -150,6 +150,42 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
                          int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
                          const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x);
 
+/* ---- resident node records: upload once, sweep many times ----------------------------------------------
+ * The outer loop (src/algorithm.jl:13-117) sweeps the SAME nodes again and again: between two sweeps only the
+ * parameters w (the other players' decision variables) change, while Qd, R, qd, Ad, B, l, u -- 22 KB per
+ * n = m = 32 node -- stay what they were.  A caller with host arrays (the Julia shim) that went through
+ * qpn_solve_nodes every sweep would move those records over PCIe every time (2.3 M solves/s against 85 M/s
+ * from resident records).  qpn_nodes_upload copies the records into HBM owned by the
+ * library ONCE and returns a handle; qpn_solve_nodes_h / qpn_verify_nodes_h then take the handle, w and the
+ * output buffers, exactly as qpn_solve_nodes_into / qpn_verify_nodes would with the records in place.
+ *   mem (upload)    where Qd..u live (QPN_MEM_HOST / QPN_MEM_DEVICE); the handle holds its own copy either way,
+ *                   so the records cannot change under it
+ *   mem (solve)     where w, z0/z, status, resid, pivots, active, x live.  With QPN_MEM_HOST only w goes up and
+ *                   only the requested outputs come down; z may be NULL when only the primal blocks (x) or only
+ *                   the statuses are wanted.
+ * The handle also keeps what depends on the records alone: whether any of its nodes needs the general
+ * (pivoting) kernel -- decided by Qd, Ad, l, u, never by w -- so that sweeps over well-conditioned nodes are ONE
+ * launch, and the longest-first schedule of its nodes (refreshed from a sweep's own pivot counts every
+ * `period` sweeps when `pivots` is requested; qpn_nodes_set_schedule, period 0 = natural order).
+ * qpn_nodes_update replaces one array of the records (e.g. the bounds after a new child piece was chosen). */
+typedef struct qpn_nodes qpn_nodes;
+enum { QPN_NODE_QD = 0, QPN_NODE_R = 1, QPN_NODE_Q = 2, QPN_NODE_AD = 3, QPN_NODE_B = 4, QPN_NODE_L = 5, QPN_NODE_U = 6 };
+int qpn_nodes_upload(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                     const double *R, const double *qd, const double *Ad, const double *B, const double *l,
+                     const double *u, int mem, qpn_nodes **out);
+int qpn_nodes_update(qpn_ctx *ctx, qpn_nodes *nodes, int32_t field, const double *data, int mem);
+int qpn_nodes_set_schedule(qpn_ctx *ctx, qpn_nodes *nodes, int32_t period);
+int qpn_nodes_free(qpn_ctx *ctx, qpn_nodes *nodes);
+/* info[0] = what is known about the general kernel's share of these records: 0 nothing yet, 1 the count of the first
+ * sweep is on its way to the host, 2 no node needs it (sweeps are one launch), 3 some do; info[1] = that count (valid
+ * in states 2, 3); info[2] = 1 when a longest-first schedule is installed; info[3] = sweeps since the last schedule reset. */
+int qpn_nodes_info(qpn_ctx *ctx, qpn_nodes *nodes, int32_t info[4]);
+int qpn_solve_nodes_h(qpn_ctx *ctx, qpn_nodes *nodes, const double *w, int64_t stride_w, double *z,
+                      int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
+                      const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x);
+int qpn_verify_nodes_h(qpn_ctx *ctx, qpn_nodes *nodes, const double *xd, const double *w, int64_t stride_w,
+                       double tol, int32_t *solution, double *lambda, int32_t *path, int mem);
+
 /* ---- schedule hint for qpn_solve_nodes[_into]: longest solves first ---------------------------------
  * The outer loop (src/algorithm.jl:13-117) sweeps the SAME nodes again and again, and a node's pivot
  * count changes little between sweeps, while a launch ends with a tail in which the last, longest

@@ -17,7 +17,7 @@ Layout:
   sharding.py      node-range sharding + RCCL all-gather of the primal iterate
 """
 from ._lib import LibraryMissing, load_library  # noqa: F401
-from .engine import Engine, default_engine  # noqa: F401
+from .engine import Engine, Nodes, default_engine  # noqa: F401
 
 SUCCESS, RAY_TERM, MAX_ITERS, FAILURE = 1, 2, 3, 4
 ROW_STD, ROW_GAVI = 0, 1

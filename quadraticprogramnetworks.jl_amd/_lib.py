@@ -18,6 +18,8 @@ ABI_SYMBOLS = (
     "qpn_set_node_order", "qpn_verify_nodes",
     "qpn_shared_alloc", "qpn_shared_open", "qpn_shared_close", "qpn_shared_free", "qpn_set_primal_mirrors",
     "qpn_sweep_status", "qpn_ctx_set_auto_schedule",
+    "qpn_nodes_upload", "qpn_nodes_update", "qpn_nodes_set_schedule", "qpn_nodes_free", "qpn_nodes_info", "qpn_solve_nodes_h",
+    "qpn_verify_nodes_h",
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -95,10 +97,14 @@ def load_library():
     lib.qpn_set_primal_mirrors.argtypes = [vp, vp, C.c_size_t, C.c_int32, C.POINTER(vp)]
     lib.qpn_sweep_status.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(vp), C.c_uint64,
                                      C.c_int32]
-    for s in ABI_SYMBOLS:
-        f = getattr(lib, s)
-        if f.restype is C.c_int and s not in ("qpn_abi_version",):
-            pass
+    lib.qpn_nodes_upload.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int,
+                                     C.POINTER(vp)]
+    lib.qpn_nodes_update.argtypes = [vp, vp, C.c_int32, vp, C.c_int]
+    lib.qpn_nodes_set_schedule.argtypes = [vp, vp, C.c_int32]
+    lib.qpn_nodes_free.argtypes = [vp, vp]
+    lib.qpn_nodes_info.argtypes = [vp, vp, vp]
+    lib.qpn_solve_nodes_h.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(AviOpts), C.c_int, vp, C.c_int64]
+    lib.qpn_verify_nodes_h.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
     del dp, ip, bp
     _lib = lib
     return lib

@@ -92,7 +92,9 @@ __device__ __forceinline__ double rcp64(double x)
 #endif
 constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resident at once: 16 per CU, 256 CUs
 
-template <bool NODES, int STAGGER = 0>
+// FULL32 (node path only): the launch's nodes are n = m = 32 -- the hot shape gets its own instantiation, without the
+// ragged-shape code, predicates and padding selects (sizes are compile-time constants there)
+template <bool NODES, int STAGGER = 0, bool FULL32 = false>
 __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
     if constexpr (NODES) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                          : "scc", "vcc");
         }
     }
-    const int N = NODES ? a.nd.n + a.nd.m : a.N;
+    const int N = FULL32 ? 64 : (NODES ? a.nd.n + a.nd.m : a.N);
     const int l = threadIdx.x;
     int b = blockIdx.x;
     if constexpr (NODES) {
@@ -129,6 +131,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     // l & 15 recomputed on the spot (one v_and) where the pivot loop compares it: kept in a register for the whole
     // kernel it is what the allocator spills to scratch first
     auto lc_now = [&]() -> int { int t_ = l; asm volatile("" : "+v"(t_)); return t_ & 15; };
+    // this wavefront hands its item to the general kernel (status = -1); node path: counted for the owner of the records
+    // (the counter's address is read from the kernarg segment on the spot, not kept in registers)
+    auto decline = [&]() {
+        if (l == 0) {
+            a.status[b] = -1;
+            if constexpr (NODES) {
+                typedef const AviBatchArgs __attribute__((address_space(4))) *kargs_d;
+                int32_t *dc = ((kargs_d)__builtin_amdgcn_kernarg_segment_ptr())->decl_count;
+                if (dc) atomicAdd(dc, 1);
+            }
+        }
+    };
 
     // Stage A scratch (sU: pivot columns, [row][k]) and Stage B / read-back scratch never live at the
     // same time: one buffer.
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime() & 0xffffffffull;
 #endif
     // node records (fused path): M = [[Qd, -Ad'],[Ad, 0]], q = [qd + R w; B w], src/avi.jl:205-251 + :305-377
-    const int nn = a.nd.n, nm = a.nd.m, np_ = a.nd.p;
+    const int nn = FULL32 ? 32 : a.nd.n, nm = FULL32 ? 32 : a.nd.m, np_ = a.nd.p;
     const double *Q_ = NODES ? a.nd.Qd + (size_t)b * nn * nn : nullptr;
     const double *A_ = NODES ? a.nd.Ad + (size_t)b * nm * nn : nullptr;
     const double *R_ = NODES ? a.nd.R + (size_t)b * nn * np_ : nullptr;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         // a node record IS of that shape (n free rows, then m GAVI rows): nothing to read, so the block loads
         // below are the first memory round trip of the wave
         n = nn; m = nm;
-        if (!(n + m == N && n <= 32 && m <= 32 && n >= 1)) { if (l == 0) a.status[b] = -1; return; }
+        if (!(n + m == N && n <= 32 && m <= 32 && n >= 1)) { decline(); return; }
     } else {
         double lk, uk; int gk;
         row_bounds(lk, uk, gk);
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         const bool shape_ok = n + m == N && n <= 32 && m <= 32 && n >= 1 &&
                               mfree == ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) &&
                               mg == ((((m + n) >= 64) ? ~0ull : ((1ull << (m + n)) - 1ull)) & ~((1ull << n) - 1ull));
-        if (!shape_ok) { if (l == 0) a.status[b] = -1; return; }
+        if (!shape_ok) { decline(); return; }
     }
 
     // ---- load: the top half [H | C] straight into the MFMA tile layout ----------------------------------
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         wave_sync();                                                                                \
         M_LOADC(0, 2, FULL) M_LOADC(0, 3, FULL) M_LOADC(1, 2, FULL) M_LOADC(1, 3, FULL)             \
     }
-        if (nn == 32 && nm == 32) M_NODE_LOAD(true) else M_NODE_LOAD(false)
+        if constexpr (FULL32) M_NODE_LOAD(true) else { if (nn == 32 && nm == 32) M_NODE_LOAD(true) else M_NODE_LOAD(false) }
 #undef M_NODE_LOAD
 #undef M_LOADH
 #undef M_LOADC
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
 #undef M_STEP
 #undef M_COLTILE
 #undef M_GATHER
-    if (fail) { if (l == 0) a.status[b] = -1; return; }
+    if (fail) { decline(); return; }
 
     // ---- S = D - A W on the matrix cores, c = b - A h -----------------------------------------------------
     // W = TL(0..1, 2..3) (rows = x, an aligned group of 4 rows is a B operand), h = kx (lanes 0..31).
@@ -502,7 +516,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         else if (actb && it >= 0) { lo = a.l[vo + it]; hi = a.u[vo + it]; }
     }
     // equality GAVI rows need their multiplier crashed in: left to the general kernel
-    if (__ballot(actb && lo == hi)) { if (l == 0) a.status[b] = -1; return; }
+    if (__ballot(actb && lo == hi)) { decline(); return; }
     const double lo0 = lo, hi0 = hi;      // bounds of pair l (fixed); lo/hi follow the row's basic variable
     // class of pair l (0 bounded on at least one side, 2 free; equal bounds were sent to the general kernel
     // above) and its range, so that the per-pivot bookkeeping is integer / scalar work, not fp64 compares
@@ -698,10 +712,36 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         const d4 ub = *reinterpret_cast<const d4 *>(sucol + lq * 8 + 4);
         __builtin_amdgcn_sched_barrier(0);
         // ---- write-back of the single-lane bookkeeping updates
-        rowvar = writelane_i32(rowvar, rW, veW); lo = writelane_f64(lo, rW, eloW); hi = writelane_f64(hi, rW, ehiW);
-        colvar = writelane_i32(colvar, cW, vlW);
-        nbval = writelane_f64(nbval, c, nbW);
-        satv = writelane_i32(satv, kW, auW);
+        // (ONE asm block for the nine v_writelane_b32: M0 -- the lane select, gfx9 allows one SGPR per VALU instruction -- is
+        // saved and restored once instead of six times, and the four lane selects follow each other without the
+        // compiler's copies in between: ~20 instructions less on the pivot's dependent chain)
+        {
+            const int s_rW = uni(rW), s_cW = uni(cW), s_cc = uni(c), s_kW = uni(kW);
+            const int s_ve = uni(veW), s_vl = uni(vlW), s_au = uni(auW);
+            const int s_el = uni(__double2loint(eloW)), s_eh = uni(__double2hiint(eloW));
+            const int s_fl = uni(__double2loint(ehiW)), s_fh = uni(__double2hiint(ehiW));
+            const int s_nl = uni(__double2loint(nbW)), s_nh = uni(__double2hiint(nbW));
+            int lol = __double2loint(lo), loh = __double2hiint(lo), hil = __double2loint(hi), hih = __double2hiint(hi);
+            int nbl = __double2loint(nbval), nbh = __double2hiint(nbval);
+            int m0save;
+            asm("s_mov_b32 %[sv], m0\n\t"
+                "s_mov_b32 m0, %[lr]\n\ts_nop 3\n\t"
+                "v_writelane_b32 %[rowvar], %[ve], m0\n\t"
+                "v_writelane_b32 %[lol], %[el], m0\n\tv_writelane_b32 %[loh], %[eh], m0\n\t"
+                "v_writelane_b32 %[hil], %[fl], m0\n\tv_writelane_b32 %[hih], %[fh], m0\n\t"
+                "s_mov_b32 m0, %[lc]\n\ts_nop 0\n\t"
+                "v_writelane_b32 %[colvar], %[vl], m0\n\t"
+                "s_mov_b32 m0, %[cc]\n\ts_nop 0\n\t"
+                "v_writelane_b32 %[nbl], %[nl], m0\n\tv_writelane_b32 %[nbh], %[nh], m0\n\t"
+                "s_mov_b32 m0, %[lk]\n\ts_nop 0\n\t"
+                "v_writelane_b32 %[satv], %[au], m0\n\t"
+                "s_mov_b32 m0, %[sv]"
+                : [rowvar] "+v"(rowvar), [lol] "+v"(lol), [loh] "+v"(loh), [hil] "+v"(hil), [hih] "+v"(hih), [colvar] "+v"(colvar),
+                  [nbl] "+v"(nbl), [nbh] "+v"(nbh), [satv] "+v"(satv), [sv] "=&s"(m0save)
+                : [lr] "s"(s_rW), [lc] "s"(s_cW), [cc] "s"(s_cc), [lk] "s"(s_kW), [ve] "s"(s_ve), [vl] "s"(s_vl), [au] "s"(s_au),
+                  [el] "s"(s_el), [eh] "s"(s_eh), [fl] "s"(s_fl), [fh] "s"(s_fh), [nl] "s"(s_nl), [nh] "s"(s_nh));
+            lo = __hiloint2double(loh, lol); hi = __hiloint2double(hih, hil); nbval = __hiloint2double(nbh, nbl);
+        }
         if (stop) break;
         // ---- the exchange on the 32 x 32 dictionary (see the header of this stage)
         {
@@ -797,19 +837,16 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     double lk, uk; int gk;
     row_bounds_e(lk, uk, gk);
     double mq32[32];
-    if constexpr (NODES) {
-        if (nn == 32) {
-            const double *qc = Qe_ + (l < 32 ? l : 0);
-#pragma unroll
-            for (int j = 0; j < 32; ++j) mq32[j] = qc[(size_t)j * 32];
-        }
-    }
     // ---- read back: lambda_k, then x = -(W lambda + h) ---------------------------------------------------
+    // lane coordinates recomputed from the lane id here (two VALU instructions): kept alive across the pivot loops they
+    // are what the register allocator spills to scratch
+    int lE_ = l; asm volatile("" : "+v"(lE_));
+    const int lcE = lE_ & 15, lqE = lE_ >> 4;
     wave_sync();
     if (actb) sval[rowvar] = xb;
     if (l <= XC) sval[colvar] = nbval;
     wave_sync();
-    const double lam0 = sval[NBP + lc], lam1 = sval[NBP + 16 + lc];     // lambda of this lane's two columns
+    const double lam0 = sval[NBP + lcE], lam1 = sval[NBP + 16 + lcE];     // lambda of this lane's two columns
     {
         // (W lambda)_row = sum over the 16 lanes of a DPP row of this lane's two-column partial, for the 8
         // rows j = 4 Ib + g a lane holds.  Folded butterfly: at each of the first three stages a lane gives
@@ -819,7 +856,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         double p2 = TL(0, 2)[2] * lam0 + TL(0, 3)[2] * lam1, p3 = TL(0, 2)[3] * lam0 + TL(0, 3)[3] * lam1;
         double p4 = TL(1, 2)[0] * lam0 + TL(1, 3)[0] * lam1, p5 = TL(1, 2)[1] * lam0 + TL(1, 3)[1] * lam1;
         double p6 = TL(1, 2)[2] * lam0 + TL(1, 3)[2] * lam1, p7 = TL(1, 2)[3] * lam0 + TL(1, 3)[3] * lam1;
-        const bool b0 = (lc & 1) != 0, b1 = (lc & 2) != 0, b2 = (lc & 4) != 0;
+        // (the W tiles are dead from here on: their 32 registers take the 32 entries of Qd this lane needs for the
+        // post-check, requested now so that the round trip hides behind the reduction and its LDS hops)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NODES) {
+            if (nn == 32) {
+                const double *qc = Qe_ + (l < 32 ? l : 0);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) mq32[j] = qc[(size_t)j * 32];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool b0 = (lcE & 1) != 0, b1 = (lcE & 2) != 0, b2 = (lcE & 4) != 0;
         // stage 1 (partner lc ^ 1): keep rows with bit0 == b0
         const double q0 = (b0 ? p1 : p0) + dpp_f64<0xB1>(b0 ? p0 : p1), q1 = (b0 ? p3 : p2) + dpp_f64<0xB1>(b0 ? p2 : p3);
         const double q2 = (b0 ? p5 : p4) + dpp_f64<0xB1>(b0 ? p4 : p5), q3 = (b0 ? p7 : p6) + dpp_f64<0xB1>(b0 ? p6 : p7);
@@ -834,8 +882,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         double t0 = (b2 ? r1 : r0) + swz(b2 ? r0 : r1, std::integral_constant<int, 0x101F>{});   // keep rows with bit2 == b2
         t0 += swz(t0, std::integral_constant<int, 0x201F>{});
         // the lane now holds the full sum for row j = b0 + 2 b1 + 4 b2 of its own lc bits
-        const int jrow = lc & 7;
-        if (lc < 8) sz[16 * (jrow >> 2) + 4 * (jrow & 3) + lq] = t0;
+        const int jrow = lcE & 7;
+        if (lcE < 8) sz[16 * (jrow >> 2) + 4 * (jrow & 3) + lqE] = t0;
     }
     wave_sync();
     // item order: rows < n are x, rows n.. are lambda
@@ -860,11 +908,17 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         double rq = SQ(l), ra = rq;
         int j = 0;
         if (nn == 32) {
+            // eight columns at a time, with both accumulators pinned in between: left alone the compiler sinks the `ra` chain
+            // below the lambda loop (only the constraint lanes keep it) and carries its 32 LDS operands there through scratch
 #pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                const double zj = sz[jj];
-                rq = fma(mq32[jj], zj, rq);
-                ra = fma(sA[jj * SAS + aoff], zj, ra);
+            for (int jb = 0; jb < 32; jb += 8) {
+#pragma unroll
+                for (int jj = jb; jj < jb + 8; ++jj) {
+                    const double zj = sz[jj];
+                    rq = fma(mq32[jj], zj, rq);
+                    ra = fma(sA[jj * SAS + aoff], zj, ra);
+                }
+                asm volatile("" : "+v"(ra), "+v"(rq));
             }
             j = 32;
         }
@@ -985,9 +1039,15 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
     }
     static const bool no_stagger = [] { const char *e = getenv("QPN_NO_STAGGER"); return e && e[0] == '1'; }();   // A/B switch
     // a partial round has no burst to spread; other CU counts (partitioned modes) run without the stagger
-    if (!no_stagger && resident[dev] == kResidentMI355X && a.batch > kResidentMI355X)
-        hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+    const bool stag = !no_stagger && resident[dev] == kResidentMI355X && a.batch > kResidentMI355X;
+    const bool full = a.nd.n == 32 && a.nd.m == 32;
+    if (stag && full)
+        hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, true>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+    else if (stag)
+        hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, false>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+    else if (full)
+        hipLaunchKernelGGL((avi_solve_schur<true, 0, true>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
     else
-        hipLaunchKernelGGL((avi_solve_schur<true, 0>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+        hipLaunchKernelGGL((avi_solve_schur<true, 0, false>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
     return hipGetLastError();
 }

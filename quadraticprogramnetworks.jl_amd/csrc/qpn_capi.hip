@@ -147,13 +147,18 @@ int qpn_ctx_destroy(qpn_ctx *ctx)
 int qpn_ctx_set_stream(qpn_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return QPN_ERR_ARG;
-    ctx->stream = static_cast<hipStream_t>(hip_stream);   // NULL = HIP's legacy default stream
+    hipStream_t ns = static_cast<hipStream_t>(hip_stream);   // NULL = HIP's legacy default stream
+    // the workspace is shared by all entry points and carved from offset 0 by each: launches still running on the
+    // stream that is being left may be using it
+    if (ns != ctx->stream) { HIPCHK(ctx, hipSetDevice(ctx->device)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+    ctx->stream = ns;
     return QPN_OK;
 }
 
 int qpn_ctx_use_own_stream(qpn_ctx *ctx)
 {
     if (!ctx) return QPN_ERR_ARG;
+    if (ctx->stream != ctx->own_stream) { HIPCHK(ctx, hipSetDevice(ctx->device)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
     ctx->stream = ctx->own_stream;
     return QPN_OK;
 }
@@ -433,6 +438,229 @@ int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p
                                 pivots, active, opts, mem, nullptr, 0);
 }
 
+} // extern "C"
+
+// resident node records (qpn_nodes_upload): library-owned copies in HBM + what depends on them alone
+struct qpn_nodes {
+    int device = 0;
+    int32_t batch = 0, n = 0, m = 0, p = 0;
+    double *buf = nullptr;                      // one allocation, the seven arrays carved from it
+    double *f[7] = {};                          // QPN_NODE_QD .. QPN_NODE_U
+    size_t fbytes[7] = {};
+    // does any node of these records need the general kernel?  0 unknown, 1 a count is on its way to the host,
+    // 2 none (sweeps are ONE launch), 3 some
+    int decl_state = 0;
+    int32_t *decl_dev = nullptr;                // device counter the fused kernel adds to
+    int32_t *decl_host = nullptr;               // pinned host copy
+    hipEvent_t decl_ev = nullptr;
+    // longest-first schedule of these nodes
+    int32_t *order = nullptr;
+    int32_t *key = nullptr;                     // smoothed pivot counts the order is made from
+    bool order_valid = false;
+    int32_t period = 16, calls = 0;
+};
+
+namespace {
+
+struct NodeDev {                // device views of one qpn_solve_nodes call
+    const double *Q, *R, *q, *A, *B, *l, *u, *w;
+    double *z; int32_t *st; double *res; int32_t *pv; uint8_t *act;
+};
+
+void nodes_poll_declines(qpn_nodes *h)
+{
+    if (h && h->decl_state == 1 && hipEventQuery(h->decl_ev) == hipSuccess) h->decl_state = (*h->decl_host == 0) ? 2 : 3;
+}
+
+// The launches of one sweep over device-resident records and outputs.  `h` (may be null) owns the records:
+// its decline knowledge and its schedule are used and refreshed.  wM.. = assembled-block workspace for the
+// general path (null only when h knows that no node declines).
+int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_t m, int32_t p, const NodeDev &d,
+                       int64_t stride_w, const qpn_avi_opts &o, double *x_dev, int64_t stride_x, double *wM, double *wq,
+                       double *wl, double *wu, uint8_t *wk, double *wbig)
+{
+    hipStream_t s = ctx->stream;
+    const int N = n + m;
+    AviBatchArgs a{};
+    a.batch = batch; a.N = N; a.z = d.z; a.status = d.st; a.resid = d.res; a.pivots = d.pv; a.active = d.act;
+    a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
+    a.max_pivots = o.max_pivots; a.flags = o.flags;
+    a.nd = NodeSrc{n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w};
+#ifdef QPN_STAMPS
+    a.stamps = g_stamps;
+#endif
+    const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
+    if (x_dev && mfma_shape) { a.x = x_dev; a.stride_x = stride_x; }      // written by the solve kernels themselves
+    // replicas on peer GPUs: only when the whole written range lies inside the registered buffer
+    const size_t x_span = x_dev ? ((size_t)(batch - 1) * (size_t)stride_x + (size_t)n) * 8 : 0;
+    const bool mirrored = x_dev && ctx->mirror_count > 0 && (const char *)x_dev >= (const char *)ctx->mirror_own &&
+                          (const char *)x_dev + x_span <= (const char *)ctx->mirror_own + ctx->mirror_bytes;
+    const ptrdiff_t x_off = mirrored ? x_dev - ctx->mirror_own : 0;
+    if (mirrored && mfma_shape) {
+        a.n_mirror = ctx->mirror_count;
+        for (int k = 0; k < ctx->mirror_count; ++k) a.mirror[k] = ctx->mirror_peer[k] + x_off;
+    }
+    if (mfma_shape) {
+        // schedule hint (longest first): the handle's own, else the context's
+        if (h && h->order_valid) a.order = h->order;
+        else if (ctx->order_count == batch && (!h || ctx->order_user)) a.order = ctx->order;     // a caller-installed order also serves handles
+        bool need_general = true;
+        if (h) {
+            nodes_poll_declines(h);
+            need_general = h->decl_state != 2;
+            if (h->decl_state == 0) {
+                HIPCHK(ctx, hipMemsetAsync(h->decl_dev, 0, 4, s));
+                a.decl_count = h->decl_dev;
+            }
+        }
+        // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
+        // (one small scan-mode launch: its waves pick the flagged items, assemble their blocks into the
+        // workspace and solve them)
+        HIPCHK(ctx, qpn_launch_avi_solve_schur_nodes(a, s));
+        if (need_general) {
+            if (!wM) return fail_arg(ctx, "qpn_solve_nodes: internal error (no workspace for the general path)");
+            AviBatchArgs g = a;
+            g.decl_count = nullptr;
+            g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
+            g.only_if = d.st; g.only_if_value = -1; g.scan = 1; g.assemble_first = 1;
+            HIPCHK(ctx, qpn_launch_avi_solve_reg(g, s));
+        }
+        if (h && h->decl_state == 0) {
+            // which nodes decline depends on Qd, Ad, l, u alone (block pivots of H, equality rows), never on w: ask once
+            HIPCHK(ctx, hipMemcpyAsync(h->decl_host, h->decl_dev, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipEventRecord(h->decl_ev, s));
+            h->decl_state = 1;
+        }
+        if (h) {
+            // the handle's own longest-first schedule for the NEXT sweeps (launches that fill the GPU only)
+            if (h->period > 0 && d.pv && batch > 4096) {
+                if (h->calls % h->period == 0) {
+                    HIPCHK(ctx, qpn_launch_order_by_pivots(d.pv, batch, h->order, s, h->key));
+                    h->order_valid = true;
+                }
+                h->calls++;
+            }
+        } else if (ctx->auto_period > 0 && !ctx->order_user && d.pv && batch > 4096) {
+            // automatic longest-first schedule for the NEXT calls over this batch (launches that fill the GPU only)
+            if (ctx->auto_batch != batch) { ctx->auto_batch = batch; ctx->auto_calls = 0; }
+            if (ctx->auto_calls % ctx->auto_period == 0) {
+                int rc = order_reserve(ctx, batch);
+                if (rc != QPN_OK) return rc;
+                HIPCHK(ctx, qpn_launch_order_by_pivots(d.pv, batch, ctx->order, s));
+                ctx->order_count = batch;
+            }
+            ctx->auto_calls++;
+        }
+    } else {
+        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
+                                              wu, wk, s));
+        AviBatchArgs g = a;
+        g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
+        if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
+        else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
+    }
+    if (x_dev && !mfma_shape) {     // general sizes: strided device copy of the primal blocks (and to the replicas)
+        HIPCHK(ctx, hipMemcpy2DAsync(x_dev, (size_t)stride_x * 8, d.z, (size_t)N * 8, (size_t)n * 8, (size_t)batch,
+                                     hipMemcpyDeviceToDevice, s));
+        for (int k = 0; mirrored && k < ctx->mirror_count; ++k)
+            HIPCHK(ctx, hipMemcpy2DAsync(ctx->mirror_peer[k] + x_off, (size_t)stride_x * 8, d.z, (size_t)N * 8,
+                                         (size_t)n * 8, (size_t)batch, hipMemcpyDefault, s));
+    }
+    return QPN_OK;
+}
+
+// One sweep: stages host buffers (the records only when h == null), carves the workspace, launches, reads back.
+int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                    const double *R, const double *qd, const double *Ad, const double *B, const double *l, const double *u,
+                    const double *w, int64_t stride_w, double *z, int32_t *status, double *resid, int32_t *pivots,
+                    uint8_t *active, const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x)
+{
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_solve_nodes: bad mem kind");
+    const int N = n + m;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    qpn_avi_opts o;
+    if (opts) o = *opts; else qpn_avi_default_opts(&o);
+    hipStream_t s = ctx->stream;
+    const size_t bN = (size_t)batch * N;
+    const NodeSizes sz = node_sizes(batch, n, m, p, stride_w);
+    const bool host = mem == QPN_MEM_HOST;
+    const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
+    // the handle may already know that the general path has nothing to do: no workspace for it then
+    nodes_poll_declines(h);
+    const bool need_ws = !(h && mfma_shape && h->decl_state == 2);
+
+    NodeDev d{Qd, R, qd, Ad, B, l, u, w, z, status, resid, pivots, active};
+    double *wM = nullptr, *wq = nullptr, *wl = nullptr, *wu = nullptr, *wbig = nullptr; uint8_t *wk = nullptr;
+    double *hQ, *hR, *hq, *hA, *hB, *hl, *hu, *hw, *hz = nullptr, *hres, *hx = nullptr; int32_t *hst, *hpv; uint8_t *hact;
+    Carver cv(ctx);
+    if (need_ws) {
+        cv.add((void **)&wM, bN * N * 8); cv.add((void **)&wq, bN * 8); cv.add((void **)&wl, bN * 8);
+        cv.add((void **)&wu, bN * 8); cv.add((void **)&wk, bN);
+        if (N > 64) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, N));
+    }
+    const bool z_ws = !z;          // no z wanted (handle calls): the kernels still need somewhere to put it
+    if (host) {
+        if (!h) {
+            cv.add((void **)&hQ, sz.Q); cv.add((void **)&hR, sz.R + 8); cv.add((void **)&hq, sz.q);
+            cv.add((void **)&hA, sz.A + 8); cv.add((void **)&hB, sz.B + 8); cv.add((void **)&hl, sz.lu + 8);
+            cv.add((void **)&hu, sz.lu + 8);
+        }
+        cv.add((void **)&hw, sz.w + 8); cv.add((void **)&hz, bN * 8);
+        cv.add((void **)&hres, (size_t)batch * 8); cv.add((void **)&hst, (size_t)batch * 4);
+        cv.add((void **)&hpv, (size_t)batch * 4); cv.add((void **)&hact, bN);
+        if (x && mfma_shape) cv.add((void **)&hx, (size_t)batch * n * 8);
+    } else if (z_ws) cv.add((void **)&hz, bN * 8);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    if (host) {
+        if (!h) {
+            HIPCHK(ctx, hipMemcpyAsync(hQ, Qd, sz.Q, hipMemcpyHostToDevice, s));
+            if (sz.R) HIPCHK(ctx, hipMemcpyAsync(hR, R, sz.R, hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipMemcpyAsync(hq, qd, sz.q, hipMemcpyHostToDevice, s));
+            if (sz.A) HIPCHK(ctx, hipMemcpyAsync(hA, Ad, sz.A, hipMemcpyHostToDevice, s));
+            if (sz.B) HIPCHK(ctx, hipMemcpyAsync(hB, B, sz.B, hipMemcpyHostToDevice, s));
+            if (sz.lu) {
+                HIPCHK(ctx, hipMemcpyAsync(hl, l, sz.lu, hipMemcpyHostToDevice, s));
+                HIPCHK(ctx, hipMemcpyAsync(hu, u, sz.lu, hipMemcpyHostToDevice, s));
+            }
+            d.Q = hQ; d.R = hR; d.q = hq; d.A = hA; d.B = hB; d.l = hl; d.u = hu;
+        }
+        if (p > 0) HIPCHK(ctx, hipMemcpyAsync(hw, w, sz.w, hipMemcpyHostToDevice, s));
+        if (z && !(o.flags & QPN_AVI_FLAG_COLD_START)) HIPCHK(ctx, hipMemcpyAsync(hz, z, bN * 8, hipMemcpyHostToDevice, s));
+        else if (!z) o.flags |= QPN_AVI_FLAG_COLD_START;
+        d.w = hw; d.z = hz; d.res = hres; d.st = hst; d.pv = hpv; d.act = hact;
+    } else if (z_ws) { d.z = hz; o.flags |= QPN_AVI_FLAG_COLD_START; }
+
+    double *x_dev = host ? hx : x;
+    const int64_t sx_dev = host ? (int64_t)n : stride_x;
+    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig);
+    if (rc != QPN_OK) return rc;
+    if (host) {
+        if (z) HIPCHK(ctx, hipMemcpyAsync(z, d.z, bN * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(status, d.st, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+        if (resid) HIPCHK(ctx, hipMemcpyAsync(resid, d.res, (size_t)batch * 8, hipMemcpyDeviceToHost, s));
+        if (pivots) HIPCHK(ctx, hipMemcpyAsync(pivots, d.pv, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+        if (active) HIPCHK(ctx, hipMemcpyAsync(active, d.act, bN, hipMemcpyDeviceToHost, s));
+        if (x && hx)       // the primal blocks come down on their own (2.5 MB at 10 000 nodes; z is twice that)
+            HIPCHK(ctx, hipMemcpy2DAsync(x, (size_t)stride_x * 8, hx, (size_t)n * 8, (size_t)n * 8, (size_t)batch,
+                                         hipMemcpyDeviceToHost, s));
+        else if (x)
+            HIPCHK(ctx, hipMemcpy2DAsync(x, (size_t)stride_x * 8, d.z, (size_t)N * 8, (size_t)n * 8, (size_t)batch,
+                                         hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+    }
+    return QPN_OK;
+}
+
+int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_t n, int32_t m, int32_t p,
+                     const double *Qd, const double *R, const double *qd, const double *Ad, const double *B,
+                     const double *l, const double *u, const double *xd, const double *w, int64_t stride_w, double tol,
+                     int32_t *solution, double *lambda, int32_t *path, int mem);
+
+} // namespace
+
+extern "C" {
+
 int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
                          const double *R, const double *qd, const double *Ad, const double *B,
                          const double *l, const double *u, const double *w, int64_t stride_w, double *z,
@@ -446,118 +674,126 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
     if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || !w || (m > 0 && !B))) || !z || !status)
         return fail_arg(ctx, "qpn_solve_nodes: null pointer");
     if (stride_w != 0 && stride_w < p) return fail_arg(ctx, "qpn_solve_nodes: stride_w < p");
-    const int N = n + m;
-    if (N > qpn_avi_max_n()) { ctx->last_error = "qpn_solve_nodes: n+m > 1024 not supported by ABI v1"; return QPN_ERR_SIZE; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    qpn_avi_opts o;
-    if (opts) o = *opts; else qpn_avi_default_opts(&o);
-    hipStream_t s = ctx->stream;
-    const size_t bN = (size_t)batch * N;
-    const NodeSizes sz = node_sizes(batch, n, m, p, stride_w);
+    if (n + m > qpn_avi_max_n()) { ctx->last_error = "qpn_solve_nodes: n+m > 1024 not supported by ABI v1"; return QPN_ERR_SIZE; }
+    return solve_nodes_any(ctx, nullptr, batch, n, m, p, Qd, R, qd, Ad, B, l, u, w, stride_w, z, status, resid, pivots,
+                           active, opts, mem, x, stride_x);
+}
 
-    // device views of the inputs / outputs
-    const double *dQ = Qd, *dR = R, *dq = qd, *dA = Ad, *dB = B, *dl = l, *du = u, *dw = w;
-    double *dz = z, *dres = resid; int32_t *dst = status, *dpv = pivots; uint8_t *dact = active;
-    // workspace: assembled blocks for the fallback / general path (written only for gated items)
-    double *wM, *wq, *wl, *wu, *wbig = nullptr; uint8_t *wk;
-    double *hQ, *hR, *hq, *hA, *hB, *hl, *hu, *hw, *hz, *hres; int32_t *hst, *hpv; uint8_t *hact;
-    Carver cv(ctx);
-    cv.add((void **)&wM, bN * N * 8); cv.add((void **)&wq, bN * 8); cv.add((void **)&wl, bN * 8);
-    cv.add((void **)&wu, bN * 8); cv.add((void **)&wk, bN);
-    if (N > 64) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, N));
-    if (mem == QPN_MEM_HOST) {
-        cv.add((void **)&hQ, sz.Q); cv.add((void **)&hR, sz.R + 8); cv.add((void **)&hq, sz.q);
-        cv.add((void **)&hA, sz.A + 8); cv.add((void **)&hB, sz.B + 8); cv.add((void **)&hl, sz.lu + 8);
-        cv.add((void **)&hu, sz.lu + 8); cv.add((void **)&hw, sz.w + 8); cv.add((void **)&hz, bN * 8);
-        cv.add((void **)&hres, (size_t)batch * 8); cv.add((void **)&hst, (size_t)batch * 4);
-        cv.add((void **)&hpv, (size_t)batch * 4); cv.add((void **)&hact, bN);
-    } else if (mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_solve_nodes: bad mem kind");
-    int rc = cv.commit();
-    if (rc != QPN_OK) return rc;
-    if (mem == QPN_MEM_HOST) {
-        HIPCHK(ctx, hipMemcpyAsync(hQ, Qd, sz.Q, hipMemcpyHostToDevice, s));
-        if (sz.R) HIPCHK(ctx, hipMemcpyAsync(hR, R, sz.R, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(hq, qd, sz.q, hipMemcpyHostToDevice, s));
-        if (sz.A) HIPCHK(ctx, hipMemcpyAsync(hA, Ad, sz.A, hipMemcpyHostToDevice, s));
-        if (sz.B) HIPCHK(ctx, hipMemcpyAsync(hB, B, sz.B, hipMemcpyHostToDevice, s));
-        if (sz.lu) {
-            HIPCHK(ctx, hipMemcpyAsync(hl, l, sz.lu, hipMemcpyHostToDevice, s));
-            HIPCHK(ctx, hipMemcpyAsync(hu, u, sz.lu, hipMemcpyHostToDevice, s));
-        }
-        if (p > 0) HIPCHK(ctx, hipMemcpyAsync(hw, w, sz.w, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(hz, z, bN * 8, hipMemcpyHostToDevice, s));
-        dQ = hQ; dR = hR; dq = hq; dA = hA; dB = hB; dl = hl; du = hu; dw = hw;
-        dz = hz; dres = hres; dst = hst; dpv = hpv; dact = hact;
-    }
-
-    AviBatchArgs a{};
-    a.batch = batch; a.N = N; a.z = dz; a.status = dst; a.resid = dres; a.pivots = dpv; a.active = dact;
-    a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
-    a.max_pivots = o.max_pivots; a.flags = o.flags;
-    a.nd = NodeSrc{n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w};
-#ifdef QPN_STAMPS
-    a.stamps = g_stamps;
-#endif
-    const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
-    const bool x_dev = x && mem == QPN_MEM_DEVICE;
-    if (x_dev && mfma_shape) { a.x = x; a.stride_x = stride_x; }      // written by the solve kernels themselves
-    // replicas on peer GPUs: only when the whole written range lies inside the registered buffer
-    const size_t x_span = x ? ((size_t)(batch - 1) * (size_t)stride_x + (size_t)n) * 8 : 0;
-    const bool mirrored = x_dev && ctx->mirror_count > 0 && (const char *)x >= (const char *)ctx->mirror_own &&
-                          (const char *)x + x_span <= (const char *)ctx->mirror_own + ctx->mirror_bytes;
-    const ptrdiff_t x_off = mirrored ? x - ctx->mirror_own : 0;
-    if (mirrored && mfma_shape) {
-        a.n_mirror = ctx->mirror_count;
-        for (int k = 0; k < ctx->mirror_count; ++k) a.mirror[k] = ctx->mirror_peer[k] + x_off;
-    }
-    if (mfma_shape && ctx->order_count == batch) a.order = ctx->order;      // schedule hint (longest first)
-    if (mfma_shape) {
-        // fused kernel; items it declines (status = -1) are assembled and solved by the general kernel
-        // (one small scan-mode launch: its waves pick the flagged items, assemble their blocks into the
-        // workspace and solve them)
-        HIPCHK(ctx, qpn_launch_avi_solve_schur_nodes(a, s));
-        AviBatchArgs g = a;
-        g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
-        g.only_if = dst; g.only_if_value = -1; g.scan = 1; g.assemble_first = 1;
-        HIPCHK(ctx, qpn_launch_avi_solve_reg(g, s));
-        // automatic longest-first schedule for the NEXT calls over this batch (launches that fill the GPU only)
-        if (ctx->auto_period > 0 && !ctx->order_user && dpv && batch > 4096) {
-            if (ctx->auto_batch != batch) { ctx->auto_batch = batch; ctx->auto_calls = 0; }
-            if (ctx->auto_calls % ctx->auto_period == 0) {
-                rc = order_reserve(ctx, batch);
-                if (rc != QPN_OK) return rc;
-                HIPCHK(ctx, qpn_launch_order_by_pivots(dpv, batch, ctx->order, s));
-                ctx->order_count = batch;
-            }
-            ctx->auto_calls++;
-        }
-    } else {
-        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dw, stride_w, wM, wq, wl,
-                                              wu, wk, s));
-        AviBatchArgs g = a;
-        g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
-        if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
-        else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
-    }
-    if (x_dev && !mfma_shape) {     // general sizes: strided device copy of the primal blocks (and to the replicas)
-        HIPCHK(ctx, hipMemcpy2DAsync(x, (size_t)stride_x * 8, dz, (size_t)N * 8, (size_t)n * 8, (size_t)batch,
-                                     hipMemcpyDeviceToDevice, s));
-        for (int k = 0; mirrored && k < ctx->mirror_count; ++k)
-            HIPCHK(ctx, hipMemcpy2DAsync(ctx->mirror_peer[k] + x_off, (size_t)stride_x * 8, dz, (size_t)N * 8,
-                                         (size_t)n * 8, (size_t)batch, hipMemcpyDefault, s));
-    }
-    if (mem == QPN_MEM_HOST) {
-        HIPCHK(ctx, hipMemcpyAsync(z, dz, bN * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipMemcpyAsync(status, dst, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
-        if (resid) HIPCHK(ctx, hipMemcpyAsync(resid, dres, (size_t)batch * 8, hipMemcpyDeviceToHost, s));
-        if (pivots) HIPCHK(ctx, hipMemcpyAsync(pivots, dpv, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
-        if (active) HIPCHK(ctx, hipMemcpyAsync(active, dact, bN, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        if (x)
-            for (int32_t b = 0; b < batch; ++b)
-                for (int32_t i = 0; i < n; ++i) x[(size_t)b * (size_t)stride_x + i] = z[(size_t)b * N + i];
-    }
+// ---- resident node records ------------------------------------------------------------------------------------
+int qpn_nodes_free(qpn_ctx *ctx, qpn_nodes *h)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!h) return QPN_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (h->decl_ev) { (void)hipEventSynchronize(h->decl_ev); (void)hipEventDestroy(h->decl_ev); }
+    if (h->buf) (void)hipFree(h->buf);
+    if (h->decl_dev) (void)hipFree(h->decl_dev);
+    if (h->decl_host) (void)hipHostFree(h->decl_host);
+    if (h->order) (void)hipFree(h->order);
+    if (h->key) (void)hipFree(h->key);
+    delete h;
     return QPN_OK;
+}
+
+int qpn_nodes_upload(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                     const double *R, const double *qd, const double *Ad, const double *B, const double *l,
+                     const double *u, int mem, qpn_nodes **out)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!out) return fail_arg(ctx, "qpn_nodes_upload: null out");
+    *out = nullptr;
+    if (batch <= 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_nodes_upload: bad sizes");
+    if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || (m > 0 && !B))))
+        return fail_arg(ctx, "qpn_nodes_upload: null pointer");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_nodes_upload: bad mem kind");
+    if (n + m > qpn_avi_max_n()) { ctx->last_error = "qpn_nodes_upload: n+m > 1024 not supported by ABI v1"; return QPN_ERR_SIZE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    qpn_nodes *h = new (std::nothrow) qpn_nodes();
+    if (!h) return fail_arg(ctx, "qpn_nodes_upload: out of host memory");
+    h->device = ctx->device; h->batch = batch; h->n = n; h->m = m; h->p = p;
+    const NodeSizes sz = node_sizes(batch, n, m, p, 0);
+    const size_t fb[7] = {sz.Q, sz.R, sz.q, sz.A, sz.B, sz.lu, sz.lu};
+    const double *src[7] = {Qd, R, qd, Ad, B, l, u};
+    size_t total = 0, off[7];
+    for (int i = 0; i < 7; ++i) { off[i] = total; total += (fb[i] + 8 + 255) & ~(size_t)255; h->fbytes[i] = fb[i]; }
+    hipError_t e = hipMalloc((void **)&h->buf, total);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->decl_dev, 4);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->decl_host, 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->decl_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->order, (size_t)batch * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->key, (size_t)batch * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(h->key, 0, (size_t)batch * 4, ctx->stream);
+    const hipMemcpyKind kind = mem == QPN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    for (int i = 0; i < 7 && e == hipSuccess; ++i) {
+        h->f[i] = reinterpret_cast<double *>(reinterpret_cast<char *>(h->buf) + off[i]);
+        if (fb[i]) e = hipMemcpyAsync(h->f[i], src[i], fb[i], kind, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // the caller's arrays are free again on return
+    if (e != hipSuccess) { int rc = fail_hip(ctx, e, "qpn_nodes_upload"); qpn_nodes_free(ctx, h); return rc; }
+    *h->decl_host = 0;
+    *out = h;
+    return QPN_OK;
+}
+
+int qpn_nodes_update(qpn_ctx *ctx, qpn_nodes *h, int32_t field, const double *data, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!h || field < 0 || field > 6 || !data) return fail_arg(ctx, "qpn_nodes_update: bad argument");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_nodes_update: bad mem kind");
+    if (h->device != ctx->device) return fail_arg(ctx, "qpn_nodes_update: handle belongs to another device");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (h->fbytes[field])
+        HIPCHK(ctx, hipMemcpyAsync(h->f[field], data, h->fbytes[field],
+                                   mem == QPN_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    if (mem == QPN_MEM_HOST) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // what was known about the old records is void (an answer still in flight must not be read as the new one's)
+    if (h->decl_state == 1) HIPCHK(ctx, hipEventSynchronize(h->decl_ev));
+    h->decl_state = 0;
+    return QPN_OK;
+}
+
+int qpn_nodes_set_schedule(qpn_ctx *ctx, qpn_nodes *h, int32_t period)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!h || period < 0) return fail_arg(ctx, "qpn_nodes_set_schedule: bad argument");
+    h->period = period; h->calls = 0;
+    if (period == 0) h->order_valid = false;
+    return QPN_OK;
+}
+
+int qpn_nodes_info(qpn_ctx *ctx, qpn_nodes *h, int32_t info[4])
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!h || !info) return fail_arg(ctx, "qpn_nodes_info: null argument");
+    nodes_poll_declines(h);
+    info[0] = h->decl_state; info[1] = h->decl_state >= 2 ? *h->decl_host : 0;
+    info[2] = h->order_valid ? 1 : 0; info[3] = h->calls;
+    return QPN_OK;
+}
+
+int qpn_solve_nodes_h(qpn_ctx *ctx, qpn_nodes *h, const double *w, int64_t stride_w, double *z,
+                      int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
+                      const qpn_avi_opts *opts, int mem, double *x, int64_t stride_x)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!h) return fail_arg(ctx, "qpn_solve_nodes_h: null handle");
+    if (h->device != ctx->device) return fail_arg(ctx, "qpn_solve_nodes_h: handle belongs to another device");
+    if (x && stride_x < h->n) return fail_arg(ctx, "qpn_solve_nodes_h: stride_x < n");
+    if (!status || (h->p > 0 && !w)) return fail_arg(ctx, "qpn_solve_nodes_h: null pointer");
+    if (stride_w != 0 && stride_w < h->p) return fail_arg(ctx, "qpn_solve_nodes_h: stride_w < p");
+    return solve_nodes_any(ctx, h, h->batch, h->n, h->m, h->p, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], h->f[5], h->f[6],
+                           w, stride_w, z, status, resid, pivots, active, opts, mem, x, stride_x);
+}
+
+int qpn_verify_nodes_h(qpn_ctx *ctx, qpn_nodes *h, const double *xd, const double *w, int64_t stride_w,
+                       double tol, int32_t *solution, double *lambda, int32_t *path, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (!h) return fail_arg(ctx, "qpn_verify_nodes_h: null handle");
+    if (h->device != ctx->device) return fail_arg(ctx, "qpn_verify_nodes_h: handle belongs to another device");
+    return verify_nodes_any(ctx, true, h->batch, h->n, h->m, h->p, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], h->f[5],
+                            h->f[6], xd, w, stride_w, tol, solution, lambda, path, mem);
 }
 
 // ---- multi-GPU: shared iterate buffers and their replicas ------------------------------------------------
@@ -727,6 +963,18 @@ int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t 
                      const double *w, int64_t stride_w, double tol, int32_t *solution,
                      double *lambda, int32_t *path, int mem)
 {
+    return verify_nodes_any(ctx, mem == QPN_MEM_DEVICE, batch, n, m, p, Qd, R, qd, Ad, B, l, u, xd, w, stride_w, tol, solution,
+                            lambda, path, mem);
+}
+
+} // extern "C"
+
+namespace {
+int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_t n, int32_t m, int32_t p,
+                     const double *Qd, const double *R, const double *qd, const double *Ad, const double *B,
+                     const double *l, const double *u, const double *xd, const double *w, int64_t stride_w, double tol,
+                     int32_t *solution, double *lambda, int32_t *path, int mem)
+{
     if (!ctx) return QPN_ERR_ARG;
     if (batch < 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_verify_nodes: bad sizes");
     if (batch == 0) return QPN_OK;
@@ -752,12 +1000,18 @@ int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t 
                                             solution, lambda, path, sG, sq, slb, sub, sz, sres, sst, s));
         return QPN_OK;
     }
+    if (mem != QPN_MEM_HOST) return fail_arg(ctx, "qpn_verify_nodes: bad mem kind");
     const NodeSizes sz_ = node_sizes(batch, n, m, p, stride_w);
-    double *dQ, *dR, *dq, *dA, *dB, *dl, *du, *dw, *dx, *dlam; int32_t *dsol, *dpath;
+    const double *dQ = Qd, *dR = R, *dq = qd, *dA = Ad, *dB = B, *dl = l, *du = u;
+    double *sQ, *sR, *sqq, *sA, *sB, *sl, *su;
+    double *dw, *dx, *dlam; int32_t *dsol, *dpath;
     Carver cv(ctx);
-    cv.add((void **)&dQ, sz_.Q); cv.add((void **)&dR, sz_.R + 8); cv.add((void **)&dq, sz_.q);
-    cv.add((void **)&dA, sz_.A + 8); cv.add((void **)&dB, sz_.B + 8); cv.add((void **)&dl, sz_.lu + 8);
-    cv.add((void **)&du, sz_.lu + 8); cv.add((void **)&dw, sz_.w + 8); cv.add((void **)&dx, sz_.q);
+    if (!records_on_device) {
+        cv.add((void **)&sQ, sz_.Q); cv.add((void **)&sR, sz_.R + 8); cv.add((void **)&sqq, sz_.q);
+        cv.add((void **)&sA, sz_.A + 8); cv.add((void **)&sB, sz_.B + 8); cv.add((void **)&sl, sz_.lu + 8);
+        cv.add((void **)&su, sz_.lu + 8);
+    }
+    cv.add((void **)&dw, sz_.w + 8); cv.add((void **)&dx, sz_.q);
     cv.add((void **)&dlam, sz_.lu + 8); cv.add((void **)&dsol, (size_t)batch * 4);
     cv.add((void **)&dpath, (size_t)batch * 4);
     cv.add((void **)&sG, (size_t)batch * mm * mm * 8); cv.add((void **)&sq, (size_t)batch * mm * 8);
@@ -766,16 +1020,19 @@ int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t 
     cv.add((void **)&sst, (size_t)batch * 4);
     int rc = cv.commit();
     if (rc != QPN_OK) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(dQ, Qd, sz_.Q, hipMemcpyHostToDevice, s));
-    if (sz_.R) HIPCHK(ctx, hipMemcpyAsync(dR, R, sz_.R, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(dq, qd, sz_.q, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(dx, xd, sz_.q, hipMemcpyHostToDevice, s));
-    if (sz_.A) HIPCHK(ctx, hipMemcpyAsync(dA, Ad, sz_.A, hipMemcpyHostToDevice, s));
-    if (sz_.B) HIPCHK(ctx, hipMemcpyAsync(dB, B, sz_.B, hipMemcpyHostToDevice, s));
-    if (sz_.lu) {
-        HIPCHK(ctx, hipMemcpyAsync(dl, l, sz_.lu, hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipMemcpyAsync(du, u, sz_.lu, hipMemcpyHostToDevice, s));
+    if (!records_on_device) {
+        HIPCHK(ctx, hipMemcpyAsync(sQ, Qd, sz_.Q, hipMemcpyHostToDevice, s));
+        if (sz_.R) HIPCHK(ctx, hipMemcpyAsync(sR, R, sz_.R, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(sqq, qd, sz_.q, hipMemcpyHostToDevice, s));
+        if (sz_.A) HIPCHK(ctx, hipMemcpyAsync(sA, Ad, sz_.A, hipMemcpyHostToDevice, s));
+        if (sz_.B) HIPCHK(ctx, hipMemcpyAsync(sB, B, sz_.B, hipMemcpyHostToDevice, s));
+        if (sz_.lu) {
+            HIPCHK(ctx, hipMemcpyAsync(sl, l, sz_.lu, hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipMemcpyAsync(su, u, sz_.lu, hipMemcpyHostToDevice, s));
+        }
+        dQ = sQ; dR = sR; dq = sqq; dA = sA; dB = sB; dl = sl; du = su;
     }
+    HIPCHK(ctx, hipMemcpyAsync(dx, xd, sz_.q, hipMemcpyHostToDevice, s));
     if (p > 0) HIPCHK(ctx, hipMemcpyAsync(dw, w, sz_.w, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dx, dw, stride_w, tol,
                                         dsol, dlam, dpath, sG, sq, slb, sub, sz, sres, sst, s));
@@ -786,4 +1043,4 @@ int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t 
     return QPN_OK;
 }
 
-} // extern "C"
+} // namespace

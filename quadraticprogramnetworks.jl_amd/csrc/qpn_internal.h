@@ -56,6 +56,9 @@ struct AviBatchArgs {
     // are then laid out with stride vec_stride, the workspace with the launch-wide N)
     const int32_t *n_items;
     int64_t vec_stride;
+    // fused node kernel only: counts the items it declines (status = -1), for callers that own the records and
+    // want to know whether the general-kernel launch behind it has anything to do (qpn_nodes handles); may be null
+    int32_t *decl_count;
 };
 
 // Function attributes (dynamic LDS limits) are per device: a launcher sets them once per device it is used on.
@@ -97,7 +100,8 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream);  // register-tableau kernel
 
 // qpn_kkt.hip
-hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int32_t *order, hipStream_t stream);
+hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int32_t *order, hipStream_t stream,
+                                      int32_t *key = nullptr);     // key: smoothed counts, see the kernel
 // per-sweep status pair, optionally exchanged through the ranks' mailboxes (box[r] = rank r's mailbox as mapped here)
 #define QPN_MAX_RANKS (QPN_MAX_MIRRORS + 1)
 struct SweepBoxes { void *box[QPN_MAX_RANKS]; };

@@ -101,6 +101,33 @@ class Engine:
     def _host(self, a, dtype):
         return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
+    @staticmethod
+    def _require_dev64(*ts):
+        """Device arguments go to the kernels as raw addresses: they must be what the ABI says they are."""
+        for t in ts:
+            if t is None:
+                continue
+            if t.dtype != torch.float64 or not t.is_contiguous():
+                raise QpnError("device buffers must be contiguous float64 tensors")
+
+    @staticmethod
+    def _x_stride(x_out, dev, batch, n):
+        if x_out is None:
+            return 0
+        if dev:
+            if x_out.dtype != torch.float64 or x_out.dim() != 2 or x_out.shape[0] != batch or x_out.shape[1] < n \
+                    or x_out.stride(1) != 1:
+                raise ValueError("x_out must be a [batch, >= n] fp64 tensor with unit inner stride")
+            return x_out.stride(0)
+        if x_out.dtype != np.float64 or x_out.ndim != 2 or x_out.shape[0] != batch or x_out.shape[1] < n \
+                or x_out.strides[1] != 8:
+            raise ValueError("x_out must be a [batch, >= n] float64 array with unit inner stride")
+        return x_out.strides[0] // 8
+
+    def upload_nodes(self, Qc, Rc, qd, Ac, Bc, l, u) -> "Nodes":
+        """Make a level's node records resident (qpn_nodes_upload); see ``Nodes``."""
+        return Nodes(self, Qc, Rc, qd, Ac, Bc, l, u)
+
     def _alloc(self, dev, shape, dtype):
         if dev:
             tdt = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8}[dtype]
@@ -242,6 +269,8 @@ class Engine:
         self._bind_stream(dev)
         if not dev:
             Qc, Rc, qd, Ac, Bc, l, u, w = (self._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u, w))
+        else:
+            self._require_dev64(Qc, Rc, qd, Ac, Bc, l, u, w)
         batch, n = qd.shape
         m = l.shape[1]
         p = w.shape[-1]
@@ -267,18 +296,7 @@ class Engine:
             z.copy_(z0)
         else:
             z[...] = np.asarray(z0, dtype=np.float64)
-        sx = 0
-        if x_out is not None:
-            if dev:
-                if x_out.dtype != z.dtype or x_out.dim() != 2 or x_out.shape[0] != batch or x_out.shape[1] < n \
-                        or x_out.stride(1) != 1:
-                    raise ValueError("x_out must be a [batch, >= n] fp64 tensor with unit inner stride")
-                sx = x_out.stride(0)
-            else:
-                if x_out.dtype != np.float64 or x_out.ndim != 2 or x_out.shape[0] != batch or x_out.shape[1] < n \
-                        or x_out.strides[1] != 8:
-                    raise ValueError("x_out must be a [batch, >= n] float64 array with unit inner stride")
-                sx = x_out.strides[0] // 8
+        sx = self._x_stride(x_out, dev, batch, n)
         rc = self.lib.qpn_solve_nodes_into(self.ctx, batch, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac),
                                            _ptr(Bc), _ptr(l), _ptr(u), _ptr(w), sw, _ptr(z), _ptr(status),
                                            _ptr(resid), _ptr(pivots), _ptr(active), C.byref(o),
@@ -366,6 +384,8 @@ class Engine:
         if not dev:
             Qc, Rc, qd, Ac, Bc, l, u, xd, w = (self._host(a, np.float64)
                                                for a in (Qc, Rc, qd, Ac, Bc, l, u, xd, w))
+        else:
+            self._require_dev64(Qc, Rc, qd, Ac, Bc, l, u, xd, w)
         batch, n = qd.shape
         m = l.shape[1]
         p = w.shape[-1]
@@ -379,6 +399,108 @@ class Engine:
                                        MEM_DEVICE if dev else MEM_HOST)
         self._chk(rc, "qpn_verify_nodes")
         return sol, lam[:, :m], path
+
+
+class Nodes:
+    """Resident node records (``qpn_nodes_upload``): the records of a level's single-node pools live in HBM owned by the
+    library; a sweep hands over only the parameters ``w`` and the output buffers.  What the outer loop
+    (src/algorithm.jl:13-117) does between two sweeps -- new parameters, same nodes -- costs no record traffic, and the
+    handle remembers what depends on the records alone (whether any node needs the general kernel; the longest-first
+    schedule).  ``solve`` = Engine.solve_nodes, ``verify`` = Engine.verify_nodes with the records in place."""
+
+    FIELDS = dict(Qd=0, R=1, qd=2, Ad=3, B=4, l=5, u=6)
+
+    def __init__(self, eng: "Engine", Qc, Rc, qd, Ac, Bc, l, u):
+        self.eng = eng
+        dev = eng._mode(Qc, Rc, qd, Ac, Bc, l, u)
+        eng._bind_stream(dev)
+        if not dev:
+            Qc, Rc, qd, Ac, Bc, l, u = (eng._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u))
+        else:
+            eng._require_dev64(Qc, Rc, qd, Ac, Bc, l, u)
+        self.batch, self.n = qd.shape
+        self.m = l.shape[1]
+        self.p = Rc.shape[1]
+        h = C.c_void_p()
+        rc = eng.lib.qpn_nodes_upload(eng.ctx, self.batch, self.n, self.m, self.p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac),
+                                      _ptr(Bc), _ptr(l), _ptr(u), MEM_DEVICE if dev else MEM_HOST, C.byref(h))
+        eng._chk(rc, "qpn_nodes_upload")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.eng, "ctx", None):
+            self.eng.lib.qpn_nodes_free(self.eng.ctx, self.h)
+        self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, field: str, data):
+        """Replace one array of the records (same shape), e.g. the bounds after another child piece was chosen."""
+        dev = self.eng._mode(data)
+        self.eng._bind_stream(dev)
+        if not dev:
+            data = self.eng._host(data, np.float64)
+        else:
+            self.eng._require_dev64(data)
+        rc = self.eng.lib.qpn_nodes_update(self.eng.ctx, self.h, self.FIELDS[field], _ptr(data), MEM_DEVICE if dev else MEM_HOST)
+        self.eng._chk(rc, "qpn_nodes_update")
+
+    def info(self):
+        """dict(decline_state, declined, scheduled, sweeps) -- see qpn_nodes_info."""
+        a = (C.c_int32 * 4)()
+        self.eng._chk(self.eng.lib.qpn_nodes_info(self.eng.ctx, self.h, a), "qpn_nodes_info")
+        return dict(decline_state=a[0], declined=a[1], scheduled=bool(a[2]), sweeps=a[3])
+
+    def set_schedule(self, period=16):
+        self.eng._chk(self.eng.lib.qpn_nodes_set_schedule(self.eng.ctx, self.h, int(period)), "qpn_nodes_set_schedule")
+
+    def solve(self, w, opts=None, want=("z", "resid", "pivots", "active"), out=None, x_out=None):
+        """One sweep over the resident nodes with parameters w ((p,) shared or (batch, p)); cold duals.  `want` names the
+        optional outputs (status always comes back); x_out as in Engine.solve_nodes."""
+        eng = self.eng
+        dev = eng._mode(w, x_out)
+        eng._bind_stream(dev)
+        if not dev:
+            w = eng._host(w, np.float64)
+        elif w.dtype != torch.float64 or w.stride(-1) != 1:
+            raise QpnError("w must be a float64 tensor with unit inner stride")
+        N = self.n + self.m
+        sw = 0 if w.ndim == 1 else int(w.stride(0) if dev else w.strides[0] // 8)
+        o = opts if opts is not None else eng.default_opts()
+        o.flags |= _lib.AVI_FLAG_COLD_START
+        if out is None:
+            out = dict(status=eng._alloc(dev, (self.batch,), np.int32),
+                       z=eng._alloc(dev, (self.batch, N), np.float64) if "z" in want else None,
+                       resid=eng._alloc(dev, (self.batch,), np.float64) if "resid" in want else None,
+                       pivots=eng._alloc(dev, (self.batch,), np.int32) if "pivots" in want else None,
+                       active=eng._alloc(dev, (self.batch, N), np.uint8) if "active" in want else None)
+        sx = eng._x_stride(x_out, dev, self.batch, self.n)
+        rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, _ptr(w), sw, _ptr(out["z"]), _ptr(out["status"]), _ptr(out["resid"]),
+                                       _ptr(out["pivots"]), _ptr(out["active"]), C.byref(o),
+                                       MEM_DEVICE if dev else MEM_HOST, _ptr(x_out), sx)
+        eng._chk(rc, "qpn_solve_nodes_h")
+        return out
+
+    def verify(self, xd, w, tol=1e-4):
+        eng = self.eng
+        dev = eng._mode(xd, w)
+        eng._bind_stream(dev)
+        if not dev:
+            xd, w = eng._host(xd, np.float64), eng._host(w, np.float64)
+        else:
+            eng._require_dev64(xd, w)
+        sw = 0 if w.ndim == 1 else self.p
+        sol = eng._alloc(dev, (self.batch,), np.int32)
+        path = eng._alloc(dev, (self.batch,), np.int32)
+        lam = eng._alloc(dev, (self.batch, max(self.m, 1)), np.float64)
+        rc = eng.lib.qpn_verify_nodes_h(eng.ctx, self.h, _ptr(xd), _ptr(w), sw, float(tol), _ptr(sol), _ptr(lam), _ptr(path),
+                                        MEM_DEVICE if dev else MEM_HOST)
+        eng._chk(rc, "qpn_verify_nodes_h")
+        return sol, lam[:, :self.m], path
 
 
 _default = {}

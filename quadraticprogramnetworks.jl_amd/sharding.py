@@ -10,8 +10,9 @@ sweep's R_i w / B_i w terms.  Two routes:
   point-to-point and the blocks are 8n bytes, so the exchange rides inside the launch; the sweep ends
   with qpn_sweep_status, a 24-byte mailbox exchange that is both the stop/raise decision and the
   barrier.  No collective on the data path.
-* all_gather_primal + all_reduce_status: the same exchange as two collectives (RCCL on the GPU box,
-  gloo in the CPU tests); the fallback when buffers cannot be shared.
+* GatheredIterate (the default of bench.py for N > 1): ONE in-place all-gather per sweep of
+  [primal blocks | sweep status] -- the route north_star names (RCCL over xGMI; gloo in the CPU tests).
+* all_gather_primal + all_reduce_status: the same exchange as two collectives; ragged shards.
 
 What does NOT shard: a single Nash pool is ONE AVI (src/avi.jl:399-400) -- shard over instances
 instead.
@@ -63,6 +64,66 @@ def all_reduce_status(n_failed_local: int, max_resid_local: float, device, dist)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(s[0].item()), float(t[1].item())
+
+
+class GatheredIterate:
+    """The iterate x [total, n] on every rank, reassembled by ONE collective per sweep (the route BASELINE.json's north_star
+    names: an RCCL all-gather over xGMI; gloo in the CPU tests).
+
+    Each rank's contribution is its primal blocks followed by an 8-double tail that carries the sweep's stop/raise pair
+    (items not solved, max residual -- src/algorithm.jl:95-109 ends a sweep with solved = false when any solve of the level
+    failed), so the status needs no collective of its own: buffer [world, count * n + 8], rank r's row = [x of its nodes |
+    tail].  The all-gather is in place (every rank's send buffer is its own row of the receive buffer).
+    Equal shard sizes only (all_gather_into_tensor); ragged shards use all_gather_primal + all_reduce_status.
+
+    x_local          [count, n] view the solve writes (solve_nodes(x_out=...))
+    finish_sweep(status, resid)   fills the tail (qpn_sweep_status on the GPU, no host sync) and issues the all-gather
+    x_of(r)          rank r's [count, n] block after the sweep;  x_all() -> [total, n] copy
+    sweep_result()   (items not solved over all ranks, max residual) -- host sync
+    """
+    TAIL = 8
+
+    def __init__(self, eng, dist, total, n, device):
+        import torch
+        self.eng, self.dist = eng, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        ranges = [node_range(total, self.world, r) for r in range(self.world)]
+        sizes = {hi - lo for lo, hi in ranges}
+        if len(sizes) != 1:
+            raise ValueError("GatheredIterate needs equal shard sizes")
+        self.count, self.n, self.total = sizes.pop(), int(n), int(total)
+        self.row = self.count * self.n + self.TAIL
+        self.buf = torch.zeros((self.world, self.row), dtype=torch.float64, device=device)
+        self.x_local = self.buf[self.rank, : self.count * self.n].view(self.count, self.n)
+        self._tail = self.buf[self.rank, self.count * self.n: self.count * self.n + 4]
+
+    def finish_sweep(self, status, resid):
+        if self.buf.is_cuda:
+            self.eng.sweep_status(status, resid, self._tail)       # [not solved, max resid, 1, 0], one small launch
+        else:                                                      # CPU rehearsal (gloo tests): the same pair, torch ops
+            self._tail[0] = float((status != 1).sum())
+            self._tail[1] = float(resid.max()) if resid.numel() else 0.0
+            self._tail[2] = 1.0
+        if self.buf.is_cuda and self.dist.get_backend() == "gloo":
+            # rehearsal only (several ranks on one GPU, host channel gloo): stage through the host
+            got = [None] * self.world
+            self.dist.all_gather_object(got, self.buf[self.rank].cpu())
+            for r, b in enumerate(got):
+                if r != self.rank:
+                    self.buf[r].copy_(b.to(self.buf.device))
+        else:
+            self.dist.all_gather_into_tensor(self.buf.view(-1), self.buf[self.rank])
+        return self.buf
+
+    def x_of(self, r):
+        return self.buf[r, : self.count * self.n].view(self.count, self.n)
+
+    def x_all(self):
+        return self.buf[:, : self.count * self.n].reshape(self.total, self.n)
+
+    def sweep_result(self):
+        t = self.buf[:, self.count * self.n: self.count * self.n + 2]
+        return int(t[:, 0].sum().item()), float(t[:, 1].max().item())
 
 
 def _device_tensor(addr: int, shape, device):

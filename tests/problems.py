@@ -26,7 +26,11 @@ def reduced_blocks(Q, R, qd, A, B, l, u, w):
     M[:, :n, :n] = Q
     M[:, :n, n:] = -np.swapaxes(A, 1, 2)
     M[:, n:, :n] = A
-    q = np.concatenate([qd + R @ w, B @ w], axis=1)
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim == 1:
+        q = np.concatenate([qd + R @ w, B @ w], axis=1)
+    else:                                   # one parameter vector per node
+        q = np.concatenate([qd + np.einsum("bnp,bp->bn", R, w), np.einsum("bmp,bp->bm", B, w)], axis=1)
     lo = np.concatenate([np.full((count, n), -INF), l], axis=1)
     hi = np.concatenate([np.full((count, n), INF), u], axis=1)
     kind = np.concatenate([np.zeros((count, n), np.uint8), np.ones((count, m), np.uint8)], axis=1)

@@ -61,3 +61,65 @@ def test_two_rank_sweep_equals_single_process(tmp_path, total, ragged):
     assert np.array_equal(x1, x2)
     assert [sharding.node_range(13, 2, r) for r in range(2)] == [(0, 7), (7, 13)]
     assert [sharding.node_range(10000, 8, r)[1] - sharding.node_range(10000, 8, r)[0] for r in range(8)] == [1250] * 8
+
+
+def _worker_gathered(rank, world, port, total, n, m, sweeps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import qpn_amd  # noqa: F401
+    from qpn_amd import sharding, synthetic
+    from oracle_engine import OracleEngine
+    import problems as P
+    eng = OracleEngine()
+    lo, hi = sharding.node_range(total, world, rank)
+    Q, R, qd, A, B, l, u = synthetic.synth_nodes(lo, hi - lo, n, m)
+    it = sharding.GatheredIterate(eng, dist, total, n, "cpu")
+    w = synthetic.shared_params()
+    xs = []
+    for k in range(sweeps):
+        # the next sweep's parameters come from the WHOLE previous iterate (every rank must hold all of it)
+        wk = w + (0.1 * it.x_all().numpy()[:: max(total // 8, 1), 0][:8] if k else 0.0)
+        M, q, lo_, hi_, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, wk)
+        res = eng.solve_avi_batch(np.swapaxes(M, 1, 2), q, lo_, hi_, kind=kind)
+        it.x_local.copy_(torch.tensor(res["z"][:, :n]))
+        it.finish_sweep(torch.tensor(res["status"]), torch.tensor(res["resid"]))
+        nfail, maxres = it.sweep_result()
+        assert nfail == 0 and maxres <= 1e-8
+        xs.append(it.x_all().numpy().copy())
+    if rank == 1:
+        np.save(out, np.stack(xs))
+    dist.destroy_process_group()
+
+
+def test_one_all_gather_per_sweep_carries_iterate_and_status(tmp_path):
+    """GatheredIterate (the N > 1 default of bench.py): two ranks, three dependent sweeps, equal to one process."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import qpn_amd  # noqa: F401
+    from qpn_amd import synthetic
+    from oracle import binding as ob
+    import problems as P
+    total, n, m, sweeps = 16, 5, 6, 3
+    out = str(tmp_path / "xs.npy")
+    mp.spawn(_worker_gathered, args=(2, _free_port(), total, n, m, sweeps, out), nprocs=2, join=True)
+    xs = np.load(out)
+    Q, R, qd, A, B, l, u = synthetic.synth_nodes(0, total, n, m)
+    w = synthetic.shared_params()
+    x = None
+    for k in range(sweeps):
+        wk = w + (0.1 * x[:: total // 8, 0][:8] if k else 0.0)
+        M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, wk)
+        x = ob.solve_avi_batch(M, q, lo, hi, kind=kind)["z"][:, :n]
+        assert np.array_equal(xs[k], x)
+    with pytest.raises(ValueError):
+        class _D:                       # ragged shards are refused (they take all_gather_primal)
+            @staticmethod
+            def get_rank(): return 0
+            @staticmethod
+            def get_world_size(): return 3
+        from qpn_amd import sharding
+        sharding.GatheredIterate(None, _D, 10, 4, "cpu")
