@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqpn_hip.so")
+# QPN_HIP_LIB selects another build of the SAME library (A/B of kernel variants; the Julia shim honours it too)
+LIB_PATH = os.environ.get("QPN_HIP_LIB") or os.path.join(_HERE, "libqpn_hip.so")
 
 # every symbol include/qpn_hip.h declares
 ABI_SYMBOLS = (

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void assemble_nodes_wide_kernel(
 // Pivot counts are small integers; bins 0..1023 (larger counts share the last bin).  The order inside a
 // bin is whatever the atomics give -- any order is a valid schedule.
 // `key` (optional, [count] int32, zero at first): an exponentially smoothed pivot count per node in units of 1/16 pivot
-// (key <- key - key/4 + 4 p): between sweeps the parameters change and with them a node's pivot count, by about half of
+// (key <- key - key/8 + 2 p): between sweeps the parameters change and with them a node's pivot count, by about half of
 // the spread between nodes on the bench workload; ordering by the smoothed count is worth 2-3 % of the sweep there.
 __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pivots, int32_t count, int32_t *order, int32_t *key)
 {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
         p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
         if (key) {
             const int k0 = key[i];
-            const int k1 = k0 > 0 ? k0 - (k0 >> 2) + 4 * p : 16 * p;
+            const int k1 = k0 > 0 ? k0 - (k0 >> 3) + 2 * p : 16 * p;
             p = k1 >> 2;                                    // quarter pivots
             p = p > 1023 ? 1023 : p;
         }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
             int p = pivots[i];
             p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
             const int k0 = key[i];
-            key[i] = k0 > 0 ? k0 - (k0 >> 2) + 4 * p : 16 * p;
+            key[i] = k0 > 0 ? k0 - (k0 >> 3) + 2 * p : 16 * p;
         }
     }
 }

@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import qpn_amd
-from qpn_amd import synthetic
+from qpn_amd import synthetic, _lib
+if os.environ.get('QPN_LIB'):
+    _lib.LIB_PATH = os.environ['QPN_LIB']; _lib._lib = None
 from qpn_amd.engine import colmajor
 scale = float(os.environ.get("SCALE", "1.0"))
 cnt, n, m = 10000, 32, 32

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 set -euo pipefail
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/pc"; mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/pc${TAG:-}"; mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
 for sc in 1.0 3.0; do
   export SCALE=$sc
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d "$O/s$sc" -- python3 $R/tools/pivot_cost.py > "$O/s$sc.log" 2>&1
