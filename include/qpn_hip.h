@@ -126,6 +126,38 @@ int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_
                        int64_t stride_w, double *Mout, double *qout, double *lout, double *uout,
                        uint8_t *kind_out, int mem);
 
+/* ---- (A6) pool assembly: combine_gavis, src/avi.jl:305-377 (and convert, :113-128) -------------------------------
+ * One AVI per Nash pool (all nodes of a level jointly, src/avi.jl:399-400), `batch` instances of ONE pool shape
+ * (config 3: 1 000 payoff draws of the four-player game; a level of a net: batch = 1).  The shape (host arrays, read
+ * during the call only): `players` nodes in pool order (sorted ids, :319), player i with n_i decision variables and m_i
+ * constraint rows; the pool's decision variables are the union (nd positions = dec_inds, sorted), the other variables
+ * of the net are the p parameters; dpos (concatenated over the players, sum n_i entries) = position in dec_inds of each
+ * of a player's decision variables.
+ * Numeric inputs, the players' blocks stacked in pool order, column-major, sn = sum n_i, sm = sum m_i:
+ *   Qd [sn x nd] = Q_i[dvars_i, dec_inds]     Qp [sn x p] = Q_i[dvars_i, param_inds]     qd [sn] = q_i[dvars_i]
+ *   Ad [sm x nd] = M2_i[:, dec_inds]          Bp [sm x p] = M2_i[:, param_inds]          l, u [sm]
+ *   w [p] parameters.  Every input has an item stride in doubles; 0 shares it across the batch.
+ * Output: M [N x N] column-major (item stride strideM; 0 = ONE shared M, allowed when Qd and Ad are shared), q, l, u,
+ * kind [batch][N], ready for qpn_solve_avi_batch.
+ *   QPN_POOL_REFERENCE  z = [dec | xi_i per player | lambda-psi_i per player | slack], N = nd + sn + 2 sm: the AVI the
+ *                       reference hands to PATH, rows [sum_i xi^i_d = 0 (:356-367) | player KKT rows (:335-340) |
+ *                       [A -I] | [0 I 0] (:113-128)], all STD
+ *   QPN_POOL_REDUCED    z = [dec | lambda-psi], N = nd + sm, kinds [STD x nd | GAVI x sm]: without the xi block (it is
+ *                       multiplied by 0, :244) and the slack block; needs disjoint decision sets (sn = nd)
+ * qpn_pool_size returns N for a shape and form. */
+typedef struct {
+    int32_t players, nd, p;
+    const int32_t *n_i, *m_i; /* [players] */
+    const int32_t *dpos;      /* [sum n_i] */
+} qpn_pool_shape;
+enum { QPN_POOL_REDUCED = 0, QPN_POOL_REFERENCE = 1 };
+int qpn_pool_size(const qpn_pool_shape *shape, int form, int32_t *N);
+int qpn_assemble_pools(qpn_ctx *ctx, const qpn_pool_shape *shape, int form, int32_t batch, const double *Qd,
+                       int64_t stride_Qd, const double *Qp, int64_t stride_Qp, const double *qd, int64_t stride_qd,
+                       const double *Ad, int64_t stride_Ad, const double *Bp, int64_t stride_Bp, const double *l,
+                       const double *u, int64_t stride_lu, const double *w, int64_t stride_w, double *Mout,
+                       int64_t strideM, double *qout, double *lout, double *uout, uint8_t *kind_out, int mem);
+
 /* ---- (A5+A6+A2+A3+A9) fused: assemble each node's KKT blocks on the fly and solve ----------
  * Same inputs as qpn_assemble_nodes, same outputs as qpn_solve_avi_batch (N = n+m, z = [x_d; lambda]);
  * identical results to calling the two in sequence, without materialising M in HBM: one pass of the

@@ -20,7 +20,7 @@ ABI_SYMBOLS = (
     "qpn_shared_alloc", "qpn_shared_open", "qpn_shared_close", "qpn_shared_free", "qpn_set_primal_mirrors",
     "qpn_sweep_status", "qpn_ctx_set_auto_schedule",
     "qpn_nodes_upload", "qpn_nodes_update", "qpn_nodes_set_schedule", "qpn_nodes_free", "qpn_nodes_info", "qpn_solve_nodes_h",
-    "qpn_verify_nodes_h",
+    "qpn_verify_nodes_h", "qpn_pool_size", "qpn_assemble_pools",
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -33,6 +33,14 @@ SWEEP_BOX_BYTES = 512
 
 class LibraryMissing(RuntimeError):
     pass
+
+
+class PoolShape(C.Structure):
+    _fields_ = [("players", C.c_int32), ("nd", C.c_int32), ("p", C.c_int32), ("n_i", C.c_void_p), ("m_i", C.c_void_p),
+                ("dpos", C.c_void_p)]
+
+
+POOL_REDUCED, POOL_REFERENCE = 0, 1
 
 
 class AviOpts(C.Structure):
@@ -106,6 +114,10 @@ def load_library():
     lib.qpn_nodes_info.argtypes = [vp, vp, vp]
     lib.qpn_solve_nodes_h.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(AviOpts), C.c_int, vp, C.c_int64]
     lib.qpn_verify_nodes_h.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
+    lib.qpn_pool_size.argtypes = [C.POINTER(PoolShape), C.c_int, C.POINTER(C.c_int32)]
+    lib.qpn_assemble_pools.argtypes = [vp, C.POINTER(PoolShape), C.c_int, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
+                                       vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, vp,
+                                       vp, C.c_int]
     del dp, ip, bp
     _lib = lib
     return lib

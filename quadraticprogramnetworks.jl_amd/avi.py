@@ -203,6 +203,36 @@ def combine_gavis_reduced(n, dec_inds, param_inds, labeled_gavis) -> GAVI:
     return GAVI(H, Nn, o, np.full(nd, -INF), np.full(nd, INF), A, B, l2, u2)
 
 
+# ---- the same pool on the device: qpn_assemble_pools ----------------------------------------------
+def pool_blocks(n, dec_inds, param_inds, labeled_gavis):
+    """The numeric blocks of a pool as qpn_assemble_pools takes them (include/qpn_hip.h): the players' rows stacked in
+    pool order (sorted ids, src/avi.jl:319), split into decision / parameter columns, math layout.
+    Returns dict(n_i, m_i, dpos, nd, Qd [sn x nd], Qp [sn x p], qd, Ad [sm x nd], Bp [sm x p], l, u)."""
+    pool = sorted(labeled_gavis.keys())
+    pos = {d: k for k, d in enumerate(dec_inds)}
+    n_i = [len(labeled_gavis[i]["dvars"]) for i in pool]
+    m_i = [labeled_gavis[i]["M2"].shape[0] for i in pool]
+    dpos = [pos[d] for i in pool for d in labeled_gavis[i]["dvars"]]
+    Qd = np.vstack([labeled_gavis[i]["M1"][:, dec_inds] for i in pool])
+    Qp = np.vstack([labeled_gavis[i]["M1"][:, param_inds] for i in pool])
+    qd = np.concatenate([labeled_gavis[i]["q1"] for i in pool])
+    Ad = np.vstack([labeled_gavis[i]["M2"][:, dec_inds] for i in pool])
+    Bp = np.vstack([labeled_gavis[i]["M2"][:, param_inds] for i in pool])
+    l = np.concatenate([labeled_gavis[i]["l2"] for i in pool]); u = np.concatenate([labeled_gavis[i]["u2"] for i in pool])
+    return dict(n_i=n_i, m_i=m_i, dpos=dpos, nd=len(dec_inds), Qd=Qd, Qp=Qp, qd=qd, Ad=Ad, Bp=Bp, l=l, u=u)
+
+
+def assemble_pool_batch(blocks, w, engine=None, form="reduced", qd=None, l=None, u=None):
+    """One qpn_assemble_pools call: `blocks` from pool_blocks (shared across the batch); qd / l / u / w may carry a
+    leading batch dimension (instances of the pool that differ in their linear terms, bounds or parameters: config 3's
+    payoff draws).  Returns (Mc, q, lo, hi, kind) in the ABI layout for solve_avi_batch."""
+    b = blocks
+    return _eng(engine).assemble_pools(b["n_i"], b["m_i"], b["dpos"], b["nd"], colmajor(b["Qd"]), colmajor(b["Qp"]),
+                                       b["qd"] if qd is None else qd, colmajor(b["Ad"]), colmajor(b["Bp"]),
+                                       b["l"] if l is None else l, b["u"] if u is None else u, np.asarray(w, dtype=np.float64),
+                                       form=form)
+
+
 # ---- src/avi.jl:382-444 -------------------------------------------------------------------------
 def solve_qep(qp_net, player_pool, x, S: Optional[Dict[int, object]] = None, engine=None,
               reference_form=False):

@@ -428,6 +428,123 @@ int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_
     return QPN_OK;
 }
 
+// ---- (A6) pool assembly -------------------------------------------------------------------------------------
+int qpn_pool_size(const qpn_pool_shape *sh, int form, int32_t *N)
+{
+    if (!sh || !N || sh->players <= 0 || sh->nd <= 0 || sh->p < 0 || !sh->n_i || !sh->m_i) return QPN_ERR_ARG;
+    if (form != QPN_POOL_REDUCED && form != QPN_POOL_REFERENCE) return QPN_ERR_ARG;
+    int64_t sn = 0, sm = 0;
+    for (int i = 0; i < sh->players; ++i) {
+        if (sh->n_i[i] <= 0 || sh->m_i[i] < 0) return QPN_ERR_ARG;
+        sn += sh->n_i[i]; sm += sh->m_i[i];
+    }
+    const int64_t n = form == QPN_POOL_REFERENCE ? sh->nd + sn + 2 * sm : sh->nd + sm;
+    if (n > 1 << 20) return QPN_ERR_SIZE;
+    *N = (int32_t)n;
+    return QPN_OK;
+}
+
+int qpn_assemble_pools(qpn_ctx *ctx, const qpn_pool_shape *sh, int form, int32_t batch, const double *Qd,
+                       int64_t stride_Qd, const double *Qp, int64_t stride_Qp, const double *qd, int64_t stride_qd,
+                       const double *Ad, int64_t stride_Ad, const double *Bp, int64_t stride_Bp, const double *l,
+                       const double *u, int64_t stride_lu, const double *w, int64_t stride_w, double *Mout,
+                       int64_t strideM, double *qout, double *lout, double *uout, uint8_t *kind_out, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    int32_t N = 0;
+    int rc = qpn_pool_size(sh, form, &N);
+    if (rc != QPN_OK) return rc == QPN_ERR_ARG ? fail_arg(ctx, "qpn_assemble_pools: bad pool shape or form") : rc;
+    if (batch < 0) return fail_arg(ctx, "qpn_assemble_pools: batch < 0");
+    if (batch == 0) return QPN_OK;
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_assemble_pools: bad mem kind");
+    if (!sh->dpos) return fail_arg(ctx, "qpn_assemble_pools: null dpos");
+    const int nd = sh->nd, p = sh->p;
+    int sn = 0, sm = 0;
+    for (int i = 0; i < sh->players; ++i) { sn += sh->n_i[i]; sm += sh->m_i[i]; }
+    if (!Qd || !qd || (sm > 0 && (!Ad || !l || !u)) || (p > 0 && (!Qp || !w || (sm > 0 && !Bp))) || !Mout || !qout || !lout ||
+        !uout || !kind_out)
+        return fail_arg(ctx, "qpn_assemble_pools: null pointer");
+    // the index maps of the shape
+    std::vector<int32_t> maps((size_t)2 * sn + sm + nd, -1);
+    int32_t *xi_owner = maps.data(), *xi_dpos = xi_owner + sn, *con_owner = xi_dpos + sn, *dec_src = con_owner + sm;
+    {
+        int t = 0, k = 0;
+        for (int i = 0; i < sh->players; ++i) {
+            for (int e = 0; e < sh->n_i[i]; ++e, ++t) {
+                const int d = sh->dpos[t];
+                if (d < 0 || d >= nd) return fail_arg(ctx, "qpn_assemble_pools: dpos outside 0..nd-1");
+                xi_owner[t] = i; xi_dpos[t] = d;
+                if (form == QPN_POOL_REDUCED) {
+                    if (dec_src[d] >= 0) return fail_arg(ctx, "qpn_assemble_pools: reduced form needs disjoint decision sets");
+                    dec_src[d] = t;
+                }
+            }
+            for (int r = 0; r < sh->m_i[i]; ++r, ++k) con_owner[k] = i;
+        }
+        if (form == QPN_POOL_REDUCED)
+            for (int d = 0; d < nd; ++d)
+                if (dec_src[d] < 0) return fail_arg(ctx, "qpn_assemble_pools: a decision position belongs to no player");
+    }
+    const size_t szQd = (size_t)sn * nd, szQp = (size_t)sn * p, szAd = (size_t)sm * nd, szBp = (size_t)sm * p;
+    auto bad_stride = [&](int64_t st, size_t need) { return st != 0 && (st < 0 || (size_t)st < need); };
+    if (bad_stride(stride_Qd, szQd) || bad_stride(stride_Qp, szQp) || bad_stride(stride_qd, (size_t)sn) || bad_stride(stride_Ad, szAd) ||
+        bad_stride(stride_Bp, szBp) || bad_stride(stride_lu, (size_t)sm) || bad_stride(stride_w, (size_t)p) ||
+        bad_stride(strideM, (size_t)N * N))
+        return fail_arg(ctx, "qpn_assemble_pools: item stride smaller than the item");
+    if (strideM == 0 && batch > 1 && (stride_Qd != 0 || stride_Ad != 0))
+        return fail_arg(ctx, "qpn_assemble_pools: a shared M needs shared Qd and Ad");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    auto span = [&](int64_t st, size_t item) { return (st ? (size_t)(batch - 1) * (size_t)st + item : item) * 8; };
+    const size_t bQd = span(stride_Qd, szQd), bQp = span(stride_Qp, szQp), bqd = span(stride_qd, sn), bAd = span(stride_Ad, szAd),
+                 bBp = span(stride_Bp, szBp), blu = span(stride_lu, sm), bw = span(stride_w, p);
+    const size_t bM = span(strideM, (size_t)N * N), bN = (size_t)batch * N;
+    int32_t *dmaps;
+    double *dQd = nullptr, *dQp = nullptr, *dqd = nullptr, *dAd = nullptr, *dBp = nullptr, *dl = nullptr, *du = nullptr, *dw = nullptr;
+    double *dM = nullptr, *dq = nullptr, *dlo = nullptr, *dhi = nullptr; uint8_t *dk = nullptr;
+    Carver cv(ctx);
+    cv.add((void **)&dmaps, maps.size() * 4);
+    if (mem == QPN_MEM_HOST) {
+        cv.add((void **)&dQd, bQd + 8); cv.add((void **)&dQp, bQp + 8); cv.add((void **)&dqd, bqd + 8); cv.add((void **)&dAd, bAd + 8);
+        cv.add((void **)&dBp, bBp + 8); cv.add((void **)&dl, blu + 8); cv.add((void **)&du, blu + 8); cv.add((void **)&dw, bw + 8);
+        cv.add((void **)&dM, bM); cv.add((void **)&dq, bN * 8); cv.add((void **)&dlo, bN * 8); cv.add((void **)&dhi, bN * 8);
+        cv.add((void **)&dk, bN);
+    }
+    rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(dmaps, maps.data(), maps.size() * 4, hipMemcpyHostToDevice, s));
+    QpnPoolLaunch L{};
+    L.batch = batch; L.form = form; L.nd = nd; L.sn = sn; L.sm = sm; L.p = p;
+    L.xi_owner = dmaps; L.xi_dpos = dmaps + sn; L.con_owner = dmaps + 2 * sn; L.dec_src = dmaps + 2 * sn + sm;
+    L.s_Qd = stride_Qd; L.s_Qp = stride_Qp; L.s_qd = stride_qd; L.s_Ad = stride_Ad; L.s_Bp = stride_Bp; L.s_lu = stride_lu;
+    L.s_w = stride_w; L.s_M = strideM;
+    if (mem == QPN_MEM_HOST) {
+        HIPCHK(ctx, hipMemcpyAsync(dQd, Qd, bQd, hipMemcpyHostToDevice, s));
+        if (szQp) HIPCHK(ctx, hipMemcpyAsync(dQp, Qp, bQp, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipMemcpyAsync(dqd, qd, bqd, hipMemcpyHostToDevice, s));
+        if (szAd) HIPCHK(ctx, hipMemcpyAsync(dAd, Ad, bAd, hipMemcpyHostToDevice, s));
+        if (szBp) HIPCHK(ctx, hipMemcpyAsync(dBp, Bp, bBp, hipMemcpyHostToDevice, s));
+        if (sm) { HIPCHK(ctx, hipMemcpyAsync(dl, l, blu, hipMemcpyHostToDevice, s)); HIPCHK(ctx, hipMemcpyAsync(du, u, blu, hipMemcpyHostToDevice, s)); }
+        if (p) HIPCHK(ctx, hipMemcpyAsync(dw, w, bw, hipMemcpyHostToDevice, s));
+        L.Qd = dQd; L.Qp = dQp; L.qd = dqd; L.Ad = dAd; L.Bp = dBp; L.l = dl; L.u = du; L.w = dw;
+        L.M = dM; L.q = dq; L.lo = dlo; L.hi = dhi; L.kind = dk;
+    } else {
+        // (the maps were copied from a host vector that dies with this call: the copy must have left it)
+        L.Qd = Qd; L.Qp = Qp; L.qd = qd; L.Ad = Ad; L.Bp = Bp; L.l = l; L.u = u; L.w = w;
+        L.M = Mout; L.q = qout; L.lo = lout; L.hi = uout; L.kind = kind_out;
+    }
+    HIPCHK(ctx, qpn_launch_assemble_pools(L, s));
+    if (mem == QPN_MEM_HOST) {
+        HIPCHK(ctx, hipMemcpyAsync(Mout, dM, bM, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(qout, dq, bN * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(lout, dlo, bN * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(uout, dhi, bN * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(kind_out, dk, bN, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));      // host mode: results; device mode: the pageable maps copy must be done
+    return QPN_OK;
+}
+
 int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
                     const double *R, const double *qd, const double *Ad, const double *B,
                     const double *l, const double *u, const double *w, int64_t stride_w, double *z,

@@ -108,6 +108,16 @@ struct SweepBoxes { void *box[QPN_MAX_RANKS]; };
 hipError_t qpn_launch_sweep_status(const int32_t *status, const double *resid, int32_t count, double *out,
                                    int32_t rank, int32_t world, const SweepBoxes &boxes, unsigned long long epoch,
                                    unsigned long long timeout_ticks, hipStream_t stream);
+// pool assembly (combine_gavis): all pointers device
+struct QpnPoolLaunch {
+    int32_t batch, form, nd, sn, sm, p;
+    const int32_t *xi_owner, *xi_dpos, *con_owner, *dec_src;
+    const double *Qd, *Qp, *qd, *Ad, *Bp, *l, *u, *w;
+    int64_t s_Qd, s_Qp, s_qd, s_Ad, s_Bp, s_lu, s_w;
+    double *M, *q, *lo, *hi; uint8_t *kind;
+    int64_t s_M;
+};
+hipError_t qpn_launch_assemble_pools(const QpnPoolLaunch &L, hipStream_t stream);
 hipError_t qpn_launch_check_avi(int32_t batch, int32_t N, const double *M, int64_t strideM,
                                 const double *q, const double *l, const double *u,
                                 const uint8_t *kind, int64_t stride_kind, const double *z,

@@ -153,6 +153,99 @@ __global__ __launch_bounds__(256) void assemble_nodes_wide_kernel(
 // ---- schedule hint: permutation of 0..count-1 by descending pivot count (counting sort, ONE workgroup) ----
 // Pivot counts are small integers; bins 0..1023 (larger counts share the last bin).  The order inside a
 // bin is whatever the atomics give -- any order is a valid schedule.
+// ---- (A6) pool assembly: combine_gavis, src/avi.jl:305-377 (+ convert, :113-128, for the reference form) ----------
+// One workgroup per (pool instance, strip of 32 columns of the output).  A pool is `players` nodes of one level; its
+// decision variables are the union of theirs (nd positions), everything else is a parameter (p columns).  Inputs are
+// the players' rows stacked in pool order (sorted ids, :319): Qd [sn x nd] = Q_i[dvars_i, dec_inds], Qp [sn x p] =
+// Q_i[dvars_i, param_inds], qd [sn]; Ad [sm x nd] = M2_i[:, dec_inds], Bp [sm x p], l, u [sm]  (sn = sum n_i, sm = sum m_i),
+// all column-major.  xi_owner / xi_dpos [sn]: player and decision position of stacked row t; con_owner [sm].
+//   REFERENCE form (what the reference hands to PATH): z = [dec (nd) | xi (sn) | lambda-psi (sm) | slack (sm)],
+//     rows [ sum_i xi^i_d = 0 (:356-367) | player rows [Q_i  0  -A_i[:, dvars_i]'] (:335-339) | [A -I] | [0 I 0] (:113-128) ],
+//     all STD, bounds [free | free | l..u on the slack block].
+//   REDUCED form (disjoint decision sets, sn = nd): the structurally dead xi block (multiplied by 0 at :244), its rows
+//     and the slack block are dropped: z = [dec | lambda-psi], rows [player rows at their decision positions | A],
+//     kinds [STD x nd | GAVI x sm]  -- the form of the solve kernels.
+// Item strides of 0 share an input across the batch; Mout stride 0 writes one shared M (config 3: 1 000 payoff draws
+// of one game differ only in q).
+struct PoolArgs {
+    int32_t batch, form, nd, sn, sm, p;
+    const int32_t *xi_owner, *xi_dpos, *con_owner, *dec_src;       // dec_src [nd]: stacked row of decision position r (reduced form)
+    const double *Qd, *Qp, *qd, *Ad, *Bp, *l, *u, *w;
+    int64_t s_Qd, s_Qp, s_qd, s_Ad, s_Bp, s_lu, s_w;
+    double *M, *q, *lo, *hi; uint8_t *kind;
+    int64_t s_M;
+};
+
+__global__ __launch_bounds__(256) void assemble_pools_kernel(PoolArgs a)
+{
+    const int b = blockIdx.x, strip = blockIdx.y, tid = threadIdx.x;
+    const int nd = a.nd, sn = a.sn, sm = a.sm, p = a.p;
+    const bool ref = a.form == QPN_POOL_REFERENCE;
+    const int d1 = ref ? nd + sn : nd;
+    const int N = ref ? d1 + 2 * sm : nd + sm;
+    const double *Qd = a.Qd + (size_t)b * (size_t)a.s_Qd, *Ad = a.Ad + (size_t)b * (size_t)a.s_Ad;
+    const bool writeM = a.s_M != 0 || b == 0;
+    double *Mo = a.M + (size_t)b * (size_t)a.s_M;
+    if (writeM) {
+        const int j0 = 32 * strip, j1 = j0 + 32 < N ? j0 + 32 : N;
+        for (int j = j0; j < j1; ++j) {
+            for (int i = tid; i < N; i += 256) {
+                double v = 0.0;
+                if (ref) {
+                    // column blocks: [dec | xi | lam | slack], row blocks: [top nd | player sn | A-rows sm | I-rows sm]
+                    if (i < nd) {                                   // sum_i xi^i_d = 0
+                        if (j >= nd && j < nd + sn) v = (a.xi_dpos[j - nd] == i) ? 1.0 : 0.0;
+                    } else if (i < d1) {
+                        const int t = i - nd;
+                        if (j < nd) v = Qd[(size_t)j * sn + t];
+                        else if (j >= d1 && j < d1 + sm) {
+                            const int k = j - d1;
+                            if (a.con_owner[k] == a.xi_owner[t]) v = -Ad[(size_t)a.xi_dpos[t] * sm + k];
+                        }
+                    } else if (i < d1 + sm) {
+                        const int k = i - d1;
+                        if (j < nd) v = Ad[(size_t)j * sm + k];
+                        else if (j == d1 + sm + k) v = -1.0;
+                    } else {
+                        const int k = i - d1 - sm;
+                        if (j == d1 + k) v = 1.0;
+                    }
+                } else {
+                    if (i < nd) {
+                        const int t = a.dec_src[i];
+                        if (j < nd) v = Qd[(size_t)j * sn + t];
+                        else { const int k = j - nd; if (a.con_owner[k] == a.xi_owner[t]) v = -Ad[(size_t)i * sm + k]; }
+                    } else if (j < nd) v = Ad[(size_t)j * sm + (i - nd)];
+                }
+                Mo[(size_t)j * N + i] = v;
+            }
+        }
+    }
+    if (strip == 0) {
+        const double *Qp = a.Qp + (size_t)b * (size_t)a.s_Qp, *Bp = a.Bp + (size_t)b * (size_t)a.s_Bp;
+        const double *qd = a.qd + (size_t)b * (size_t)a.s_qd;
+        const double *lc = a.l + (size_t)b * (size_t)a.s_lu, *uc = a.u + (size_t)b * (size_t)a.s_lu;
+        const double *w = a.w + (size_t)b * (size_t)a.s_w;
+        const size_t vo = (size_t)b * (size_t)N;
+        for (int i = tid; i < N; i += 256) {
+            double q = 0.0, lo = -QINF, hi = QINF;
+            uint8_t kd = QPN_ROW_STD;
+            int t = -1, k = -1;                                       // stacked player row / constraint row behind item row i
+            if (ref) {
+                if (i >= nd && i < d1) t = i - nd;
+                else if (i >= d1 && i < d1 + sm) k = i - d1;
+                else if (i >= d1 + sm) { lo = lc[i - d1 - sm]; hi = uc[i - d1 - sm]; }
+            } else {
+                if (i < nd) t = a.dec_src[i];
+                else { k = i - nd; lo = lc[k]; hi = uc[k]; kd = QPN_ROW_GAVI; }
+            }
+            if (t >= 0) { q = qd[t]; for (int c = 0; c < p; ++c) q = fma(Qp[(size_t)c * sn + t], w[c], q); }
+            if (k >= 0) { for (int c = 0; c < p; ++c) q = fma(Bp[(size_t)c * sm + k], w[c], q); }
+            a.q[vo + i] = q; a.lo[vo + i] = lo; a.hi[vo + i] = hi; a.kind[vo + i] = kd;
+        }
+    }
+}
+
 // `key` (optional, [count] int32, zero at first): an exponentially smoothed pivot count per node in units of 1/16 pivot
 // (key <- key - key/8 + 2 p): between sweeps the parameters change and with them a node's pivot count, by about half of
 // the spread between nodes on the bench workload; ordering by the smoothed count is worth 2-3 % of the sweep there.
@@ -294,6 +387,20 @@ hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int3
 {
     if (count <= 0) return hipSuccess;
     hipLaunchKernelGGL(order_by_pivots_kernel, dim3(1), dim3(1024), 0, stream, pivots, count, order, key);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_assemble_pools(const QpnPoolLaunch &L, hipStream_t stream)
+{
+    if (L.batch <= 0) return hipSuccess;
+    PoolArgs a{};
+    a.batch = L.batch; a.form = L.form; a.nd = L.nd; a.sn = L.sn; a.sm = L.sm; a.p = L.p;
+    a.xi_owner = L.xi_owner; a.xi_dpos = L.xi_dpos; a.con_owner = L.con_owner; a.dec_src = L.dec_src;
+    a.Qd = L.Qd; a.Qp = L.Qp; a.qd = L.qd; a.Ad = L.Ad; a.Bp = L.Bp; a.l = L.l; a.u = L.u; a.w = L.w;
+    a.s_Qd = L.s_Qd; a.s_Qp = L.s_Qp; a.s_qd = L.s_qd; a.s_Ad = L.s_Ad; a.s_Bp = L.s_Bp; a.s_lu = L.s_lu; a.s_w = L.s_w;
+    a.M = L.M; a.q = L.q; a.lo = L.lo; a.hi = L.hi; a.kind = L.kind; a.s_M = L.s_M;
+    const int N = L.form == QPN_POOL_REFERENCE ? L.nd + L.sn + 2 * L.sm : L.nd + L.sm;
+    hipLaunchKernelGGL(assemble_pools_kernel, dim3((unsigned)L.batch, (unsigned)((N + 31) / 32)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

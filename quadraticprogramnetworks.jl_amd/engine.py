@@ -257,6 +257,66 @@ class Engine:
         self._chk(rc, "qpn_assemble_nodes")
         return Mout, qout, lout, uout, kind
 
+    # -- (A6) pool assembly ----------------------------------------------------------------------
+    def assemble_pools(self, n_i, m_i, dpos, nd, Qd, Qp, qd, Ad, Bp, l, u, w, form="reduced", share_M=None):
+        """combine_gavis (src/avi.jl:305-377) for `batch` instances of one pool shape, on the device.
+
+        Shape: n_i, m_i (per player, pool order), dpos (decision position of every stacked player row), nd.
+        Blocks in the ABI layout (column-major), each either shared ((cols, rows)) or per item ((batch, cols, rows)):
+        Qd (nd, sn), Qp (p, sn), qd (sn,), Ad (nd, sm), Bp (p, sm), l, u (sm,), w (p,).  form: "reduced" | "reference".
+        share_M (default: automatically when Qd and Ad are shared): write ONE M for the whole batch.
+        Returns (Mc, q, lo, hi, kind) ready for solve_avi_batch (Mc (N, N) when shared)."""
+        from ._lib import POOL_REDUCED, POOL_REFERENCE, PoolShape
+        dev = self._mode(Qd, Qp, qd, Ad, Bp, l, u, w)
+        self._bind_stream(dev)
+        n_i = np.ascontiguousarray(n_i, dtype=np.int32); m_i = np.ascontiguousarray(m_i, dtype=np.int32)
+        dpos = np.ascontiguousarray(dpos, dtype=np.int32)
+        sn, sm = int(n_i.sum()), int(m_i.sum())
+        if not dev:
+            Qd, Qp, qd, Ad, Bp, l, u, w = (self._host(a, np.float64) for a in (Qd, Qp, qd, Ad, Bp, l, u, w))
+        else:
+            self._require_dev64(Qd, Qp, qd, Ad, Bp, l, u, w)
+        p = int(w.shape[-1])
+        item_dims = dict(Qd=2, Qp=2, qd=1, Ad=2, Bp=2, l=1, u=1, w=1)
+        arrs = dict(Qd=Qd, Qp=Qp, qd=qd, Ad=Ad, Bp=Bp, l=l, u=u, w=w)
+        sizes = dict(Qd=sn * nd, Qp=sn * p, qd=sn, Ad=sm * nd, Bp=sm * p, l=sm, u=sm, w=p)
+        batch = 1
+        strides = {}
+        for k, a_ in arrs.items():
+            if a_.ndim == item_dims[k] + 1:
+                batch = max(batch, int(a_.shape[0])); strides[k] = sizes[k]
+            elif a_.ndim == item_dims[k]:
+                strides[k] = 0
+            else:
+                raise ValueError(f"assemble_pools: {k} has {a_.ndim} dimensions")
+            n_el = int(np.prod(a_.shape[-item_dims[k]:])) if item_dims[k] else 1
+            if n_el != sizes[k]:
+                raise ValueError(f"assemble_pools: {k} has {n_el} entries per item, the shape says {sizes[k]}")
+        if strides["l"] != strides["u"]:
+            raise ValueError("assemble_pools: l and u must both be shared or both per item")
+        for k, a_ in arrs.items():
+            if strides[k] and a_.shape[0] != batch:
+                raise ValueError(f"assemble_pools: {k} has batch {a_.shape[0]}, others {batch}")
+        fcode = {"reduced": POOL_REDUCED, "reference": POOL_REFERENCE}[form]
+        shape = PoolShape(len(n_i), int(nd), p, n_i.ctypes.data, m_i.ctypes.data, dpos.ctypes.data)
+        Nn = C.c_int32(0)
+        if self.lib.qpn_pool_size(C.byref(shape), fcode, C.byref(Nn)) != 0:
+            raise QpnError("qpn_pool_size: bad pool shape")
+        N = int(Nn.value)
+        if share_M is None:
+            share_M = strides["Qd"] == 0 and strides["Ad"] == 0
+        Mout = self._alloc(dev, (N, N) if share_M else (batch, N, N), np.float64)
+        qout = self._alloc(dev, (batch, N), np.float64)
+        lout = self._alloc(dev, (batch, N), np.float64)
+        uout = self._alloc(dev, (batch, N), np.float64)
+        kind = self._alloc(dev, (batch, N), np.uint8)
+        rc = self.lib.qpn_assemble_pools(self.ctx, C.byref(shape), fcode, batch, _ptr(Qd), strides["Qd"], _ptr(Qp), strides["Qp"],
+                                         _ptr(qd), strides["qd"], _ptr(Ad), strides["Ad"], _ptr(Bp), strides["Bp"], _ptr(l), _ptr(u),
+                                         strides["l"], _ptr(w), strides["w"], _ptr(Mout), 0 if share_M else N * N, _ptr(qout),
+                                         _ptr(lout), _ptr(uout), _ptr(kind), MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_assemble_pools")
+        return Mout, qout, lout, uout, kind
+
     # -- (A5+A6+A2+A3+A9 fused) --------------------------------------------------------------
     def solve_nodes(self, Qc, Rc, qd, Ac, Bc, l, u, w, z0=None, opts=None, want_active=True, out=None,
                     x_out=None):

@@ -182,3 +182,31 @@ def test_batched_subpiece_verification_equals_one_by_one(eng):
         S = {child: [pieces[0], bad] + pieces[1:]}
         out = process_qp(net, pid, x, S, engine=eng)
         assert out["solution"] is False and out["subpiece_assignments"] == {child: 1}
+
+
+def test_robust_avoid_pool_avis_all_levels_with_fixture_pieces(eng):
+    """BASELINE config 2 on the host logic (oracle engine): the pool AVIs of the three levels of robust_avoid_simple with
+    the committed child pieces have the sizes SURVEY section 8 derives (N_ref 52 / 60-100 / 60-120) and solve; the
+    HIP twin (device assembly + HIP solve) is tests/test_gpu_pools.py."""
+    import json, os
+    from qpn_amd import avi, examples
+    from qpn_amd.programs import Poly
+    net = examples.setup("robust_avoid_simple")
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "robust_avoid_pieces.json")))
+    x = np.asarray(fx["x"])
+    S = {int(k): Poly(np.asarray(v["A"]), np.asarray(v["l"], dtype=float), np.asarray(v["u"], dtype=float), normalise=False)
+         for k, v in fx["pieces"].items()}
+    sizes = {}
+    for level in (3, 2, 1):
+        pool = sorted(net.network_depth_map[level])
+        dec = sorted(set().union(*[set(net.decision_inds(i)) for i in pool]))
+        par = [i for i in range(net.num_vars) if i not in set(dec)]
+        lab = {i: avi.create_labeled_gavi_from_qp(net, i, S) for i in pool}
+        g = avi.combine_gavis(net.num_vars, dec, par, lab)
+        sizes[level] = len(g.l1) + 2 * len(g.l2)
+        z0 = np.concatenate([x[dec], np.zeros(g.M.shape[1] - len(dec))])
+        z, st, info = avi.solve_gavi(g, z0, x[par], engine=eng, reference_form=True)
+        assert st == avi.StatusCode.SUCCESS and info["resid"] <= 1e-8
+        b = avi.pool_blocks(net.num_vars, dec, par, lab)
+        assert sum(b["n_i"]) == len(dec) and b["Qd"].shape == (len(dec), len(dec)) and b["Ad"].shape[0] == len(g.l2)
+    assert sizes == {3: 52, 2: 68, 1: 80}
