@@ -276,6 +276,26 @@ int qpn_set_primal_mirrors(qpn_ctx *ctx, const double *own, size_t bytes, int32_
 int qpn_sweep_status(qpn_ctx *ctx, const int32_t *status, const double *resid, int32_t count, double *out,
                      int32_t rank, int32_t world, void *const *boxes, uint64_t epoch, int32_t timeout_ms);
 
+/* ---- (F1) local pieces of a node's solution map: local_piece, src/avi_solutions.jl:400-496 -----------------------
+ * For the per-node GAVI of process_solution_graph (src/avi.jl:447-477) -- z = [x_d (n); lambda (m)], w = x_p (p), built from
+ * the same node records as qpn_solve_nodes -- and a recipe K (one code per row of z: 1..4 on the x_d rows, 5..8 on the
+ * constraint rows, src/avi_solutions.jl:390-399; code 0 = no condition), the polyhedral piece on which that recipe holds:
+ *     rows [M N ; I2 0 ; I1 0 ; A B] over [z; w]  (:405-408),  bounds per code (:413-432),  noisy l > u -> l = u (:437-438),
+ *     entries <= 1e-8 dropped (:439),  keep[] = find_non_trivial (:384-388).
+ * Output per piece: Ap [(2N) x (N+p)] column-major (N = n+m), lp, up [2N], keep [2N]; simplify / projection stay with the
+ * caller (polyhedral algebra).  `pieces` items; item t uses the records of node node_of[t] (node_of == NULL: node t), so
+ * the many recipes of one solution share its records (nodes = number of record sets behind the pointers).
+ * qpn_recipes_from_masks enumerates recipes from the active-set masks of a solve (`active` of qpn_solve_nodes, one uint8
+ * per row: the code sets J of src/avi_solutions.jl:511-562): recipe number first + t of the Cartesian product of the rows'
+ * code sets (all_Ks, :200-215; row 0 is the fastest digit) for t < count; *total (may be NULL) = number of recipes
+ * (saturating at INT64_MAX). */
+int qpn_local_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd,
+                     const double *R, const double *qd, const double *Ad, const double *B, const double *l,
+                     const double *u, const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up,
+                     uint8_t *keep, int mem);
+int qpn_recipes_from_masks(qpn_ctx *ctx, int32_t N, const uint8_t *mask, int64_t first, int32_t count, uint8_t *K,
+                           int64_t *total, int mem);
+
 /* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
  *   xd [batch][n] current decision values, w as above.
  *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower

@@ -231,3 +231,18 @@ def verify_solution(Qd, R, qd, Ad, B, l, u, xd, w, tol=1e-4):
                                     _p(_colmajor(Ad)), _p(_colmajor(B)), _p(_f64(l)), _p(_f64(u)),
                                     _p(_f64(xd)), _p(w), C.c_double(tol), _p(lam), C.byref(path))
     return bool(sol), lam[:m].copy(), int(path.value)
+
+
+def local_piece(Qd, R, qd, Ad, B, l, u, K):
+    """qpo_local_piece: the piece of recipe K (codes 1..8 per row of z = [x_d; lambda]) before simplify.
+    Math-layout inputs; returns (Ap (2N, N+p), lp, up, keep)."""
+    Qd = _f64(Qd); n = Qd.shape[0]
+    Ad = _f64(Ad).reshape(-1, n); m = Ad.shape[0]
+    R = _f64(R).reshape(n, -1); p = R.shape[1]
+    B = _f64(B).reshape(m, p)
+    N = n + m
+    K = np.ascontiguousarray(K, dtype=np.uint8)
+    Ap = np.zeros(2 * N * (N + p)); lp = np.zeros(2 * N); up = np.zeros(2 * N); keep = np.zeros(2 * N, dtype=np.uint8)
+    lib().qpo_local_piece(n, m, p, _p(_colmajor(Qd)), _p(_colmajor(R)), _p(_f64(qd)), _p(_colmajor(Ad)), _p(_colmajor(B)),
+                          _p(_f64(l)), _p(_f64(u)), _p(K, C.c_uint8), _p(Ap), _p(lp), _p(up), _p(keep, C.c_uint8))
+    return Ap.reshape(N + p, 2 * N).T.copy(), lp, up, keep

@@ -765,3 +765,59 @@ done:
     free(qt); free(ax);
     return sol;
 }
+
+/* ---- local_piece, src/avi_solutions.jl:400-441 + :491-496 --------------------------------------------------------
+ * A = [gavi.M gavi.N; I2 0; I1 0; gavi.A gavi.B] (:405-408) for the per-node GAVI of src/avi.jl:466-473; bounds per
+ * recipe code (:413-432); l = [bounds[:,1]; bounds[:,3]], u = [bounds[:,2]; bounds[:,4]] (:434-435). */
+void qpo_local_piece(int n, int m, int p, const double *Qd, const double *R, const double *qd, const double *Ad,
+                     const double *B, const double *l, const double *u, const uint8_t *K, double *Ap, double *lp,
+                     double *up, uint8_t *keep)
+{
+    const int N = n + m, rows = 2 * N, cols = N + p;
+    const double inf = INFINITY;
+    for (long t = 0; t < (long)rows * cols; ++t) Ap[t] = 0.0;
+#define AP(r, c) Ap[(size_t)(c) * rows + (r)]
+    for (int i = 0; i < n; ++i) {                       /* [M N]: row i = [Qd(i,:)  -Ad(:,i)'  R(i,:)] */
+        for (int j = 0; j < n; ++j) AP(i, j) = Qd[(size_t)j * n + i];
+        for (int k = 0; k < m; ++k) AP(i, n + k) = -Ad[(size_t)i * m + k];
+        for (int c = 0; c < p; ++c) AP(i, N + c) = R[(size_t)c * n + i];
+    }
+    for (int k = 0; k < m; ++k) AP(n + k, n + k) = 1.0;                 /* [I2 0] */
+    for (int i = 0; i < n; ++i) AP(N + i, i) = 1.0;                     /* [I1 0] */
+    for (int k = 0; k < m; ++k) {                                       /* [A B], A = [Ad 0] */
+        for (int j = 0; j < n; ++j) AP(N + n + k, j) = Ad[(size_t)j * m + k];
+        for (int c = 0; c < p; ++c) AP(N + n + k, N + c) = B[(size_t)c * m + k];
+    }
+    for (int i = 0; i < N; ++i) {
+        double b1, b2, b3, b4;
+        const int code = K[i];
+        if (i < n) {
+            const double o = qd[i], l1 = -inf, u1 = inf;
+            switch (code) {
+            case 1: b1 = -o; b2 = inf; b3 = l1; b4 = l1; break;
+            case 2: b1 = -o; b2 = -o; b3 = l1; b4 = u1; break;
+            case 3: b1 = -inf; b2 = -o; b3 = u1; b4 = u1; break;
+            default: b1 = -inf; b2 = inf; b3 = l1; b4 = u1; break;       /* 4 */
+            }
+        } else {
+            const double l2 = l[i - n], u2 = u[i - n];
+            switch (code) {
+            case 5: b1 = 0.0; b2 = inf; b3 = l2; b4 = l2; break;
+            case 6: b1 = 0.0; b2 = 0.0; b3 = l2; b4 = u2; break;
+            case 7: b1 = -inf; b2 = 0.0; b3 = u2; b4 = u2; break;
+            default: b1 = -inf; b2 = inf; b3 = l2; b4 = u2; break;       /* 8 */
+            }
+        }
+        lp[i] = b1; up[i] = b2; lp[N + i] = b3; up[N + i] = b4;
+    }
+    for (int r = 0; r < rows; ++r) {
+        if (lp[r] > up[r]) lp[r] = up[r];                                /* noisy_inds, :437-438 */
+        int nz = 0;
+        for (int c = 0; c < cols; ++c) {
+            if (fabs(AP(r, c)) <= 1e-8) AP(r, c) = 0.0;                  /* droptol!, :439 */
+            else nz = 1;
+        }
+        keep[r] = (uint8_t)((!isinf(lp[r]) || !isinf(up[r])) && nz);     /* find_non_trivial, :384-388 */
+    }
+#undef AP
+}

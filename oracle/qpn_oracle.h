@@ -13,6 +13,7 @@
  *   qpo_assemble_node        src/avi.jl:205-251 + 305-377 (single-node pool, dense, reduced form)
  *   qpo_verify_solution      src/qp_processing.jl:57-149 (+ :12-33 bounded-LSQ fallback)
  *   qpo_comp_indices         src/avi_solutions.jl:511-562, 587-612
+ *   qpo_local_piece          src/avi_solutions.jl:400-441, 491-496, 384-388 (piece of a recipe, before simplify)
  *
  * PARITY STATUS: "parity unpinned" at the solve_mcp boundary.  The arithmetic
  * behind src/avi.jl:64 lives in PATHSolver.jl (compat "1.7", Project.toml:28;
@@ -105,6 +106,17 @@ int qpo_verify_solution(int n, int m, int p, const double *Qd, const double *R, 
                         const double *Ad, const double *B, const double *l, const double *u,
                         const double *xd, const double *w, double tol, double *lambda,
                         int *path_out);
+
+/* src/avi_solutions.jl:400-441 + :491-496 (find_non_trivial :384-388), reducible_inds empty (the live caller, `expand`,
+ * :246-247), for the per-node GAVI of process_solution_graph (src/avi.jl:447-477): z = [x_d (n); lambda (m)], w = x_p (p),
+ *   M = [Qd -Ad'], N = R, o = qd, l1/u1 = -+inf, A = [Ad 0], B = B, l2 = l, u2 = u.
+ * K[i] in 1..4 for i < n, 5..8 for i >= n: the recipe's code of row i (:390-399).
+ * Outputs the piece BEFORE simplify (polyhedral; host): Ap [(2N) x (N+p)] column-major, N = n+m, rows
+ * [M N ; I2 0 ; I1 0 ; A B], bounds lp/up [2N] (noisy l > u fixed to l = u, :437-438; entries <= 1e-8 dropped, :439),
+ * keep [2N] = find_non_trivial (a finite bound and a non-empty row). */
+void qpo_local_piece(int n, int m, int p, const double *Qd, const double *R, const double *qd, const double *Ad,
+                     const double *B, const double *l, const double *u, const uint8_t *K, double *Ap, double *lp,
+                     double *up, uint8_t *keep);
 
 int qpo_num_threads(void);
 

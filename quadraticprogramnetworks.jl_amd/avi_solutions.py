@@ -35,6 +35,43 @@ def masks_to_sets(mask):
     return {i + 1: {c + 1 for c in range(8) if (int(m) >> c) & 1} for i, m in enumerate(mask)}
 
 
+def node_records(Q, q, A, l, u, dec_inds):
+    """The per-node GAVI of process_solution_graph (src/avi.jl:447-477) as node records (math layout):
+    Qd = Q[dec, dec], R = Q[dec, param], qd = q[dec], Ad = A[:, dec], B = A[:, param]."""
+    n = Q.shape[0]
+    dec = list(dec_inds)
+    par = [i for i in range(n) if i not in set(dec)]
+    return dict(Qd=Q[np.ix_(dec, dec)], R=Q[np.ix_(dec, par)], qd=q[dec], Ad=A[:, dec], B=A[:, par], l=np.asarray(l, float),
+                u=np.asarray(u, float), dec=dec, par=par)
+
+
+def local_pieces(rec, K, engine=None, simplify=True):
+    """local_piece (src/avi_solutions.jl:400-496) for every recipe in K [pieces, n+m] (codes 1..8 per row of z = [x_d; lambda])
+    of ONE node (records from node_records): one qpn_local_pieces launch.  Returns a list of Poly over [x_d; lambda; x_p]
+    (rows that pass find_non_trivial; `simplify` merges duplicate normals, the array part of src/sets.jl:255-311)."""
+    from .engine import colmajor
+    eng = _eng(engine)
+    K = np.atleast_2d(np.asarray(K, dtype=np.uint8))
+    one = lambda a: np.asarray(a, dtype=np.float64)[None]
+    Ap, lp, up, keep = eng.local_pieces(colmajor(one(rec["Qd"])), colmajor(one(rec["R"])), one(rec["qd"]), colmajor(one(rec["Ad"])),
+                                        colmajor(one(rec["B"])), one(rec["l"]), one(rec["u"]), K,
+                                        node_of=np.zeros(K.shape[0], np.int32))
+    out = []
+    for t in range(K.shape[0]):
+        rows = np.asarray(keep[t]).astype(bool)
+        P = Poly(np.asarray(Ap[t]).T[rows], np.asarray(lp[t])[rows], np.asarray(up[t])[rows])
+        out.append(_dedupe(P) if simplify else P)
+    return out
+
+
+def all_Ks(mask, engine=None, limit=4096):
+    """all_Ks (src/avi_solutions.jl:200-215): every recipe compatible with the masks J of one solution (the Cartesian
+    product of the rows' code sets), enumerated on the device.  Returns (K [count, N], total)."""
+    eng = _eng(engine)
+    _, total = eng.recipes_from_masks(np.asarray(mask, dtype=np.uint8), 0, 0)
+    return eng.recipes_from_masks(np.asarray(mask, dtype=np.uint8), 0, min(total, limit))
+
+
 def local_pieces_strict(Q, q, A, l, u, dec_inds, x, lam, tol=1e-2, max_pieces=64):
     """Local pieces of a node's solution map around (x, lam), in global x coordinates, for a
     node whose Q[dec,dec] is positive definite and whose active rows are linearly independent.

@@ -1,7 +1,9 @@
 // qpn_capi.hip -- the extern "C" boundary of libqpn_hip.so (include/qpn_hip.h).
 // Host-side staging, argument checking and error mapping only; all arithmetic is in the
 // HIP kernels (qpn_avi_solve.hip, qpn_kkt.hip, qpn_verify.hip).  No exceptions cross the ABI.
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -424,6 +426,94 @@ int qpn_assemble_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_
     HIPCHK(ctx, hipMemcpyAsync(lout, dlo, bN * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(uout, duo, bN * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(kind_out, dk, bN, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+// ---- (F1) local pieces ------------------------------------------------------------------------------------------
+int qpn_recipes_from_masks(qpn_ctx *ctx, int32_t N, const uint8_t *mask, int64_t first, int32_t count, uint8_t *K,
+                           int64_t *total, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (N <= 0 || !mask || first < 0 || count < 0 || (count > 0 && !K)) return fail_arg(ctx, "qpn_recipes_from_masks: bad argument");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_recipes_from_masks: bad mem kind");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<uint8_t> hm((size_t)N);
+    if (mem == QPN_MEM_HOST) memcpy(hm.data(), mask, (size_t)N);
+    else { HIPCHK(ctx, hipMemcpyAsync(hm.data(), mask, (size_t)N, hipMemcpyDeviceToHost, s)); HIPCHK(ctx, hipStreamSynchronize(s)); }
+    int64_t tot = 1;
+    for (int i = 0; i < N; ++i) {
+        const int r = __builtin_popcount(hm[i]);
+        if (r > 1) tot = (tot > INT64_MAX / r) ? INT64_MAX : tot * r;
+    }
+    if (total) *total = tot;
+    if (count == 0) return QPN_OK;
+    if (first >= tot || (int64_t)count > tot - first) return fail_arg(ctx, "qpn_recipes_from_masks: first + count beyond the number of recipes");
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_recipes(N, mask, first, count, K, s));
+        return QPN_OK;
+    }
+    uint8_t *dm, *dK;
+    Carver cv(ctx);
+    cv.add((void **)&dm, (size_t)N); cv.add((void **)&dK, (size_t)count * N);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(dm, mask, (size_t)N, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_recipes(N, dm, first, count, dK, s));
+    HIPCHK(ctx, hipMemcpyAsync(K, dK, (size_t)count * N, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+int qpn_local_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd,
+                     const double *R, const double *qd, const double *Ad, const double *B, const double *l,
+                     const double *u, const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up,
+                     uint8_t *keep, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (pieces < 0 || nodes <= 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_local_pieces: bad sizes");
+    if (pieces == 0) return QPN_OK;
+    if (n + m > 512) { ctx->last_error = "qpn_local_pieces: n + m <= 512 in ABI v1"; return QPN_ERR_SIZE; }
+    if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || (m > 0 && !B))) || !K || !Ap || !lp || !up || !keep)
+        return fail_arg(ctx, "qpn_local_pieces: null pointer");
+    if (!node_of && nodes < pieces) return fail_arg(ctx, "qpn_local_pieces: fewer record sets than pieces and no node_of");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_local_pieces: bad mem kind");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_local_pieces(pieces, n, m, p, Qd, R, qd, Ad, B, l, u, node_of, K, Ap, lp, up, keep, s));
+        return QPN_OK;
+    }
+    if (node_of)
+        for (int t = 0; t < pieces; ++t)
+            if (node_of[t] < 0 || node_of[t] >= nodes) return fail_arg(ctx, "qpn_local_pieces: node_of outside 0..nodes-1");
+    const int N = n + m;
+    const NodeSizes sz = node_sizes(nodes, n, m, p, 0);
+    const size_t rows = 2 * (size_t)N, cols = (size_t)N + p;
+    double *dQ, *dR, *dq, *dA, *dB, *dl, *du, *dAp, *dlp, *dup; int32_t *dno = nullptr; uint8_t *dK, *dkeep;
+    Carver cv(ctx);
+    cv.add((void **)&dQ, sz.Q); cv.add((void **)&dR, sz.R + 8); cv.add((void **)&dq, sz.q); cv.add((void **)&dA, sz.A + 8);
+    cv.add((void **)&dB, sz.B + 8); cv.add((void **)&dl, sz.lu + 8); cv.add((void **)&du, sz.lu + 8);
+    if (node_of) cv.add((void **)&dno, (size_t)pieces * 4);
+    cv.add((void **)&dK, (size_t)pieces * N); cv.add((void **)&dAp, (size_t)pieces * rows * cols * 8);
+    cv.add((void **)&dlp, (size_t)pieces * rows * 8); cv.add((void **)&dup, (size_t)pieces * rows * 8);
+    cv.add((void **)&dkeep, (size_t)pieces * rows);
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(dQ, Qd, sz.Q, hipMemcpyHostToDevice, s));
+    if (sz.R) HIPCHK(ctx, hipMemcpyAsync(dR, R, sz.R, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dq, qd, sz.q, hipMemcpyHostToDevice, s));
+    if (sz.A) HIPCHK(ctx, hipMemcpyAsync(dA, Ad, sz.A, hipMemcpyHostToDevice, s));
+    if (sz.B) HIPCHK(ctx, hipMemcpyAsync(dB, B, sz.B, hipMemcpyHostToDevice, s));
+    if (sz.lu) { HIPCHK(ctx, hipMemcpyAsync(dl, l, sz.lu, hipMemcpyHostToDevice, s)); HIPCHK(ctx, hipMemcpyAsync(du, u, sz.lu, hipMemcpyHostToDevice, s)); }
+    if (node_of) HIPCHK(ctx, hipMemcpyAsync(dno, node_of, (size_t)pieces * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dK, K, (size_t)pieces * N, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_local_pieces(pieces, n, m, p, dQ, dR, dq, dA, dB, dl, du, dno, dK, dAp, dlp, dup, dkeep, s));
+    HIPCHK(ctx, hipMemcpyAsync(Ap, dAp, (size_t)pieces * rows * cols * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(lp, dlp, (size_t)pieces * rows * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(up, dup, (size_t)pieces * rows * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(keep, dkeep, (size_t)pieces * rows, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return QPN_OK;
 }

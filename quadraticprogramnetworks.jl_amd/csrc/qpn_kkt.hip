@@ -246,6 +246,94 @@ __global__ __launch_bounds__(256) void assemble_pools_kernel(PoolArgs a)
     }
 }
 
+// ---- (F1) local pieces: local_piece, src/avi_solutions.jl:400-441 + :491-496, for the per-node GAVI of
+// process_solution_graph (src/avi.jl:447-477): z = [x_d (n); lambda (m)], w = x_p (p),
+//     rows of the piece  [M N ; I2 0 ; I1 0 ; A B],   M = [Qd -Ad'], N = R, A = [Ad 0], B = B   (:405-408)
+// with the bounds of recipe K (one code 1..8 per row of z, :413-432).  One workgroup per piece; item t takes the records of
+// node node_of[t] (or t): many recipes of one node share its records.  Output BEFORE simplify (polyhedral, host side):
+// Ap [(2N) x (N+p)] column-major, lp / up [2N] with the noisy l > u fix (:437-438), entries <= 1e-8 dropped (:439),
+// keep [2N] = find_non_trivial (:384-388: a finite bound and a non-empty row).
+__global__ __launch_bounds__(256) void local_pieces_kernel(int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+                                                            const double *R, const double *qd, const double *Ad,
+                                                            const double *B, const double *l, const double *u,
+                                                            const int32_t *node_of, const uint8_t *K, double *Ap,
+                                                            double *lp, double *up, uint8_t *keep)
+{
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int b = node_of ? node_of[t] : t;
+    const int N = n + m, rows = 2 * N, cols = N + p;
+    const double *Q_ = Qd + (size_t)b * n * n, *A_ = Ad + (size_t)b * m * n, *R_ = R + (size_t)b * n * p, *B_ = B + (size_t)b * m * p;
+    double *Ao = Ap + (size_t)t * (size_t)rows * cols;
+    __shared__ int s_nz[1024];                                       // non-empty flag per row (rows <= 2 * 512)
+    for (int r = tid; r < rows; r += 256) s_nz[r] = 0;
+    __syncthreads();
+    for (int c = 0; c < cols; ++c) {
+        for (int r = tid; r < rows; r += 256) {
+            double v = 0.0;
+            if (r < n) {
+                if (c < n) v = Q_[(size_t)c * n + r];
+                else if (c < N) v = -A_[(size_t)r * m + (c - n)];
+                else v = R_[(size_t)(c - N) * n + r];
+            } else if (r < N) v = (c == r) ? 1.0 : 0.0;
+            else if (r < N + n) v = (c == r - N) ? 1.0 : 0.0;
+            else {
+                const int k = r - N - n;
+                if (c < n) v = A_[(size_t)c * m + k];
+                else if (c >= N) v = B_[(size_t)(c - N) * m + k];
+            }
+            if (fabs(v) <= 1e-8) v = 0.0; else s_nz[r] = 1;          // (a lane's own rows only: no race)
+            Ao[(size_t)c * rows + r] = v;
+        }
+    }
+    __syncthreads();
+    const double inf = QINF;
+    for (int i = tid; i < N; i += 256) {
+        const int code = K[(size_t)t * N + i];
+        double b1, b2, b3, b4;
+        if (i < n) {
+            const double o = qd[(size_t)b * n + i];
+            if (code == 1) { b1 = -o; b2 = inf; b3 = -inf; b4 = -inf; }
+            else if (code == 2) { b1 = -o; b2 = -o; b3 = -inf; b4 = inf; }
+            else if (code == 3) { b1 = -inf; b2 = -o; b3 = inf; b4 = inf; }
+            else { b1 = -inf; b2 = inf; b3 = -inf; b4 = inf; }
+        } else {
+            const double l2 = l[(size_t)b * m + (i - n)], u2 = u[(size_t)b * m + (i - n)];
+            if (code == 5) { b1 = 0.0; b2 = inf; b3 = l2; b4 = l2; }
+            else if (code == 6) { b1 = 0.0; b2 = 0.0; b3 = l2; b4 = u2; }
+            else if (code == 7) { b1 = -inf; b2 = 0.0; b3 = u2; b4 = u2; }
+            else { b1 = -inf; b2 = inf; b3 = l2; b4 = u2; }
+        }
+        if (b1 > b2) b1 = b2;
+        if (b3 > b4) b3 = b4;
+        const size_t vo = (size_t)t * rows;
+        lp[vo + i] = b1; up[vo + i] = b2; lp[vo + N + i] = b3; up[vo + N + i] = b4;
+        keep[vo + i] = (uint8_t)((!isinf(b1) || !isinf(b2)) && s_nz[i]);
+        keep[vo + N + i] = (uint8_t)((!isinf(b3) || !isinf(b4)) && s_nz[N + i]);
+    }
+}
+
+// recipe number first + t of the Cartesian product of the rows' code sets (all_Ks, src/avi_solutions.jl:200-215; row 0 is
+// the fastest digit): K[t][i] = the digit-th set bit of mask[i] (+1 = code); an empty set gives code 0 (treated as free)
+__global__ __launch_bounds__(256) void recipes_kernel(int32_t N, const uint8_t *mask, long long first, int32_t count, uint8_t *K)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    unsigned long long idx = (unsigned long long)first + (unsigned long long)t;
+    for (int i = 0; i < N; ++i) {
+        const unsigned mk = mask[i];
+        const int radix = __popc(mk);
+        int code = 0;
+        if (radix > 0) {
+            int d = (int)(idx % (unsigned)radix);
+            idx /= (unsigned)radix;
+            unsigned mm = mk;
+            while (d-- > 0) mm &= mm - 1;                            // drop the d lowest set bits
+            code = __ffs(mm);                                        // 1-based bit position = code
+        }
+        K[(size_t)t * N + i] = (uint8_t)code;
+    }
+}
+
 // `key` (optional, [count] int32, zero at first): an exponentially smoothed pivot count per node in units of 1/16 pivot
 // (key <- key - key/8 + 2 p): between sweeps the parameters change and with them a node's pivot count, by about half of
 // the spread between nodes on the bench workload; ordering by the smoothed count is worth 2-3 % of the sweep there.
@@ -387,6 +475,24 @@ hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int3
 {
     if (count <= 0) return hipSuccess;
     hipLaunchKernelGGL(order_by_pivots_kernel, dim3(1), dim3(1024), 0, stream, pivots, count, order, key);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_local_pieces(int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
+                                   const double *qd, const double *Ad, const double *B, const double *l, const double *u,
+                                   const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up, uint8_t *keep,
+                                   hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(local_pieces_kernel, dim3((unsigned)batch), dim3(256), 0, stream, batch, n, m, p, Qd, R, qd, Ad, B, l, u,
+                       node_of, K, Ap, lp, up, keep);
+    return hipGetLastError();
+}
+
+hipError_t qpn_launch_recipes(int32_t N, const uint8_t *mask, long long first, int32_t count, uint8_t *K, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(recipes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, N, mask, first, count, K);
     return hipGetLastError();
 }
 

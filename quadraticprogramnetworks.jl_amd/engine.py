@@ -257,6 +257,54 @@ class Engine:
         self._chk(rc, "qpn_assemble_nodes")
         return Mout, qout, lout, uout, kind
 
+    # -- (F1) local pieces ------------------------------------------------------------------------
+    def recipes_from_masks(self, mask, first=0, count=None):
+        """all_Ks (src/avi_solutions.jl:200-215) from one solution's active-set masks (uint8 per row of z): recipes number
+        first .. first+count-1 of the Cartesian product of the rows' code sets.  Returns (K [count, N] uint8, total)."""
+        dev = self._mode(mask)
+        self._bind_stream(dev)
+        if not dev:
+            mask = self._host(mask, np.uint8)
+        N = int(mask.shape[0])
+        total = C.c_int64(0)
+        rc = self.lib.qpn_recipes_from_masks(self.ctx, N, _ptr(mask), 0, 0, None, C.byref(total), MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_recipes_from_masks")
+        tot = int(total.value)
+        if count is None:
+            count = tot - first
+        K = self._alloc(dev, (count, N), np.uint8)
+        rc = self.lib.qpn_recipes_from_masks(self.ctx, N, _ptr(mask), int(first), int(count), _ptr(K), None,
+                                             MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_recipes_from_masks")
+        return K, tot
+
+    def local_pieces(self, Qc, Rc, qd, Ac, Bc, l, u, K, node_of=None):
+        """local_piece (src/avi_solutions.jl:400-496, before simplify) for recipes K [pieces, n+m] over node records in the
+        ABI layout (as solve_nodes); node_of [pieces] int32 names each recipe's node (default: recipe t <-> node t).
+        Returns (Ap [pieces, N+p, 2N] column-major per piece, lp, up [pieces, 2N], keep [pieces, 2N] uint8)."""
+        dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, K, node_of)
+        self._bind_stream(dev)
+        if not dev:
+            Qc, Rc, qd, Ac, Bc, l, u = (self._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u))
+            K = self._host(K, np.uint8)
+            node_of = self._host(node_of, np.int32)
+        else:
+            self._require_dev64(Qc, Rc, qd, Ac, Bc, l, u)
+        nodes, n = qd.shape
+        m = l.shape[1]
+        p = Rc.shape[1]
+        N = n + m
+        pieces = int(K.shape[0])
+        Ap = self._alloc(dev, (pieces, N + p, 2 * N), np.float64)
+        lp = self._alloc(dev, (pieces, 2 * N), np.float64)
+        up = self._alloc(dev, (pieces, 2 * N), np.float64)
+        keep = self._alloc(dev, (pieces, 2 * N), np.uint8)
+        rc = self.lib.qpn_local_pieces(self.ctx, pieces, nodes, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac), _ptr(Bc), _ptr(l),
+                                       _ptr(u), _ptr(node_of), _ptr(K), _ptr(Ap), _ptr(lp), _ptr(up), _ptr(keep),
+                                       MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_local_pieces")
+        return Ap, lp, up, keep
+
     # -- (A6) pool assembly ----------------------------------------------------------------------
     def assemble_pools(self, n_i, m_i, dpos, nd, Qd, Qp, qd, Ad, Bp, l, u, w, form="reduced", share_M=None):
         """combine_gavis (src/avi.jl:305-377) for `batch` instances of one pool shape, on the device.
