@@ -302,7 +302,7 @@ int qpn_recipes_from_masks(qpn_ctx *ctx, int32_t N, const uint8_t *mask, int64_t
  *   bound, - at the upper, :120-123), path [batch] int32: 0 infeasible (:86-89), 1 m==0
  *   shortcut (:91-96), 2 least-squares duals accepted (:114-124), 3 bounded-LSQ fallback
  *   accepted (:129-139), 4 fallback rejected (:141), 5 fallback solver failed (:144).
- *   tol = 1e-4 (:57).  n, m <= 64. */
+ *   tol = 1e-4 (:57).  n, m <= 64: one wavefront per node; up to 512: one workgroup per node. */
 int qpn_verify_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p,
                      const double *Qd, const double *R, const double *qd, const double *Ad,
                      const double *B, const double *l, const double *u, const double *xd,

@@ -1185,7 +1185,9 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     if (!ctx) return QPN_ERR_ARG;
     if (batch < 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_verify_nodes: bad sizes");
     if (batch == 0) return QPN_OK;
-    if (n > 64 || m > 64) { ctx->last_error = "qpn_verify_nodes: n, m <= 64 in ABI v1"; return QPN_ERR_SIZE; }
+    if (n > qpn_verify_max_dim() || m > qpn_verify_max_dim()) { ctx->last_error = "qpn_verify_nodes: n, m <= 512 in ABI v1"; return QPN_ERR_SIZE; }
+    const bool wide_avi = m > 64;         // the bounded-LSQ fallback of wide nodes runs on the large-item AVI kernel
+    double *wbig = nullptr;
     if (!Qd || !qd || !xd || (m > 0 && (!Ad || !l || !u || !lambda)) || (p > 0 && (!R || !w || (m > 0 && !B))) ||
         !solution || !path)
         return fail_arg(ctx, "qpn_verify_nodes: null pointer");
@@ -1201,10 +1203,11 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
         cv.add((void **)&slb, (size_t)batch * mm * 8); cv.add((void **)&sub, (size_t)batch * mm * 8);
         cv.add((void **)&sz, (size_t)batch * mm * 8); cv.add((void **)&sres, (size_t)batch * 8);
         cv.add((void **)&sst, (size_t)batch * 4);
+        if (wide_avi) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, m));
         int rc = cv.commit();
         if (rc != QPN_OK) return rc;
         HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, Qd, R, qd, Ad, B, l, u, xd, w, stride_w, tol,
-                                            solution, lambda, path, sG, sq, slb, sub, sz, sres, sst, s));
+                                            solution, lambda, path, sG, sq, slb, sub, sz, sres, sst, s, wbig));
         return QPN_OK;
     }
     if (mem != QPN_MEM_HOST) return fail_arg(ctx, "qpn_verify_nodes: bad mem kind");
@@ -1225,6 +1228,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     cv.add((void **)&slb, (size_t)batch * mm * 8); cv.add((void **)&sub, (size_t)batch * mm * 8);
     cv.add((void **)&sz, (size_t)batch * mm * 8); cv.add((void **)&sres, (size_t)batch * 8);
     cv.add((void **)&sst, (size_t)batch * 4);
+    if (wide_avi) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, m));
     int rc = cv.commit();
     if (rc != QPN_OK) return rc;
     if (!records_on_device) {
@@ -1242,7 +1246,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     HIPCHK(ctx, hipMemcpyAsync(dx, xd, sz_.q, hipMemcpyHostToDevice, s));
     if (p > 0) HIPCHK(ctx, hipMemcpyAsync(dw, w, sz_.w, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dx, dw, stride_w, tol,
-                                        dsol, dlam, dpath, sG, sq, slb, sub, sz, sres, sst, s));
+                                        dsol, dlam, dpath, sG, sq, slb, sub, sz, sres, sst, s, wbig));
     HIPCHK(ctx, hipMemcpyAsync(solution, dsol, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(path, dpath, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
     if (sz_.lu) HIPCHK(ctx, hipMemcpyAsync(lambda, dlam, sz_.lu, hipMemcpyDeviceToHost, s));

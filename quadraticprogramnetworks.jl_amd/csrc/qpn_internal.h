@@ -144,7 +144,9 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
                                    const double *u, const double *xd, const double *w,
                                    int64_t stride_w, double tol, int32_t *solution, double *lambda,
                                    int32_t *path, double *sG, double *sq, double *slb, double *sub,
-                                   double *sz, double *sres, int32_t *sst, hipStream_t stream);
+                                   double *sz, double *sres, int32_t *sst, hipStream_t stream,
+                                   double *wbig = nullptr);      // wbig: large-item AVI workspace (m > 64 only)
+int qpn_verify_max_dim();
 
 // ---- wave64 helpers (CDNA4: one wavefront = 64 lanes) --------------------------------
 #ifdef __HIPCC__

@@ -235,7 +235,233 @@ __global__ __launch_bounds__(WAVE) void verify_stage2(VerifyArgs a, const int32_
     }
 }
 
+// ---- wide nodes (n or m beyond 64, up to 512): one workgroup of 256 threads per node -----------------------------
+// The same steps as verify_stage1 with the matrices left in global memory (Ad of a 256 x 256 node is 512 KB): thread c
+// owns the active columns c, c + 256 of the Gram matrix, which lives in the node's m x m scratch block (sG, leading
+// dimension m) and is factored there by the same diagonally pivoted Cholesky; reductions go over the workgroup.
+constexpr int WTPB = 256, WMAX = 512;
+
+__device__ __forceinline__ double block_sum_f64(double v, double *red)       // all threads get the sum; 2 barriers
+{
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block_max_f64(double v, double *red)
+{
+    v = wave_max_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(WTPB) void verify_wide_stage1(VerifyArgs a)
+{
+    const int n = a.n, m = a.m, p = a.p;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    __shared__ double sx[WMAX], sqt[WMAX], ssg[WMAX], sdiag[WMAX], sb[WMAX], sy[WMAX], slv[WMAX];
+    __shared__ int srow[WMAX], sstep[WMAX], scls[WMAX], sord[WMAX];
+    __shared__ double red[4];
+    __shared__ int s_flag, s_k, s_np, s_nn, s_pv;
+
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *B_ = a.B + (size_t)b * m * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double *lam = a.lambda + (size_t)b * m;
+    double *G = a.sG + (size_t)b * m * m;                  // Gram block / factor, leading dimension m
+
+    for (int i = tid; i < n; i += WTPB) sx[i] = a.xd[(size_t)b * n + i];
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    // :58-60  q~ (thread i <-> row i: coalesced columns of Qd)
+    for (int i = tid; i < n; i += WTPB) {
+        double qt = a.qd[(size_t)b * n + i];
+        for (int j = 0; j < n; ++j) qt = fma(Q_[(size_t)j * n + i], sx[j], qt);
+        for (int k = 0; k < p; ++k) qt = fma(R_[(size_t)k * n + i], w_[k], qt);
+        sqt[i] = qt;
+    }
+    // :84 ax, :86 feasibility, :98-103 classes
+    for (int r = tid; r < m; r += WTPB) {
+        double ax = 0.0;
+        for (int j = 0; j < n; ++j) ax = fma(A_[(size_t)j * m + r], sx[j], ax);
+        for (int k = 0; k < p; ++k) ax = fma(B_[(size_t)k * m + r], w_[k], ax);
+        const double lr = a.l[(size_t)b * m + r], ur = a.u[(size_t)b * m + r];
+        lam[r] = 0.0;
+        if (!(lr - 1e-3 <= ax && ax - 1e-3 <= ur)) s_flag = 1;
+        scls[r] = ((ax < lr + 1e-2) ? 1 : 0) | ((ax > ur - 1e-2) ? 2 : 0);
+    }
+    __syncthreads();
+    if (s_flag) { if (tid == 0) { a.solution[b] = 0; a.path[b] = 0; } return; }
+    if (m == 0) {   // :91-96
+        double s = 0.0;
+        for (int i = tid; i < n; i += WTPB) s += sqt[i] * sqt[i];
+        s = block_sum_f64(s, red);
+        if (tid == 0) { a.solution[b] = sqrt(s) <= a.tol ? 1 : 0; a.path[b] = 1; }
+        return;
+    }
+    // active columns in the order [pos | neg | both] (:114), rows ascending within a class
+    if (tid == 0) {
+        int c = 0, np = 0, nn = 0;
+        for (int pass = 1; pass <= 3; ++pass)
+            for (int r = 0; r < m; ++r)
+                if (scls[r] == pass) { srow[c] = r; ssg[c] = pass == 2 ? -1.0 : 1.0; ++c; if (pass == 1) ++np; else if (pass == 2) ++nn; }
+        s_k = c; s_np = np; s_nn = nn;
+    }
+    __syncthreads();
+    const int k = s_k, npn = s_np + s_nn;
+    // Gram entries (ascending fma chains over t, as in the small kernel) and the right-hand side
+    for (int e = tid; e < k * k; e += WTPB) {
+        const int c1 = e % k, c2 = e / k;
+        const int r1 = srow[c1], r2 = srow[c2];
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s = fma(A_[(size_t)t * m + r1], A_[(size_t)t * m + r2], s);
+        G[(size_t)c2 * m + c1] = s * ssg[c1] * ssg[c2];
+    }
+    for (int c = tid; c < k; c += WTPB) {
+        double rhs = 0.0;
+        const int r = srow[c];
+        for (int t = 0; t < n; ++t) rhs = fma(A_[(size_t)t * m + r], sqt[t], rhs);
+        sb[c] = rhs * ssg[c];
+        sstep[c] = -1;
+    }
+    __syncthreads();
+    for (int c = tid; c < k; c += WTPB) sdiag[c] = G[(size_t)c * m + c];
+    double dsc = 0.0;
+    for (int c = tid; c < k; c += WTPB) dsc = fmax(dsc, G[(size_t)c * m + c]);
+    const double dscale = block_max_f64(dsc, red);
+    int rank = 0;
+    for (int s = 0; s < k; ++s) {
+        double dm = -1.0;
+        for (int c = tid; c < k; c += WTPB) if (sstep[c] < 0) dm = fmax(dm, sdiag[c]);
+        const double dmax = block_max_f64(dm, red);
+        if (!(dmax > 1e-12 * (dscale > 1.0 ? dscale : 1.0))) break;
+        if (tid == 0) s_pv = WMAX;
+        __syncthreads();
+        for (int c = tid; c < k; c += WTPB) if (sstep[c] < 0 && sdiag[c] == dmax) atomicMin(&s_pv, c);     // lowest such column
+        __syncthreads();
+        const int pv = s_pv;
+        const double lpp = sqrt(dmax);
+        for (int c = tid; c < k; c += WTPB) {
+            double lis = 0.0;
+            if (sstep[c] < 0) lis = c == pv ? lpp : G[(size_t)pv * m + c] / lpp;
+            slv[c] = (sstep[c] >= 0 || c == pv) ? 0.0 : lis;
+            sy[c] = lis;                                  // (sy doubles as this step's L(:, s) until the back substitution)
+        }
+        __syncthreads();
+        const double ws = sb[pv] / lpp;
+        for (int c = tid; c < k; c += WTPB) {
+            if (sstep[c] < 0 && c != pv) {
+                const double lis = sy[c];
+                for (int j = 0; j < k; ++j) {
+                    const double lj = slv[j];
+                    if (lj != 0.0) G[(size_t)j * m + c] = fma(-lis, lj, G[(size_t)j * m + c]);
+                }
+                sdiag[c] = G[(size_t)c * m + c];
+                sb[c] = fma(-lis, ws, sb[c]);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < k; c += WTPB) if (sstep[c] < 0) G[(size_t)pv * m + c] = sy[c];      // L(:, s) into the freed column
+        __syncthreads();
+        if (tid == 0) { sstep[pv] = s; sb[pv] = ws; sord[s] = pv; }
+        rank++;
+        __syncthreads();
+    }
+    // back substitution  L' y = w  over the pivoted columns, last step first
+    for (int c = tid; c < k; c += WTPB) sy[c] = 0.0;
+    __syncthreads();
+    for (int s = rank - 1; s >= 0; --s) {
+        const int pv = sord[s];
+        double term = 0.0;
+        for (int c = tid; c < k; c += WTPB) if (sstep[c] > s) term += G[(size_t)pv * m + c] * sy[c];
+        const double acc = block_sum_f64(term, red);
+        if (tid == 0) sy[pv] = (sb[pv] - acc) / G[(size_t)pv * m + pv];
+        __syncthreads();
+    }
+    // :119  sign and residual tests
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    for (int c = tid; c < npn; c += WTPB) if (!(sy[c] > -a.tol)) s_flag = 1;
+    for (int c = tid; c < k; c += WTPB) slv[c] = sy[c] * ssg[c];
+    __syncthreads();
+    double res = 0.0;
+    for (int i = tid; i < n; i += WTPB) {
+        double s = -sqt[i];
+        for (int c = 0; c < k; ++c) s = fma(A_[(size_t)i * m + srow[c]], slv[c], s);
+        res += s * s;
+    }
+    res = block_sum_f64(res, red);
+    const bool ok = !s_flag && sqrt(res) <= a.tol;
+    if (ok) {
+        for (int c = tid; c < k; c += WTPB) lam[srow[c]] = (ssg[c] < 0.0) ? -sy[c] : sy[c];       // :120-123
+        if (tid == 0) { a.solution[b] = 1; a.path[b] = 2; }
+        return;
+    }
+    // ---- :129-137  bounded least squares as a box-AVI in lambda, handed to the large-item AVI kernel ---
+    __syncthreads();
+    for (int e = tid; e < m * m; e += WTPB) {
+        const int i = e % m, j = e / m;
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s = fma(A_[(size_t)t * m + i], A_[(size_t)t * m + j], s);
+        G[(size_t)j * m + i] = s;
+    }
+    for (int r = tid; r < m; r += WTPB) {
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s = fma(A_[(size_t)t * m + r], sqt[t], s);
+        a.sq[(size_t)b * m + r] = -s;
+        a.slb[(size_t)b * m + r] = (scls[r] & 2) ? -QINF : 0.0;   // :129-131
+        a.sub[(size_t)b * m + r] = (scls[r] & 1) ? QINF : 0.0;    // :132-134
+        a.sz[(size_t)b * m + r] = 0.0;
+    }
+    if (tid == 0) { a.solution[b] = 0; a.path[b] = -1; }
+}
+
+__global__ __launch_bounds__(WTPB) void verify_wide_stage2(VerifyArgs a, const int32_t *avi_status)
+{
+    const int n = a.n, m = a.m, p = a.p;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (a.path[b] != -1) return;
+    double *lam = a.lambda + (size_t)b * m;
+    __shared__ double sl_[WMAX], sx[WMAX], red[4];
+    if (avi_status[b] != QPN_SUCCESS) {   // :143-145
+        for (int r = tid; r < m; r += WTPB) lam[r] = 0.0;
+        if (tid == 0) { a.solution[b] = 0; a.path[b] = 5; }
+        return;
+    }
+    for (int r = tid; r < m; r += WTPB) { sl_[r] = a.sz[(size_t)b * m + r]; lam[r] = sl_[r]; }
+    for (int i = tid; i < n; i += WTPB) sx[i] = a.xd[(size_t)b * n + i];
+    __syncthreads();
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double res = 0.0;
+    for (int i = tid; i < n; i += WTPB) {
+        double qt = a.qd[(size_t)b * n + i];
+        for (int j = 0; j < n; ++j) qt = fma(Q_[(size_t)j * n + i], sx[j], qt);
+        for (int k = 0; k < p; ++k) qt = fma(R_[(size_t)k * n + i], w_[k], qt);
+        double s = -qt;
+        for (int r = 0; r < m; ++r) s = fma(A_[(size_t)i * m + r], sl_[r], s);
+        res += s * s;
+    }
+    res = block_sum_f64(res, red);
+    if (tid == 0) {
+        const bool ok = sqrt(res) <= 1e-4;   // :138
+        a.solution[b] = ok ? 1 : 0;
+        a.path[b] = ok ? 3 : 4;
+    }
+}
+
 } // namespace
+
+int qpn_verify_max_dim() { return WMAX; }
 
 hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t p,
                                    const double *Qd, const double *R, const double *qd,
@@ -243,7 +469,7 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
                                    const double *u, const double *xd, const double *w,
                                    int64_t stride_w, double tol, int32_t *solution, double *lambda,
                                    int32_t *path, double *sG, double *sq, double *slb, double *sub,
-                                   double *sz, double *sres, int32_t *sst, hipStream_t stream)
+                                   double *sz, double *sres, int32_t *sst, hipStream_t stream, double *wbig)
 {
     if (batch <= 0) return hipSuccess;
     VerifyArgs a{};
@@ -251,6 +477,21 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
     a.Qd = Qd; a.R = R; a.qd = qd; a.Ad = Ad; a.B = B; a.l = l; a.u = u; a.xd = xd; a.w = w;
     a.stride_w = stride_w; a.tol = tol; a.solution = solution; a.lambda = lambda; a.path = path;
     a.sG = sG; a.sq = sq; a.slb = slb; a.sub = sub; a.sz = sz;
+    if (n > 64 || m > 64) {
+        // wide nodes: workgroup per node; the bounded-LSQ fallback is a large box-AVI (N = m) on the large-item kernel
+        hipLaunchKernelGGL(verify_wide_stage1, dim3((unsigned)batch), dim3(WTPB), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || m == 0) return e;
+        AviBatchArgs s{};
+        s.batch = batch; s.N = m; s.M = sG; s.strideM = (int64_t)m * m; s.q = sq; s.l = slb; s.u = sub;
+        s.kind = nullptr; s.stride_kind = 0; s.z = sz; s.status = sst; s.resid = sres; s.pivots = nullptr;
+        s.active = nullptr; s.check_tol = 1e-6; s.piv_tol = 1e-11; s.feas_tol = 1e-12; s.comp_tol = 1e-2;
+        s.max_pivots = 0; s.only_if = path; s.only_if_value = -1;
+        e = m > 64 ? qpn_launch_avi_solve_big(s, wbig, stream) : (s.scan = 1, qpn_launch_avi_solve(s, stream));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(verify_wide_stage2, dim3((unsigned)batch), dim3(WTPB), 0, stream, a, (const int32_t *)sst);
+        return hipGetLastError();
+    }
     if (n <= 32 && m <= 32) hipLaunchKernelGGL(verify_stage1<33>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     else hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     hipError_t e = hipGetLastError();

@@ -65,6 +65,12 @@ def test_config5_handle_route_and_shards(engine, full5):
     torch.cuda.synchronize()
     for k in ("z", "status", "active", "pivots"):
         assert np.array_equal(out[k].cpu().numpy(), res[k]), k
+    # row A8 at this size: every node's verify_solution accepts its AVI solution, duals = the AVI's multipliers
+    xd = out["z"][:, :N_].contiguous()
+    sol, lam, path = nodes.verify(xd, dev[-1])
+    torch.cuda.synchronize()
+    assert int(sol.sum().item()) == NODES and bool((path == 2).all())
+    assert float((lam - out["z"][:, N_:]).abs().max()) < 1e-6
     nodes.close()
     for lo_, hi_ in [(0, 64), (448, 512), (255, 258)]:
         part = [a[lo_:hi_] for a in dev[:-1]] + [dev[-1]]

@@ -242,3 +242,30 @@ def test_abi_argument_errors_are_codes_not_crashes(engine):
     assert lib.qpn_set_node_order(ctx, ptr(st), -3, 0) < 0
     assert lib.qpn_set_node_order(ctx, None, 0, 0) == 0                             # clearing is always fine
     assert lib.qpn_solve_nodes_into(None, *base[1:], None, 0) < 0                   # no context
+
+
+@pytest.mark.parametrize("n,m,cnt", [(70, 40, 6), (40, 90, 6), (100, 130, 4), (256, 256, 3)])
+def test_verify_wide_nodes(engine, oracle, n, m, cnt):
+    """Row A8 beyond n, m <= 64 (one workgroup per node, csrc/qpn_verify.hip::verify_wide_stage1/2; config 5's nodes are
+    n = m = 256): at the AVI solution (least-squares duals accepted, path 2), at a shrunk point (bounded-LSQ fallback on the
+    large-item AVI kernel, paths 3/4) and far outside (infeasible, path 0) -- flags and paths equal to the oracle's, duals
+    within 1e-7 where the active rows are independent."""
+    Q, R, qd, A, B, l, u = P.synth_nodes(3000 + n, cnt, n, m)
+    w = P.shared_params()
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+    z = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)["z"]
+    xd = z[:, :n].copy()
+    sol, lam, path = _verify_case(engine, oracle, Q, R, qd, A, B, l, u, xd, w, f"wide {n}x{m} at solution")
+    assert np.all(sol == 1) and np.all(path == 2)
+    assert np.max(np.abs(lam - z[:, n:])) < 1e-6
+    xd2 = 0.995 * xd
+    sol2, _, path2 = _verify_case(engine, oracle, Q, R, qd, A, B, l, u, xd2, w, f"wide {n}x{m} shrunk")
+    assert np.any(path2 >= 3)
+    sol3, _, path3 = _verify_case(engine, oracle, Q, R, qd, A, B, l, u, xd + 5.0, w, f"wide {n}x{m} infeasible")
+    assert np.all(sol3 == 0) and np.all(path3 == 0)
+    # resident-records route gives the same
+    from qpn_amd.engine import colmajor
+    nodes = engine.upload_nodes(colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u)
+    s4, l4, p4 = nodes.verify(xd2, w)
+    assert np.array_equal(s4, sol2) and np.array_equal(p4, path2)
+    nodes.close()
