@@ -13,9 +13,11 @@ is a strictly convex QP whose KKT system is exactly a node's reduced AVI with Q 
 Polyhedra of different sizes share a batch: missing rows are padded with 0'x in (-inf, inf), missing variables with
 unconstrained ones (their minimum-norm value is 0).
 
-Differences from the reference, by design of this first step: bounds are closed (the open-bound flags rl / ru of
-src/sets.jl:68-92 are not modelled), the exemplar is the minimum-norm point rather than OSQP's slack-maximising one
-(both are members; `isempty` agrees wherever the answer does not hinge on the 1e-4 slack of :585 / :637).
+exemplar_batch / isempty_batch (minimum-norm member, closed bounds) are the fast primitives behind issubset_batch and
+remove_subsets.  The reference's own decision rule -- the slack-minimising LP of `exemplar` (src/sets.jl:591-642) with its
+tolerance bands and open bounds (rl / ru, :68-92, :354-356) -- is exemplar_slack_batch / isempty_slack_batch, and
+implicit_bounds_batch is `implicit_bounds` (:660-713): all of them LPs over the same rows, i.e. node-AVIs with Q = 0, batched
+through the same node solver (the general kernels take them: an LP's H block has no pivots for the matrix-core path).
 """
 from __future__ import annotations
 
@@ -113,3 +115,155 @@ def remove_subsets(polys, engine, tol=1e-6):
         if any(j != i and not is_subset[j] and sub[i, j] for j in range(k)):
             is_subset[i] = True
     return [p for p, s in zip(polys, is_subset) if not s], is_subset
+
+
+# ---- the reference's own rules on the same solver: LPs as node-AVIs with Q = 0 --------------------------------------------
+def _trip(p):
+    return p.vectorize() if hasattr(p, "vectorize") else p
+
+
+def _open(p, n):
+    if hasattr(p, "open_bounds"):
+        return p.open_bounds()
+    return np.zeros(n, bool), np.zeros(n, bool)
+
+
+def _solve_lps(cost, A, l, u, engine):
+    """Batch of LPs  min cost_b' x  s.t.  l_b <= A_b x <= u_b  (B, m, d padded arrays) through the node solver.
+    -> (status [B], x [B, d], lambda [B, m])."""
+    B, m, d = A.shape
+    if hasattr(engine, "solve_nodes"):
+        from .engine import colmajor
+        res = engine.solve_nodes(colmajor(np.zeros((B, d, d))), np.zeros((B, d, 1)), cost, colmajor(A), np.zeros((B, m, 1)), l, u,
+                                 np.zeros(1))
+    else:
+        M = np.zeros((B, d + m, d + m))
+        M[:, :d, d:] = -np.swapaxes(A, 1, 2); M[:, d:, :d] = A
+        lo = np.concatenate([np.full((B, d), -INF), l], axis=1); hi = np.concatenate([np.full((B, d), INF), u], axis=1)
+        kind = np.concatenate([np.zeros((B, d), np.uint8), np.ones((B, m), np.uint8)], axis=1)
+        res = engine.solve_avi_batch(np.swapaxes(M, 1, 2), np.concatenate([cost, np.zeros((B, m))], axis=1), lo, hi, kind=kind)
+    z = np.asarray(res["z"])
+    return np.asarray(res["status"]).astype(np.int32), z[:, :d], z[:, d:]
+
+
+def exemplar_slack_batch(polys, engine, tol=1e-2, slack_cap=1.0):
+    """`exemplar(poly; tol)` (src/sets.jl:591-642), the reference's own emptiness rule, for a batch:
+        min eps  s.t.  A x + eps >= l,  -A x + eps >= -u                       (:608-619)
+        eps > tol -> empty;  eps > -tol -> empty iff an OPEN bound is active (|dual| > tol), else a member;
+        eps <= -tol -> a member with slack                                     (:625-641)
+    plus the square-equality shortcut x = A \\ l (:599-606).  One LP per polyhedron in variables (x, eps), all in one call of
+    the node solver.  eps is capped below at -slack_cap (an unbounded LP -- OSQP's status 4, which the reference does not
+    handle -- means slack without end: a member either way).  -> (empty [B] bool, example list, eps [B])."""
+    Bn = len(polys)
+    if Bn == 0:
+        return np.zeros(0, bool), [], np.zeros(0)
+    trips = [tuple(np.asarray(a, dtype=np.float64) for a in _trip(p)) for p in polys]
+    trips = [(np.atleast_2d(A), l, u) for A, l, u in trips]
+    opens = [_open(p, len(t[1])) for p, t in zip(polys, trips)]
+    empty = np.zeros(Bn, bool); eps_out = np.full(Bn, np.nan); example = [None] * Bn
+    todo = []
+    for b, ((A, l, u), (ol, oh)) in enumerate(zip(trips, opens)):
+        n, d = A.shape
+        if n == 0:
+            empty[b] = False; continue                                                     # :594
+        if n == d and not ol.any() and not oh.any() and np.allclose(l, u, atol=tol, rtol=tol):   # :599-606
+            try:
+                x = np.linalg.solve(A, l)
+                ok = np.allclose(A @ x, l, atol=tol, rtol=tol)
+            except np.linalg.LinAlgError:
+                ok, x = False, None
+            empty[b] = not ok; example[b] = x if ok else None
+            continue
+        todo.append(b)
+    if todo:
+        dmax = max(trips[b][0].shape[1] for b in todo) + 1
+        mmax = max(2 * trips[b][0].shape[0] for b in todo) + 1
+        A2 = np.zeros((len(todo), mmax, dmax)); l2 = np.full((len(todo), mmax), -INF); u2 = np.full((len(todo), mmax), INF)
+        cost = np.zeros((len(todo), dmax)); cost[:, dmax - 1] = 1.0
+        for k, b in enumerate(todo):
+            A, l, u = trips[b]
+            n, d = A.shape
+            A2[k, :n, :d] = A; A2[k, :n, dmax - 1] = 1.0; l2[k, :n] = l                    # A x + eps >= l
+            A2[k, n:2 * n, :d] = -A; A2[k, n:2 * n, dmax - 1] = 1.0; l2[k, n:2 * n] = -u   # -A x + eps >= -u
+            A2[k, mmax - 1, dmax - 1] = 1.0; l2[k, mmax - 1] = -slack_cap                  # eps >= -cap
+        st, x, lam = _solve_lps(cost, A2, l2, u2, engine)
+        for k, b in enumerate(todo):
+            if st[k] != 1:
+                raise RuntimeError(f"exemplar_slack_batch: solver status {st[k]} on item {b}")
+            n, d = trips[b][0].shape
+            eps = x[k, dmax - 1]; eps_out[b] = eps
+            ol, oh = opens[b]
+            if eps > tol:
+                empty[b] = True
+            elif eps > -tol:
+                act_l = np.abs(lam[k, :n]) > tol; act_u = np.abs(lam[k, n:2 * n]) > tol    # :629-631
+                empty[b] = bool(np.any(act_l & ol) or np.any(act_u & oh))
+            if not empty[b]:
+                example[b] = x[k, :d].copy()
+    return empty, example, eps_out
+
+
+def isempty_slack_batch(polys, engine, tol=1e-4, x=None):
+    """`isempty(poly; tol, x)` (src/sets.jl:647-655) for a batch: membership of the given point first, else the exemplar rule."""
+    out = np.zeros(len(polys), bool)
+    rest = []
+    for b, p in enumerate(polys):
+        if x is not None and hasattr(p, "contains") and p.contains(np.asarray(x, dtype=np.float64)):
+            continue
+        rest.append(b)
+    if rest:
+        e, _, _ = exemplar_slack_batch([polys[b] for b in rest], engine, tol=tol)
+        out[rest] = e
+    return out
+
+
+def implicit_bounds_batch(polys, engine, tol=1e-4):
+    """`implicit_bounds(poly; tol)` (src/sets.jl:660-713) for a batch: which rows have implicitly equal lower and upper
+    bounds on the polyhedron, and their values.  Per row that is not an explicit equality, the two LPs min / max a_i' x over
+    the polyhedron (:676-706) -- ALL rows of ALL polyhedra in one call; an unbounded LP (RAY_TERM) gives -+inf as OSQP's
+    status 4 does there.  An empty polyhedron raises "Empty set" like the reference (:688-690).
+    -> list of (implicitly_equality [n] bool, vals [n])."""
+    trips = [tuple(np.asarray(a, dtype=np.float64) for a in _trip(p)) for p in polys]
+    trips = [(np.atleast_2d(A), l, u) for A, l, u in trips]
+    empt = isempty_batch(trips, engine) if trips else np.zeros(0, bool)
+    if empt.any():
+        raise RuntimeError(f"Empty set (polyhedron {int(np.nonzero(empt)[0][0])})")
+    jobs = []                                                   # (poly, row, sign)
+    out = []
+    for b, (A, l, u) in enumerate(trips):
+        n = A.shape[0]
+        eq = np.zeros(n, bool); vals = np.full(n, INF)
+        for i in range(n - 1, -1, -1):                          # (the reference walks the rows from the last, :670)
+            if np.isclose(l[i], u[i], rtol=0, atol=tol) or (l[i] == u[i]):
+                eq[i] = True; vals[i] = 0.5 * (l[i] + u[i])
+            else:
+                jobs.append((b, i, 1.0)); jobs.append((b, i, -1.0))
+        out.append([eq, vals])
+    if jobs:
+        dmax = max(trips[b][0].shape[1] for b, _, _ in jobs); mmax = max(trips[b][0].shape[0] for b, _, _ in jobs)
+        A2 = np.zeros((len(jobs), mmax, dmax)); l2 = np.full((len(jobs), mmax), -INF); u2 = np.full((len(jobs), mmax), INF)
+        cost = np.zeros((len(jobs), dmax))
+        for k, (b, i, sg) in enumerate(jobs):
+            A, l, u = trips[b]
+            n, d = A.shape
+            A2[k, :n, :d] = A; l2[k, :n] = l; u2[k, :n] = u
+            cost[k, :d] = sg * A[i]
+        st, x, _ = _solve_lps(cost, A2, l2, u2, engine)
+        ext = {}
+        for k, (b, i, sg) in enumerate(jobs):
+            if st[k] == 1:
+                v = float(trips[b][0][i] @ x[k, :trips[b][0].shape[1]])
+            elif st[k] == 2:
+                v = -INF if sg > 0 else INF                     # unbounded in that direction (:691-693, :704-706)
+            else:
+                raise RuntimeError(f"implicit_bounds_batch: solver status {st[k]} on polyhedron {b}, row {i}")
+            ext[(b, i, sg)] = v
+        for b, (A, l, u) in enumerate(trips):
+            eq, vals = out[b]
+            for i in range(A.shape[0]):
+                if (b, i, 1.0) in ext:
+                    lo_, hi_ = ext[(b, i, 1.0)], ext[(b, i, -1.0)]
+                    eq[i] = bool(np.isfinite(lo_) and np.isfinite(hi_) and abs(lo_ - hi_) <= tol)
+                    if eq[i]:
+                        vals[i] = 0.5 * (hi_ + lo_)
+    return [(eq, vals) for eq, vals in out]

@@ -37,10 +37,13 @@ class Poly:
     keep the order they were given, so row indices are reproducible.
     """
 
-    def __init__(self, A, l, u, normalise=True, tol=1e-8):
+    def __init__(self, A, l, u, normalise=True, tol=1e-8, open_lo=None, open_hi=None):
         A = np.atleast_2d(np.asarray(A, dtype=np.float64)).copy()
         l = np.asarray(l, dtype=np.float64).copy()
         u = np.asarray(u, dtype=np.float64).copy()
+        # relations of the bounds (src/sets.jl:68-92: rl, ru in {<=, <}): True = strict.  Closed by default.
+        olo = np.zeros(l.shape, bool) if open_lo is None else np.asarray(open_lo, bool).copy()
+        ohi = np.zeros(u.shape, bool) if open_hi is None else np.asarray(open_hi, bool).copy()
         if A.size == 0:
             A = A.reshape(0, A.shape[-1] if A.ndim == 2 else 0)
         assert A.shape[0] == l.shape[0] == u.shape[0]
@@ -58,7 +61,9 @@ class Poly:
                 else:
                     A[i] = -a / nrm
                     l[i], u[i] = -u[i] / nrm, -l[i] / nrm
+                    olo[i], ohi[i] = ohi[i], olo[i]            # the relations swap with the bounds (:88)
         self.A, self.l, self.u = A, l, u
+        self.open_lo, self.open_hi = olo, ohi
 
     def __len__(self):
         return self.A.shape[0]
@@ -67,9 +72,15 @@ class Poly:
         """(A, l, u), src/sets.jl:213-221."""
         return self.A, self.l, self.u
 
+    def open_bounds(self):
+        """(open_low, open_hi), src/sets.jl:354-356: strict relations on FINITE bounds."""
+        return self.open_lo & np.isfinite(self.l), self.open_hi & np.isfinite(self.u)
+
     def contains(self, x, tol=1e-6):
-        ax = self.A @ x
-        return bool(np.all(self.l - tol <= ax) and np.all(ax - tol <= self.u))   # src/sets.jl:851-854
+        ax = self.A @ x                                                           # src/sets.jl:850-853: rl(l - tol, ax) && ru(ax - tol, u)
+        lo_ok = np.where(self.open_lo, self.l - tol < ax, self.l - tol <= ax)
+        hi_ok = np.where(self.open_hi, ax - tol < self.u, ax - tol <= self.u)
+        return bool(np.all(lo_ok) and np.all(hi_ok))
 
 
 @dataclass

@@ -143,3 +143,71 @@ def test_issubset_on_the_hip_engine(engine):
     g = polyhedra.issubset_batch(pairs, engine)
     c = polyhedra.issubset_batch(pairs, OracleEngine())
     assert np.array_equal(g, c) and np.array_equal(g, np.array([_subset_by_lp(a, b) for a, b in pairs]))
+
+
+# ---- F3 remainder: the reference's own exemplar rule, open bounds, implicit_bounds --------------------------------------
+def _lp(c, A, l, u):
+    rows, rhs = [], []
+    for i in range(A.shape[0]):
+        if np.isfinite(u[i]): rows.append(A[i]); rhs.append(u[i])
+        if np.isfinite(l[i]): rows.append(-A[i]); rhs.append(-l[i])
+    return linprog(c, A_ub=np.array(rows) if rows else None, b_ub=np.array(rhs) if rows else None,
+                   bounds=[(None, None)] * A.shape[1], method="highs")
+
+
+def _check_slack_and_implicit(engine, seed):
+    polys = _random_polys(seed, 40, dmax=5, mmax=8)
+    empty, example, eps = polyhedra.exemplar_slack_batch(polys, engine, tol=1e-4)
+    for (A, l, u), e, x, ep in zip(polys, empty, example, eps):
+        n, d = A.shape
+        # the same LP with HiGHS: min eps s.t. A x + eps >= l, -A x + eps >= -u, eps >= -1
+        A3 = np.vstack([np.hstack([A, np.ones((n, 1))]), np.hstack([-A, np.ones((n, 1))]), np.append(np.zeros(d), 1.0)[None]])
+        r = _lp(np.append(np.zeros(d), 1.0), A3, np.concatenate([l, -u, [-1.0]]), np.full(2 * n + 1, np.inf))
+        assert r.status == 0 and abs(r.x[-1] - ep) <= 1e-8
+        assert e == (ep > 1e-4)
+        if not e:
+            assert np.all(A @ x >= l - 2e-4) and np.all(A @ x <= u + 2e-4)
+    assert empty.any() and not empty.all()
+    assert np.array_equal(polyhedra.isempty_slack_batch(polys, engine), empty)
+    # implicit bounds on the non-empty ones: rows whose min and max over the set coincide
+    keep = [polys[b] for b in range(len(polys)) if not empty[b] and eps[b] < -1e-3][:12]
+    # add known structure: a row pinned by two others (x1 >= 1, x1 + x2 <= 1, x2 >= 0  =>  x1 = 1, x2 = 0, x1 + x2 = 1)
+    pinned = (np.array([[1.0, 0.0], [1.0, 1.0], [0.0, 1.0]]), np.array([1.0, -np.inf, 0.0]), np.array([np.inf, 1.0, np.inf]))
+    res = polyhedra.implicit_bounds_batch(keep + [pinned], engine)
+    for (A, l, u), (eq, vals) in zip(keep + [pinned], res):
+        for i in range(A.shape[0]):
+            lo = _lp(A[i], A, l, u); hi = _lp(-A[i], A, l, u)
+            vlo = -np.inf if lo.status == 3 else lo.fun; vhi = np.inf if hi.status == 3 else -hi.fun
+            want = bool(abs(l[i] - u[i]) <= 1e-4) or (np.isfinite(vlo) and np.isfinite(vhi) and abs(vlo - vhi) <= 1e-4)
+            assert eq[i] == want, (i, vlo, vhi)
+            if eq[i] and not abs(l[i] - u[i]) <= 1e-4:
+                assert abs(vals[i] - 0.5 * (vlo + vhi)) <= 1e-7
+    eqp, valp = res[-1]
+    assert list(eqp) == [True, True, True] and np.allclose(valp, [1.0, 1.0, 0.0], atol=1e-9)
+    with pytest.raises(RuntimeError):
+        polyhedra.implicit_bounds_batch([(np.array([[1.0]]), np.array([1.0]), np.array([0.0]))], engine)      # empty set
+
+
+def test_exemplar_rule_open_bounds_and_implicit_bounds_on_the_oracle_engine():
+    from oracle_engine import OracleEngine
+    eng = OracleEngine()
+    _check_slack_and_implicit(eng, 11)
+    # open bounds (src/sets.jl:68-92, :354-356): {0 < x <= 1} is non-empty, {0 < x <= 0} is empty, {0 <= x <= 0} is not;
+    # x = 0 is a member of the closed set only
+    P_open = Poly(np.array([[1.0]]), [0.0], [1.0], open_lo=[True])
+    P_point_open = Poly(np.array([[1.0]]), [0.0], [0.0], open_lo=[True])
+    P_point = Poly(np.array([[1.0]]), [0.0], [0.0])
+    assert not P_open.contains(np.array([-1e-6])) and P_open.contains(np.array([0.5])) and Poly(np.array([[1.0]]), [0.0], [1.0]).contains(np.array([-1e-6]))
+    e, ex, eps = polyhedra.exemplar_slack_batch([P_open, P_point_open, P_point,
+                                                 Poly(np.array([[1.0, 1.0], [1.0, -1.0]]), [0.0, 0.0], [0.0, 0.0], open_hi=[True, False])],
+                                                eng, tol=1e-4)
+    assert list(e) == [False, True, False, True]
+    assert abs(ex[0][0] - 0.5) <= 1e-9 and eps[0] == pytest.approx(-0.5)         # the slack-maximising member, not the minimum-norm one
+    # a negative leading coefficient flips the row and swaps the relations with the bounds (:83-88)
+    Pn = Poly(np.array([[-2.0]]), [-4.0], [2.0], open_lo=[True])
+    assert np.array_equal(Pn.A, [[1.0]]) and Pn.l[0] == -1.0 and Pn.u[0] == 2.0 and not Pn.open_lo[0] and Pn.open_hi[0]
+
+
+@pytest.mark.gpu
+def test_exemplar_rule_and_implicit_bounds_on_the_hip_engine(engine):
+    _check_slack_and_implicit(engine, 11)
