@@ -135,3 +135,31 @@ def process_qp(qpn, pid: int, x, S: Dict[int, list], engine=None, exploration_ve
         if len(S_out) == 0:
             raise RuntimeError("This shouldn't happen. Solution graph is empty.")
     return dict(solution=True, S=S_out, failed=False)
+
+
+def local_recipe_count(qpn, pid: int, x, S: Dict[int, list], engine=None):
+    """How many local pieces the node's solution graph has AT x: over every combination of the children's pieces for which
+    the node is optimal (src/qp_processing.jl:162-205), the number of recipes compatible with the active-set masks of the
+    node's own GAVI (process_solution_graph, src/avi.jl:447-477 -> comp_indices -> all_Ks, src/avi_solutions.jl:200-215):
+    each of them is a non-empty piece containing x (local_piece, :400-496).  A lower bound of what the reference's graph
+    enumeration collects (its pieces start from these and grow by exploration), computable on the hot path alone."""
+    from .avi import GAVI
+    from .avi_solutions import comp_indices
+    qp = qpn.qps[pid]
+    base = [qpn.constraints[c].poly for c in qp.constraint_indices]
+    dec = qpn.decision_inds(pid)
+    children = sorted(qpn.network_edges[pid])
+    combos = list(itertools.product(*[range(len(S[j])) for j in children])) if children else [()]
+    stacks = [base + [S[j][ji] for j, ji in zip(children, combo)] for combo in combos]
+    rets = verify_solutions_batched(qp, pid, stacks, dec, x, engine=engine)
+    total = 0
+    for cons, r in zip(stacks, rets):
+        if not r["solution"]:
+            continue
+        rec = node_record(qp, cons, dec, x)
+        n, m = len(dec), len(rec["l"])
+        g = GAVI(np.hstack([rec["Qd"], -rec["Ad"].T]), rec["R"], rec["qd"], np.full(n, -INF), np.full(n, INF),
+                 np.hstack([rec["Ad"], np.zeros((m, m))]), rec["B"], rec["l"], rec["u"])
+        mask = comp_indices(g, np.concatenate([rec["xd"], r["lam"]]), rec["w"], engine=engine)
+        total += int(np.prod([bin(int(v)).count("1") for v in mask]))
+    return total

@@ -13,11 +13,14 @@ def test_reference_end_to_end_cases_on_gpu(engine):
     """test/simple_bilevel.jl:17-21 through the C-ABI (BASELINE config 1 data, on the HIP path)."""
     from qpn_amd import algorithm, examples
     c = G.load("simple_bilevel_cases.json")
-    for w, xs in zip(c["w"], c["accepted_xy"]):
+    from qpn_amd.qp_processing import local_recipe_count
+    for w, xs, min_pieces in zip(c["w"], c["accepted_xy"], c["min_pieces_root_graph"]):
         net = examples.setup("simple_bilevel", gen_solution_map=True)
         ret = algorithm.solve(net, np.array(list(w) + c["x0"], float), engine=engine)
         assert ret["solved"], ret
         assert any(np.allclose(ret["x_opt"], list(w) + list(xy), atol=c["atol"]) for xy in xs), (w, ret["x_opt"])
+        # the path's counterpart of test/simple_bilevel.jl:20 (see tests/test_oracle_golden.py): local pieces of the root
+        assert local_recipe_count(net, 2, ret["x_opt"], ret["Sol"], engine=engine) >= min_pieces, w
 
 
 def test_outer_loops_match_oracle_backed_run(engine):
@@ -31,12 +34,12 @@ def test_outer_loops_match_oracle_backed_run(engine):
         assert np.max(np.abs(rg["x_opt"] - rc["x_opt"])) <= 1e-9
 
 
-def test_four_player_1000_draws_batched(engine, oracle):
-    """BASELINE config 3: 1 000 random payoff draws batched on 1 GPU, shared M (strideM = 0),
-    one Nash pool per draw (N_red = 16); equilibrium certified per draw by check_avi_solution."""
+def test_four_player_draws_host_mirror_batched(engine, oracle):
+    """Config 3 through the HOST mirror of combine_gavis (per-draw setup + combine_gavis_reduced, 100 draws), shared M
+    (strideM = 0), one Nash pool per draw (N_red = 16); equilibrium certified per draw by check_avi_solution."""
     from qpn_amd import avi, examples
     from qpn_amd.engine import colmajor
-    draws = 1000
+    draws = 100          # (the full 1 000-draw batch, assembled by ONE qpn_assemble_pools call: tests/test_gpu_pools.py)
     rng = np.random.Generator(np.random.Philox(key=[20240422, 3]))
     cs = rng.standard_normal((draws, 4, 4, 2))
     qs = []

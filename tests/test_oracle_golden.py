@@ -30,13 +30,20 @@ def test_reference_end_to_end_cases(oracle):
     from qpn_amd import algorithm, examples
     from oracle_engine import OracleEngine
     c = G.load("simple_bilevel_cases.json")
-    for w, xs in zip(c["w"], c["accepted_xy"]):
+    from qpn_amd.qp_processing import local_recipe_count
+    for w, xs, min_pieces in zip(c["w"], c["accepted_xy"], c["min_pieces_root_graph"]):
         net = examples.setup("simple_bilevel", gen_solution_map=True)
         ret = algorithm.solve(net, np.array(list(w) + c["x0"], float), engine=OracleEngine())
         assert ret["solved"], ret
         assert any(np.allclose(ret["x_opt"], list(w) + list(xy), atol=c["atol"]) for xy in xs), (w, ret["x_opt"])
         # follower's solution graph has the local pieces the reference derives
         assert 1 <= len(ret["Sol"][1]) <= 2
+        # The reference's second assertion, test/simple_bilevel.jl:20: length(collect(ret.Sol[2])) >= s -- the number of
+        # pieces its enumeration of the ROOT's solution graph collects.  That enumeration (vertex exploration + polyhedral
+        # projection, src/avi_solutions.jl rest) is outside the hot path; what the path itself yields is the number of
+        # local pieces of the root AT the equilibrium (one per recipe compatible with its active-set masks, over the child
+        # pieces for which it is optimal), which the reference's graph contains: it must reach the same lower bound.
+        assert local_recipe_count(net, 2, ret["x_opt"], ret["Sol"], engine=OracleEngine()) >= min_pieces, w
 
 
 def test_worked_trace_w_minus2_minus3(oracle):
