@@ -6,7 +6,8 @@
 #   solve_avi(avi::AVI, z0, w)                      src/avi.jl:63-77    (PATHSolver.solve_mcp + check)
 #   solve_qp(Q, q, A, l, u; solver=:PATH)           src/qp_processing.jl:12-33
 #
-# and adds a batched entry (solve_avi_batch) for many independent node-AVIs.
+# and adds batched entries: solve_avi_batch (many independent AVIs), solve_nodes! (a level of single-node pools), resident
+# node records (upload_nodes / solve_nodes!(nodes, ...) / verify_nodes), assemble_pool (combine_gavis) and local_pieces.
 #
 # Usage from the reference (one line in src/QuadraticProgramNetworks.jl after the includes):
 #     include(joinpath(ENV["QPN_HIP_HOME"], "julia", "QPNHip.jl")); using .QPNHip; QPNHip.install!()
@@ -121,6 +122,136 @@ function solve_nodes!(x::Union{Nothing,StridedMatrix{Float64}}, Qd::Array{Float6
         rc == 0 || error("qpn_solve_nodes_into failed ($rc)")
     end
     (z, status, resid, pivots, active)
+end
+
+# ---- resident node records: upload once, sweep many times (qpn_nodes_*, include/qpn_hip.h) ---------------------------
+const QPN_NODE_QD, QPN_NODE_R, QPN_NODE_Q, QPN_NODE_AD, QPN_NODE_B, QPN_NODE_L, QPN_NODE_U = Int32.(0:6)
+
+"""
+    nodes = upload_nodes(Qd, R, qd, Ad, B, l, u)      # arrays as in solve_nodes!; the library keeps its own copy in HBM
+    (z, status, resid, pivots, active) = solve_nodes!(nodes, x, w)       # one sweep: only w goes up, only outputs come down
+    (solution, lambda, path) = verify_nodes(nodes, xd, w)
+    update_nodes!(nodes, QPN_NODE_L, l_new); free_nodes!(nodes)
+
+The outer loop (src/algorithm.jl:13-117) sweeps the same nodes with new parameters every iteration: with the records
+resident the PCIe traffic per sweep is w in and the requested outputs out (`want_z = false` returns only the statuses and
+the primal blocks in `x`), instead of 22 KB per node in.  The handle also remembers whether any of its nodes needs the
+general (pivoting) kernel and keeps their longest-first schedule.
+"""
+mutable struct Nodes
+    h::Ptr{Cvoid}
+    batch::Int; n::Int; m::Int; p::Int
+end
+
+function upload_nodes(Qd::Array{Float64,3}, R::Array{Float64,3}, qd::Matrix{Float64}, Ad::Array{Float64,3}, B::Array{Float64,3},
+                      l::Matrix{Float64}, u::Matrix{Float64})
+    n, batch = size(qd); m = size(l, 1); p = size(R, 2)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:qpn_nodes_upload, LIB), Cint,
+               (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cdouble}, Cint, Ref{Ptr{Cvoid}}),
+               ctx(), Int32(batch), Int32(n), Int32(m), Int32(p), Qd, R, qd, Ad, B, l, u, QPN_MEM_HOST, h)
+    rc == 0 || error("qpn_nodes_upload failed ($rc)")
+    nodes = Nodes(h[], batch, n, m, p)
+    finalizer(free_nodes!, nodes)
+    nodes
+end
+
+function free_nodes!(nodes::Nodes)
+    nodes.h == C_NULL && return nothing
+    ccall((:qpn_nodes_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), nodes.h)
+    nodes.h = C_NULL
+    nothing
+end
+
+function update_nodes!(nodes::Nodes, field::Int32, data::Array{Float64})
+    rc = ccall((:qpn_nodes_update, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cdouble}, Cint), ctx(), nodes.h, field, data, QPN_MEM_HOST)
+    rc == 0 || error("qpn_nodes_update failed ($rc)")
+    nothing
+end
+
+function solve_nodes!(nodes::Nodes, x::Union{Nothing,StridedMatrix{Float64}}, w::VecOrMat{Float64}; want_z::Bool = true)
+    N = nodes.n + nodes.m; batch = nodes.batch
+    z = want_z ? zeros(N, batch) : nothing
+    status = zeros(Int32, batch); resid = zeros(batch); pivots = zeros(Int32, batch)
+    active = want_z ? zeros(UInt8, N, batch) : nothing
+    xp = x === nothing ? Ptr{Cdouble}(C_NULL) : pointer(x)
+    sx = x === nothing ? Int64(0) : Int64(stride(x, 2))
+    GC.@preserve x z active begin
+        rc = ccall((:qpn_solve_nodes_h, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{UInt8},
+                    Ptr{Cvoid}, Cint, Ptr{Cdouble}, Int64),
+                   ctx(), nodes.h, w, ndims(w) == 1 ? Int64(0) : Int64(nodes.p),
+                   want_z ? pointer(z) : Ptr{Cdouble}(C_NULL), status, resid, pivots, want_z ? pointer(active) : Ptr{UInt8}(C_NULL),
+                   C_NULL, QPN_MEM_HOST, xp, sx)
+        rc == 0 || error("qpn_solve_nodes_h failed ($rc)")
+    end
+    (z, status, resid, pivots, active)
+end
+
+function verify_nodes(nodes::Nodes, xd::Matrix{Float64}, w::VecOrMat{Float64}; tol::Float64 = 1e-4)
+    solution = zeros(Int32, nodes.batch); path = zeros(Int32, nodes.batch); lambda = zeros(max(nodes.m, 1), nodes.batch)
+    rc = ccall((:qpn_verify_nodes_h, LIB), Cint,
+               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Cdouble, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Cint),
+               ctx(), nodes.h, xd, w, ndims(w) == 1 ? Int64(0) : Int64(nodes.p), tol, solution, lambda, path, QPN_MEM_HOST)
+    rc == 0 || error("qpn_verify_nodes_h failed ($rc)")
+    (solution, lambda, path)
+end
+
+# ---- pool assembly (combine_gavis, src/avi.jl:305-377) and local pieces (local_piece, src/avi_solutions.jl:400-496) ----
+struct PoolShape          # qpn_pool_shape, include/qpn_hip.h
+    players::Int32
+    nd::Int32
+    p::Int32
+    n_i::Ptr{Int32}
+    m_i::Ptr{Int32}
+    dpos::Ptr{Int32}
+end
+const QPN_POOL_REDUCED = Cint(0)
+const QPN_POOL_REFERENCE = Cint(1)
+
+"""
+    (M, q, l, u, kind) = assemble_pool(n_i, m_i, dpos, nd, Qd, Qp, qd, Ad, Bp, lo, hi, w; form = QPN_POOL_REDUCED)
+
+One Nash pool (the players' blocks stacked in pool order, see include/qpn_hip.h; `dpos` 0-based positions in dec_inds) as
+the AVI `solve_avi_batch` takes: the device counterpart of `combine_gavis` (+ `convert` for `QPN_POOL_REFERENCE`).
+"""
+function assemble_pool(n_i::Vector{Int32}, m_i::Vector{Int32}, dpos::Vector{Int32}, nd::Integer, Qd::Matrix{Float64}, Qp::Matrix{Float64},
+                       qd::Vector{Float64}, Ad::Matrix{Float64}, Bp::Matrix{Float64}, lo::Vector{Float64}, hi::Vector{Float64},
+                       w::Vector{Float64}; form::Cint = QPN_POOL_REDUCED)
+    GC.@preserve n_i m_i dpos begin
+        shape = Ref(PoolShape(Int32(length(n_i)), Int32(nd), Int32(length(w)), pointer(n_i), pointer(m_i), pointer(dpos)))
+        Nr = Ref{Int32}(0)
+        ccall((:qpn_pool_size, LIB), Cint, (Ref{PoolShape}, Cint, Ref{Int32}), shape, form, Nr) == 0 || error("qpn_pool_size: bad shape")
+        N = Int(Nr[])
+        M = zeros(N, N); q = zeros(N); l = zeros(N); u = zeros(N); kind = zeros(UInt8, N)
+        rc = ccall((:qpn_assemble_pools, LIB), Cint,
+                   (Ptr{Cvoid}, Ref{PoolShape}, Cint, Int32, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Int64,
+                    Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Ptr{Cdouble},
+                    Ptr{Cdouble}, Ptr{UInt8}, Cint),
+                   ctx(), shape, form, Int32(1), Qd, 0, Qp, 0, qd, 0, Ad, 0, Bp, 0, lo, hi, 0, w, 0, M, Int64(N * N), q, l, u, kind, QPN_MEM_HOST)
+        rc == 0 || error("qpn_assemble_pools failed ($rc)")
+        return (M, q, l, u, kind)
+    end
+end
+
+"""
+    (Ap, lp, up, keep) = local_pieces(Qd, R, qd, Ad, B, l, u, K)
+
+`local_piece` (src/avi_solutions.jl:400-496, before `simplify`) for the recipes `K` ((n+m)×pieces UInt8 codes 1..8) of ONE
+node's GAVI (process_solution_graph, src/avi.jl:447-477): `Ap` is 2(n+m) × (n+m+p) × pieces over [x_d; λ; x_p].
+"""
+function local_pieces(Qd::Matrix{Float64}, R::Matrix{Float64}, qd::Vector{Float64}, Ad::Matrix{Float64}, B::Matrix{Float64},
+                      l::Vector{Float64}, u::Vector{Float64}, K::Matrix{UInt8})
+    n = length(qd); m = length(l); p = size(R, 2); N = n + m; pieces = size(K, 2)
+    Ap = zeros(2N, N + p, pieces); lp = zeros(2N, pieces); up = zeros(2N, pieces); keep = zeros(UInt8, 2N, pieces)
+    node_of = zeros(Int32, pieces)
+    rc = ccall((:qpn_local_pieces, LIB), Cint,
+               (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cdouble}, Ptr{Int32}, Ptr{UInt8}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Cint),
+               ctx(), Int32(pieces), Int32(1), Int32(n), Int32(m), Int32(p), Qd, R, qd, Ad, B, l, u, node_of, K, Ap, lp, up, keep, QPN_MEM_HOST)
+    rc == 0 || error("qpn_local_pieces failed ($rc)")
+    (Ap, lp, up, keep)
 end
 
 """

@@ -57,6 +57,9 @@ constexpr int WAVE = 64;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+// D = C - A B: on gfx950 the BLGP field of the fp64 MFMAs holds NEG modifiers (bit 0: A, bit 1: B, bit 2: C;
+// tools/mfma_neg_probe.hip), so an operand's sign costs no VALU instruction
+#define MFMA_NEGA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 1)
 
 // 8 tiles of the top half, named (no arrays: see qpn_avi_reg.hip)
 #define TL(I, J) tl_##I##_##J
@@ -80,6 +83,15 @@ __device__ __forceinline__ void wave_sync()
 // 4.6e-8; one Newton step brings it to <= 2.3e-15 relative (10 ulp), two give the correctly rounded quotient
 // (tools/rcp_probe.hip).  The pivoting arithmetic uses one step: its results are certified by the post-check
 // on the original blocks, and 1e-15 is far inside the 1e-9 parity bar.
+// max(a, |b|) in ONE instruction (fmax(a, fabs(b)) costs three: the compiler canonicalises both operands first; the
+// callers feed no NaNs that matter: a NaN entry fails the pivot test and the item goes to the general kernel)
+__device__ __forceinline__ double max_abs_nc(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double rcp64(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -251,8 +263,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
 #define M_LOADC(I, J, FULL)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq, ck = 16 * ((J) - 2) + lc;                             \
-        const double t_ = sA[rr * SAS + ck];                        /* C = -Ad' */                   \
-        TL(I, J)[g] = ((FULL) || (rr < n && ck < m)) ? -t_ : 0.0;                                   \
+        const double t_ = sA[rr * SAS + ck];        /* the tiles hold -C = +Ad': W~ = -W, signs folded in below */ \
+        TL(I, J)[g] = ((FULL) || (rr < n && ck < m)) ? t_ : 0.0;                                    \
     }
 #define M_NODE_LOAD(FULL)                                                                           \
     {                                                                                               \
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             const int cj = 2 * t + ch;                                                              \
             const double q_ = ((FULL) || (cj < nn && r5 < nn)) ? vq[t] : 0.0;                       \
             sA[cj * SQS + r5] = q_;                                                                 \
-            mabs = fmax(mabs, fabs(q_));                                                            \
+            mabs = max_abs_nc(mabs, q_);                                                            \
         }                                                                                           \
         wave_sync();                                                                                \
         M_LOADH(0, 0, FULL) M_LOADH(0, 1, FULL) M_LOADH(1, 0, FULL) M_LOADH(1, 1, FULL)             \
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             const int cj = 2 * t + ch;                                                              \
             const double a_ = ((FULL) || (cj < nn && r5 < nm)) ? va[t] : 0.0;                       \
             sA[cj * SAS + r5] = a_;                                                                 \
-            mabs = fmax(mabs, fabs(a_));                                                            \
+            mabs = max_abs_nc(mabs, a_);                                                            \
         }                                                                                           \
         wave_sync();                                                                                \
         M_LOADC(0, 2, FULL) M_LOADC(0, 3, FULL) M_LOADC(1, 2, FULL) M_LOADC(1, 3, FULL)             \
@@ -343,8 +355,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
            of the accumulator tile TL(IP, J) (else the compiler moves the whole tile out and back) */ \
         double vraw = TL(IP, J)[GP];                                                                \
         asm volatile("" : "+v"(vraw));      /* opaque: the copy itself is the compiler's (hazard-aware) */ \
-        TL(0, J) = MFMA(au0, vraw, TL(0, J));                                                       \
-        TL(1, J) = MFMA(au1, vraw, TL(1, J));                                                       \
+        TL(0, J) = MFMA_NEGA(au0, vraw, TL(0, J));                                                  \
+        TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));                                                  \
     }
 #define M_STEP(KB, JP, GP)                                                                          \
     if (!fail && 4 * (KB) < n) {       /* a block of padded rows is an identity pivot: nothing moves */ \
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 *reinterpret_cast<d4 *>(sU + l * 4) = up;                                           \
             }                                                                                       \
             wave_sync();                                                                            \
-            const double au0 = -sU[(0 + lc) * 4 + lq], au1 = -sU[(16 + lc) * 4 + lq];               \
+            const double au0 = sU[(0 + lc) * 4 + lq], au1 = sU[(16 + lc) * 4 + lq];    /* T -= U' V: NEG on A */ \
             if ((JP) <= 0) M_COLTILE(0, JP, GP)                                                     \
             if ((JP) <= 1) M_COLTILE(1, JP, GP)                                                     \
             M_COLTILE(2, JP, GP)                                                                    \
@@ -426,21 +438,23 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         M_LOADD(0, 0) M_LOADD(0, 1) M_LOADD(1, 0) M_LOADD(1, 1)
 #undef M_LOADD
     }
-    // A operand (16 x 4) of row tile Ib, k-block kk: element (i = lc, k = lq) = -A[16 Ib + lc][4 kk + lq]
+    // A operand (16 x 4) of row tile Ib, k-block kk: element (i = lc, k = lq) = A[16 Ib + lc][4 kk + lq].
+    // Node path: the tiles hold W~ = -W, so S = D - A W = D + A W~ (plain MFMA); M path: S = D - A W (NEG on A).
     auto aop = [&](int Ib, int kk) -> double {
         const int rk_ = 16 * Ib + lc, cj = 4 * kk + lq;
-        if constexpr (NODES) return -sA[cj * SAS + rk_];           // zeros outside m x n already
+        if constexpr (NODES) return sA[cj * SAS + rk_];            // zeros outside m x n already
         else {
             const bool valid = rk_ < m && cj < n;
             const double v = Mg[valid ? (size_t)cj * N + n + rk_ : 0];
-            return valid ? -v : 0.0;
+            return valid ? v : 0.0;
         }
     };
+#define M_SACC(a_, b_, c_) (NODES ? MFMA(a_, b_, c_) : MFMA_NEGA(a_, b_, c_))
 #define M_SK(I, g, kk)                                                                              \
     if (4 * (kk) < n) {                /* rows of W beyond n are zero */                             \
         const double a0_ = aop(0, kk), a1_ = aop(1, kk);                                            \
-        SB(0, 0) = MFMA(a0_, TL(I, 2)[g], SB(0, 0)); SB(0, 1) = MFMA(a0_, TL(I, 3)[g], SB(0, 1));   \
-        SB(1, 0) = MFMA(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = MFMA(a1_, TL(I, 3)[g], SB(1, 1));   \
+        SB(0, 0) = M_SACC(a0_, TL(I, 2)[g], SB(0, 0)); SB(0, 1) = M_SACC(a0_, TL(I, 3)[g], SB(0, 1)); \
+        SB(1, 0) = M_SACC(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = M_SACC(a1_, TL(I, 3)[g], SB(1, 1)); \
     }
     // bounds of pair l for Stage B: requested here so that the round trip hides behind the 32 MFMAs
     double lo_pre = -QINF, hi_pre = QINF;
@@ -449,6 +463,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     }
     M_SK(0, 0, 0) M_SK(0, 1, 1) M_SK(0, 2, 2) M_SK(0, 3, 3) M_SK(1, 0, 4) M_SK(1, 1, 5) M_SK(1, 2, 6) M_SK(1, 3, 7)
 #undef M_SK
+#undef M_SACC
     wave_sync();
     // c_k = b_k - sum_j A[k][j] h_j, lane k <-> pair k (k < m)
     double xb = 0.0;
@@ -888,7 +903,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     wave_sync();
     // item order: rows < n are x, rows n.. are lambda
     double zk = 0.0;
-    if (act) zk = l < n ? -(sz[l] + kx) : sval[NBP + (l - n)];
+    if (act) zk = l < n ? (NODES ? sz[l] - kx : -(sz[l] + kx)) : sval[NBP + (l - n)];      // node path: sz = W~ lambda = -W lambda
     wave_sync();
     if (act) sz[l] = zk;
     wave_sync();

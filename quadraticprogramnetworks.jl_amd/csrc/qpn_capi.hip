@@ -741,7 +741,10 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
         if (h) {
             // the handle's own longest-first schedule for the NEXT sweeps (launches that fill the GPU only)
             if (h->period > 0 && d.pv && batch > 4096) {
-                if (h->calls % h->period == 0) {
+                // every `period` sweeps while the smoothed counts settle (eight refreshes), every 4 x period afterwards: the
+                // refresh is a one-workgroup launch (14 us) that the next sweep waits for
+                const int32_t per = h->calls < 8 * h->period ? h->period : 4 * h->period;
+                if (h->calls % per == 0) {
                     HIPCHK(ctx, qpn_launch_order_by_pivots(d.pv, batch, h->order, s, h->key));
                     h->order_valid = true;
                 }

@@ -42,6 +42,26 @@ for sub in ("pmc_sq", "pmc_sq_b", "pmc_sq_c"):
     for r in rows(sub + "/runc/*counter_collection.csv"):
         if DOM in r["Kernel_Name"]: sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ[DOM + "_sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
+import subprocess
+try:
+    summ["commit"] = subprocess.check_output(["git", "-C", R, "rev-parse", "--short", "HEAD"]).decode().strip()
+except Exception:
+    pass
+if DOM in summ:
+    summ["avi_solve_hbm_bytes_per_launch"] = summ[DOM]["hbm_bytes_per_launch"]
+for extra in ("trace20", "trace5"):                       # the driver's own command; the config-5 line
+    st2 = rows(extra + "/runc/*kernel_stats.csv")
+    if st2:
+        with open(os.path.join(dst, f"{tag}_{extra}_kernel_stats.csv"), "w") as fh:
+            w = csv.writer(fh); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in st2:
+                w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+for lg in ("trace", "trace20", "trace5"):                 # the bench lines those traced runs printed themselves
+    f = os.path.join(src, lg + ".log")
+    if os.path.exists(f):
+        for line in open(f):
+            if line.startswith("{"):
+                open(os.path.join(dst, f"{tag}_{lg}_bench_line.json"), "w").write(line)
 json.dump(summ, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 if DOM in summ:
     json.dump({"avi_solve_hbm_bytes_per_launch": summ[DOM]["hbm_bytes_per_launch"], "kernel": DOM,
