@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         double lk, uk; int gk;
         row_bounds(lk, uk, gk);
         const bool isfree = act && !gk && lk == -QINF && uk == QINF;
-        const unsigned long long mfree = __ballot(isfree), mg = __ballot(act && gk);
+        const unsigned long long mfree = qpn_ballot(isfree), mg = qpn_ballot(act && gk);
         n = __popcll(mfree); m = __popcll(mg);
         const bool shape_ok = n + m == N && n <= 32 && m <= 32 && n >= 1 &&
                               mfree == ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) &&
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         else if (actb && it >= 0) { lo = a.l[vo + it]; hi = a.u[vo + it]; }
     }
     // equality GAVI rows need their multiplier crashed in: left to the general kernel
-    if (__ballot(actb && lo == hi)) { decline(); return; }
+    if (qpn_ballot(actb && lo == hi)) { decline(); return; }
     const double lo0 = lo, hi0 = hi;      // bounds of pair l (fixed); lo/hi follow the row's basic variable
     // class of pair l (0 bounded on at least one side, 2 free; equal bounds were sent to the general kernel
     // above) and its range, so that the per-pivot bookkeeping is integer / scalar work, not fp64 compares
@@ -600,15 +600,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         // ---- ratio test (same rule as the general kernel; reciprocal by Newton instead of a division)
         const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
         const double rc = rcp64(gdir);
-        const bool cndlo = actb && gdir < -ptol && lo > -QINF;
-        const bool cndhi = actb && gdir > ptol && hi < QINF;
-        const bool cnd = cndlo || cndhi;
-        const double arc = fabs(rc);                              // = cndlo ? -rc : rc on every candidate row
-        const double dd = (cndlo ? xb - lo : hi - xb) * arc;
+        // the bound the row's basic variable moves towards: lo when it decreases (gdir < 0), hi when it increases; a row is a
+        // candidate when that bound is finite and |gdir| is above the pivot tolerance.  (t - xb) * rc = |t - xb| * |rc|, both
+        // factors negated exactly: the same bits as the two-sided form, with one subtraction and two compares less
+        const bool gneg = __double2hiint(gdir) < 0;
+        const double tb = gneg ? lo : hi;
+        const bool cnd = actb && fabs(gdir) > ptol && fabs(tb) < QINF;
+        const double arc = fabs(rc);
+        const double dd = (tb - xb) * rc;
         const double d1 = fma(slack, arc, dd);
         const double dmax = min_f64_nc(wave_min32_all_lowlat_f64(cnd ? d1 : QINF), self_lim);      // uniform over lanes 0..31, in a VGPR
-        if (__ballot(actb && dmax == QINF) != 0ull) { status = QPN_RAY_TERM; break; }
-        const unsigned long long bal = __ballot(cnd && dd <= dmax);
+        if (qpn_ballot(actb && dmax == QINF) != 0ull) { status = QPN_RAY_TERM; break; }
+        const unsigned long long bal = qpn_ballot(cnd && dd <= dmax);
         // Both outcomes below end in the SAME exchange block (a bound flip runs it with v = 0 and empty lane
         // masks: a no-op), so the dictionary registers have one definition per iteration.
         double v0 = 0.0, v1 = 0.0, inv = 0.0;
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             if (l == 0) svrow[c] = -1.0;
             double step = readlane_f64(dd, r);
             if (step < 0.0) step = 0.0;
-            const double leave_val = readlane_f64(cndlo ? lo : hi, r);
+            const double leave_val = readlane_f64(tb, r);
             const double rcr = readlane_f64(rc, r);
             inv = sneg ? -rcr : rcr;
             const double delta = sneg ? -step : step;
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 double tcn = fma(-cm, vx, tc0);
                 if (l == r) { xbn = enter_val; tcn = -vx; }
                 xb = xbn; tcol = tcn;
-                mcol = __ballot(lc_now() == (c & 15)); mrow = __ballot(lq == rq);
+                mcol = qpn_ballot(lc_now() == (c & 15)); mrow = qpn_ballot(lq == rq);
                 cx = c;
             }
             STAMP(3);   // pivot row through LDS
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 if (vl < NBP) {
                     // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --:
                     // its multiplier d_k enters from 0
-                    au = (int)((__ballot(cndhi) >> r) & 1ull); kW = k; auW = au;
+                    au = rcr > 0.0 ? 1 : 0; kW = k; auW = au;      // (the pivot's sign: gdir_r > 0 <=> the row's variable left at hi)
                     vn = NBP + k;
                     sneg = au != 0;
                     self_lim = QINF;

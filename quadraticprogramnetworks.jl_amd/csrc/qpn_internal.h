@@ -309,10 +309,14 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// lane mask of a predicate.  HIP's __ballot(p) compares int(p) with 0: the compiler materialises the flag in a VGPR and
+// compares it again (v_cndmask + v_cmp_ne per ballot); the builtin takes the i1 as it is -- the compare that produced
+// the predicate IS the mask
+__device__ __forceinline__ unsigned long long qpn_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 // lowest lane whose predicate holds, or -1 (wave-uniform result)
 __device__ __forceinline__ int wave_first(bool pred)
 {
-    unsigned long long b = __ballot(pred);
+    unsigned long long b = qpn_ballot(pred);
     return b ? (__ffsll((long long)b) - 1) : -1;
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -148,8 +148,8 @@ class Engine:
         if not dev:
             Mc, q, l, u = (self._host(a, np.float64) for a in (Mc, q, l, u))
             kind = self._host(kind, np.uint8)
-        elif not all(t.is_contiguous() for t in (Mc, q, l, u)):
-            raise QpnError("device buffers must be contiguous")
+        else:
+            self._require_dev64(Mc, q, l, u, z0)
         batch, N = q.shape
         strideM = 0 if Mc.ndim == 2 else N * N
         sk = 0 if (kind is None or kind.ndim == 1) else N
@@ -203,6 +203,8 @@ class Engine:
         if not dev:
             Mc, q, l, u, z = (self._host(a, np.float64) for a in (Mc, q, l, u, z))
             kind = self._host(kind, np.uint8)
+        else:
+            self._require_dev64(Mc, q, l, u, z)
         batch, N = q.shape
         strideM = 0 if Mc.ndim == 2 else N * N
         sk = 0 if (kind is None or kind.ndim == 1) else N
@@ -220,6 +222,8 @@ class Engine:
         self._bind_stream(dev)
         if not dev:
             zv, rv, l, u = (self._host(a, np.float64) for a in (zv, rv, l, u))
+        else:
+            self._require_dev64(zv, rv, l, u)
         count = int(np.prod(zv.shape))
         mask = self._alloc(dev, tuple(zv.shape), np.uint8)
         rc = self.lib.qpn_comp_indices(self.ctx, count, _ptr(zv), _ptr(rv), _ptr(l), _ptr(u),
@@ -237,6 +241,8 @@ class Engine:
         self._bind_stream(dev)
         if not dev:
             Qc, Rc, qd, Ac, Bc, l, u, w = (self._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u, w))
+        else:
+            self._require_dev64(Qc, Rc, qd, Ac, Bc, l, u, w)
         batch, n = qd.shape
         m = l.shape[1]
         p = w.shape[-1]
