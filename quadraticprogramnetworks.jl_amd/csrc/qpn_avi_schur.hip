@@ -605,13 +605,15 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         // factors negated exactly: the same bits as the two-sided form, with one subtraction and two compares less
         const bool gneg = __double2hiint(gdir) < 0;
         const double tb = gneg ? lo : hi;
-        const bool cnd = actb && fabs(gdir) > ptol && fabs(tb) < QINF;
+        const bool cnd = (actb & (fabs(gdir) > ptol)) & (fabs(tb) < QINF);       // (no short circuit: three lane masks and two s_and)
         const double arc = fabs(rc);
-        const double dd = (tb - xb) * rc;
+        // the ratio of a row that is no candidate is +inf from here on (inf stays inf through the slack term), so neither the
+        // minimum nor the tie set needs the candidate flag again: the tie set is ONE compare
+        const double dd = cnd ? (tb - xb) * rc : QINF;
         const double d1 = fma(slack, arc, dd);
-        const double dmax = min_f64_nc(wave_min32_all_lowlat_f64(cnd ? d1 : QINF), self_lim);      // uniform over lanes 0..31, in a VGPR
-        if (qpn_ballot(actb && dmax == QINF) != 0ull) { status = QPN_RAY_TERM; break; }
-        const unsigned long long bal = qpn_ballot(cnd && dd <= dmax);
+        const double dmax = wave_min32_with_limit_f64(d1, self_lim);         // wave-uniform (an SGPR pair)
+        if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; break; }      // +inf: nothing blocks the ray
+        const unsigned long long bal = qpn_ballot(dd <= dmax);
         // Both outcomes below end in the SAME exchange block (a bound flip runs it with v = 0 and empty lane
         // masks: a no-op), so the dictionary registers have one definition per iteration.
         double v0 = 0.0, v1 = 0.0, inv = 0.0;
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             int r;
             if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
             else {
-                const bool cand = cnd && dd <= dmax;
+                const bool cand = dd <= dmax;
                 double ag = cand ? fabs(gdir) : -1.0;
                 if (cand && rowvar == VTH) ag = QINF;
                 const double bestg = wave_max_f64(ag);

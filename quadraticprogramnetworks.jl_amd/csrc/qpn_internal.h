@@ -297,6 +297,31 @@ __device__ __forceinline__ double wave_min32_all_lowlat_f64(double v)
     v = min_f64_nc(v, dpp_f64<0x140>(v));
     return min_f64_nc(readlane_f64(v, 0), readlane_f64(v, 16));
 }
+// min over lanes 0..31 of v and the wave-uniform `lim`, returned wave-uniform (it lands in an SGPR pair): four DPP row
+// stages, then row 0's minimum crosses into row 1 with row_bcast:15 (gfx9 DPP: lane 15 of a row to every lane of the next
+// one) and lane 31 is read out -- 2 DPP moves + 2 v_readlane for the crossing instead of 4 v_readlane + 4 v_mov; `lim`
+// rides in as one v_min with a scalar operand before the stages instead of a v_mov + v_min after them
+__device__ __forceinline__ double wave_min32_with_limit_f64(double v, double lim)
+{
+    {
+        const double ls = udbl(lim);
+        double r;
+        asm("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(v), "s"(ls));
+        v = r;
+    }
+    v = min_f64_nc(v, dpp_f64<0xB1>(v));
+    v = min_f64_nc(v, dpp_f64<0x4E>(v));
+    v = min_f64_nc(v, dpp_f64<0x141>(v));
+    v = min_f64_nc(v, dpp_f64<0x140>(v));
+    {
+        // rows 1 and 3 receive lane 15 of rows 0 and 2 (row_mask 0xa)
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_mov_dpp(lo, 0x142, 0xA, 0xF, false);      // (rows 0, 2 of the result are undefined: only lane 31 is read)
+        hi = __builtin_amdgcn_mov_dpp(hi, 0x142, 0xA, 0xF, false);
+        v = min_f64_nc(v, __hiloint2double(hi, lo));
+    }
+    return readlane_f64(v, 31);
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
 #pragma unroll
