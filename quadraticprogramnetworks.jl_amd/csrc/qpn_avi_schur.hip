@@ -664,8 +664,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
             }
             // the row's extra-column entry rides along as "column 32", and the entry of the pivot column itself is
             // replaced by -1 so that row * inv carries -inv there (what the exchange needs) without any select
-            if (l == r) svrow[XC] = tcol;
-            if (l == 0) svrow[c] = -1.0;
+            if (l == r) { svrow[XC] = tcol; svrow[c] = -1.0; }      // (one lane, program order after the owners' stores above)
             double step = readlane_f64(dd, r);
             if (step < 0.0) step = 0.0;
             const double leave_val = readlane_f64(tb, r);
@@ -687,7 +686,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 double tcn = fma(-cm, vx, tc0);
                 if (l == r) { xbn = enter_val; tcn = -vx; }
                 xb = xbn; tcol = tcn;
-                mcol = qpn_ballot(lc_now() == (c & 15)); mrow = qpn_ballot(lq == rq);
+                // the lanes of tile column c & 15 / of lane group rq, as scalar shifts (no compare)
+                mcol = 0x0001000100010001ull << (c & 15); mrow = 0xFFFFull << (16 * rq);
                 cx = c;
             }
             STAMP(3);   // pivot row through LDS
