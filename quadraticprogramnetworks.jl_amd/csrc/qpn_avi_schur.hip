@@ -704,7 +704,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 if (vl < NBP) {
                     // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --:
                     // its multiplier d_k enters from 0
-                    au = rcr > 0.0 ? 1 : 0; kW = k; auW = au;      // (the pivot's sign: gdir_r > 0 <=> the row's variable left at hi)
+                    au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0; kW = k; auW = au;      // (sign bit of the pivot, |pivot| > ptol: gdir_r > 0 <=> left at hi)
                     vn = NBP + k;
                     sneg = au != 0;
                     self_lim = QINF;
@@ -990,7 +990,9 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         nres = fabs(pp - tt);
         if (isnan(nres)) nres = QINF;
         const double ct = ae.comp_tol;
-        auto approx = [&](double x, double y) { return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= ct); };
+        // x == y, or both finite and within ct: an infinite operand makes |x - y| infinite (or NaN for inf - inf, which the
+        // first clause has already taken), so the finiteness tests of the scalar statement are implied
+        auto approx = [&](double x, double y) { return (x == y) | (fabs(x - y) <= ct); };
         if (!approx(lk, uk)) {
             if (approx(pp, lk) && dv >= -ct) mask |= 1u;
             if (lk - ct <= pp && pp <= uk + ct && fabs(dv) <= ct) mask |= 2u;
