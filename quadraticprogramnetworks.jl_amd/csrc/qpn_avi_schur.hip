@@ -333,6 +333,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     // extra column: g = q of the x rows, lane l <-> row l of the top half (lanes >= 32 idle)
     double kx;
     if constexpr (NODES) kx = (l < n) ? SQ(l) : 0.0; else kx = (l < n) ? qelem(l) : 0.0;
+    double *const sP = sbuf + 128;              // Stage A: the 4 x 4 pivot block of the current step, raw (the sz block is idle)
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
 
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         const int rr = 16 * (I) + 4 * g + lq;                                                       \
         double v = TL(I, JP)[g];                                                                    \
         /* row p0 + kcol sits in tile JP, register GP, lane group lq == kcol: a static test */      \
+        if ((I) == (JP) && g == (GP)) sP[lq * 4 + kcol] = v;        /* the pivot block itself, raw (16 lanes) */ \
         if ((I) == (JP) && g == (GP) && lq == kcol) v -= 1.0;                                       \
         sU[rr * 4 + kcol] = v;                                                                      \
     }
@@ -368,9 +370,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         /* P = L U (unit lower L, no pivoting; uniform, every lane) */                              \
         double pm[4][4];                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
-            const d4 row = *reinterpret_cast<const d4 *>(sU + (p0 + i) * 4);                        \
+            const d4 row = *reinterpret_cast<const d4 *>(sP + i * 4);                               \
             pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];             \
-            pm[i][i] += 1.0;                                                                        \
         }                                                                                           \
         const double x0 = readlane_f64(kx, p0), x1 = readlane_f64(kx, p0 + 1);                      \
         const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);                  \
@@ -872,10 +873,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         // rows j = 4 Ib + g a lane holds.  Folded butterfly: at each of the first three stages a lane gives
         // half of its values to its partner and adds the partner's other half, so 8 -> 4 -> 2 -> 1 values
         // (7 exchanges instead of 8 x 4); lane bits 0..2 of lc then name the row, bit 3 is summed last.
-        double p0 = TL(0, 2)[0] * lam0 + TL(0, 3)[0] * lam1, p1 = TL(0, 2)[1] * lam0 + TL(0, 3)[1] * lam1;
-        double p2 = TL(0, 2)[2] * lam0 + TL(0, 3)[2] * lam1, p3 = TL(0, 2)[3] * lam0 + TL(0, 3)[3] * lam1;
-        double p4 = TL(1, 2)[0] * lam0 + TL(1, 3)[0] * lam1, p5 = TL(1, 2)[1] * lam0 + TL(1, 3)[1] * lam1;
-        double p6 = TL(1, 2)[2] * lam0 + TL(1, 3)[2] * lam1, p7 = TL(1, 2)[3] * lam0 + TL(1, 3)[3] * lam1;
+        double p0 = fma(TL(0, 2)[0], lam0, TL(0, 3)[0] * lam1), p1 = fma(TL(0, 2)[1], lam0, TL(0, 3)[1] * lam1);
+        double p2 = fma(TL(0, 2)[2], lam0, TL(0, 3)[2] * lam1), p3 = fma(TL(0, 2)[3], lam0, TL(0, 3)[3] * lam1);
+        double p4 = fma(TL(1, 2)[0], lam0, TL(1, 3)[0] * lam1), p5 = fma(TL(1, 2)[1], lam0, TL(1, 3)[1] * lam1);
+        double p6 = fma(TL(1, 2)[2], lam0, TL(1, 3)[2] * lam1), p7 = fma(TL(1, 2)[3], lam0, TL(1, 3)[3] * lam1);
         // (the W tiles are dead from here on: their 32 registers take the 32 entries of Qd this lane needs for the
         // post-check, requested now so that the round trip hides behind the reduction and its LDS hops)
         __builtin_amdgcn_sched_barrier(0);
