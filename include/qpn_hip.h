@@ -197,9 +197,9 @@ int qpn_solve_nodes_into(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int3
  *                   the statuses are wanted.
  * The handle also keeps what depends on the records alone: whether any of its nodes needs the general
  * (pivoting) kernel -- decided by Qd, Ad, l, u, never by w -- so that sweeps over well-conditioned nodes are ONE
- * launch, and the longest-first schedule of its nodes (from exponentially smoothed pivot counts, refreshed from a sweep's
- * own counts every `period` sweeps at first and every 4 x `period` once settled, when `pivots` is requested;
- * qpn_nodes_set_schedule, period 0 = natural order).
+ * launch, and the longest-first schedule of its nodes (from exponentially smoothed pivot counts, which every sweep's
+ * solve kernel updates; the order is re-sorted from them every `period` sweeps at first and every 4 x `period` once
+ * settled; qpn_nodes_set_schedule, period 0 = natural order).
  * qpn_nodes_update replaces one array of the records (e.g. the bounds after a new child piece was chosen). */
 typedef struct qpn_nodes qpn_nodes;
 enum { QPN_NODE_QD = 0, QPN_NODE_R = 1, QPN_NODE_Q = 2, QPN_NODE_AD = 3, QPN_NODE_B = 4, QPN_NODE_L = 5, QPN_NODE_U = 6 };

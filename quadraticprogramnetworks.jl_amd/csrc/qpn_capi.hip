@@ -709,6 +709,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
     }
     if (mfma_shape) {
         // schedule hint (longest first): the handle's own, else the context's
+        if (h && h->period > 0 && batch > 4096) a.sched_key = h->key;      // every sweep feeds the smoothed counts
         if (h && h->order_valid) a.order = h->order;
         else if (ctx->order_count == batch && (!h || ctx->order_user)) a.order = ctx->order;     // a caller-installed order also serves handles
         bool need_general = true;
@@ -740,12 +741,13 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
         }
         if (h) {
             // the handle's own longest-first schedule for the NEXT sweeps (launches that fill the GPU only)
-            if (h->period > 0 && d.pv && batch > 4096) {
-                // every `period` sweeps while the smoothed counts settle (eight refreshes), every 4 x period afterwards: the
-                // refresh is a one-workgroup launch (14 us) that the next sweep waits for
+            if (h->period > 0 && batch > 4096) {
+                // the solve kernel keeps the smoothed counts up to date (every sweep); the order is re-sorted from them every
+                // `period` sweeps while they settle (eight refreshes), every 4 x period afterwards: the sort is a
+                // one-workgroup launch (14 us) that the next sweep waits for
                 const int32_t per = h->calls < 8 * h->period ? h->period : 4 * h->period;
                 if (h->calls % per == 0) {
-                    HIPCHK(ctx, qpn_launch_order_by_pivots(d.pv, batch, h->order, s, h->key));
+                    HIPCHK(ctx, qpn_launch_order_by_pivots(nullptr, batch, h->order, s, h->key));
                     h->order_valid = true;
                 }
                 h->calls++;

@@ -344,14 +344,15 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
     const int t = threadIdx.x;
     hist[t] = 0;
     __syncthreads();
+    // pivots == nullptr: the keys are kept up to date by the solve kernel itself (every sweep): sort by them as they are
     auto bin_of = [&](int i) -> int {
-        int p = pivots[i];
-        p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
+        int p = 0;
+        if (pivots) { p = pivots[i]; p = p < 0 ? 0 : (p > 1023 ? 1023 : p); }
         if (key) {
             const int k0 = key[i];
-            const int k1 = k0 > 0 ? k0 - (k0 >> 3) + 2 * p : 16 * p;
+            const int k1 = !pivots ? k0 : (k0 > 0 ? k0 - (k0 >> 3) + 2 * p : 16 * p);
             p = k1 >> 2;                                    // quarter pivots
-            p = p > 1023 ? 1023 : p;
+            p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
         }
         return 1023 - p;                                    // descending: bin 0 holds the largest counts
     };
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
     __syncthreads();
     for (int i = t; i < count; i += 1024) {
         order[atomicAdd(&hist[bin_of(i)], 1)] = i;
-        if (key) {
+        if (key && pivots) {
             int p = pivots[i];
             p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
             const int k0 = key[i];
