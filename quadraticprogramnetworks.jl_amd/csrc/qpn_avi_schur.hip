@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         if (ae.pivots) ae.pivots[b] = pivots;
         if constexpr (NODES) {
             int32_t *const sk = kp->sched_key;                                  // this node's smoothed pivot count
-            if (sk) { const int k0 = sk[b]; sk[b] = k0 > 0 ? k0 - (k0 >> 3) + 2 * pivots : 16 * pivots; }
+            if (sk) { const int k0 = sk[b]; sk[b] = k0 > 0 ? k0 - (k0 >> 5) + pivots : 32 * pivots; }
         }
     }
     STAMP(5);   // read-back + post-check + stores

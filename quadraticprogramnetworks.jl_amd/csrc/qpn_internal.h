@@ -59,8 +59,8 @@ struct AviBatchArgs {
     // fused node kernel only: counts the items it declines (status = -1), for callers that own the records and
     // want to know whether the general-kernel launch behind it has anything to do (qpn_nodes handles); may be null
     int32_t *decl_count;
-    // fused node kernel only: exponentially smoothed pivot count per node (units of 1/16 pivot), updated by every sweep
-    // (key <- key - key/8 + 2 pivots); the longest-first order of a resident-records handle is made from it.  May be null.
+    // fused node kernel only: exponentially smoothed pivot count per node (units of 1/32 pivot), updated by every sweep
+    // (key <- key - key/32 + pivots); the longest-first order of a resident-records handle is made from it.  May be null.
     int32_t *sched_key;
 };
 

@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void recipes_kernel(int32_t N, const uint8_t *
     }
 }
 
-// `key` (optional, [count] int32, zero at first): an exponentially smoothed pivot count per node in units of 1/16 pivot
-// (key <- key - key/8 + 2 p): between sweeps the parameters change and with them a node's pivot count, by about half of
+// `key` (optional, [count] int32, zero at first): an exponentially smoothed pivot count per node in units of 1/32 pivot
+// (key <- key - key/32 + p): between sweeps the parameters change and with them a node's pivot count, by about half of
 // the spread between nodes on the bench workload; ordering by the smoothed count is worth 2-3 % of the sweep there.
 __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pivots, int32_t count, int32_t *order, int32_t *key)
 {
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
         if (pivots) { p = pivots[i]; p = p < 0 ? 0 : (p > 1023 ? 1023 : p); }
         if (key) {
             const int k0 = key[i];
-            const int k1 = !pivots ? k0 : (k0 > 0 ? k0 - (k0 >> 3) + 2 * p : 16 * p);
-            p = k1 >> 2;                                    // quarter pivots
+            const int k1 = !pivots ? k0 : (k0 > 0 ? k0 - (k0 >> 5) + p : 32 * p);
+            p = k1 >> 3;                                    // quarter pivots (the key counts 1/32 pivots)
             p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
         }
         return 1023 - p;                                    // descending: bin 0 holds the largest counts
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(1024) void order_by_pivots_kernel(const int32_t *pi
             int p = pivots[i];
             p = p < 0 ? 0 : (p > 1023 ? 1023 : p);
             const int k0 = key[i];
-            key[i] = k0 > 0 ? k0 - (k0 >> 3) + 2 * p : 16 * p;
+            key[i] = k0 > 0 ? k0 - (k0 >> 5) + p : 32 * p;
         }
     }
 }
