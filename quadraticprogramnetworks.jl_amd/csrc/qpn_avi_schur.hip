@@ -766,7 +766,9 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         if (stop) break;
         // ---- the exchange on the 32 x 32 dictionary (see the header of this stage)
         {
-            const double nv0 = -v0, nv1 = -v1;
+            // (row r becomes -v: a multiplication by -1.0 inside the block, exact, instead of two negated copies kept ready;
+            //  1 / pivot goes in as the scalar it is)
+            const double inv_s = udbl(inv);
             cx = uni(cx); rsel = uni(rsel);
             asm volatile(
                 "v_fma_f64 %[s000], -%[u0], %[v0], %[s000]\n\tv_fma_f64 %[s001], -%[u1], %[v0], %[s001]\n\t"
@@ -797,18 +799,18 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                 "s_cmp_gt_i32 %[rs], 3\n\ts_cbranch_scc1 .Lqx_r4%=\n\t"
                 "s_cmp_gt_i32 %[rs], 1\n\ts_cbranch_scc1 .Lqx_r2%=\n\t"
                 "s_cmp_eq_u32 %[rs], 0\n\ts_cbranch_scc0 .Lqx_r1%=\n\t"
-                "v_mov_b64 %[s000], %[n0]\n\tv_mov_b64 %[s010], %[n1]\n\ts_branch .Lqx_end%=\n"
-                ".Lqx_r1%=:\n\tv_mov_b64 %[s001], %[n0]\n\tv_mov_b64 %[s011], %[n1]\n\ts_branch .Lqx_end%=\n"
+                "v_mul_f64 %[s000], %[v0], -1.0\n\tv_mul_f64 %[s010], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r1%=:\n\tv_mul_f64 %[s001], %[v0], -1.0\n\tv_mul_f64 %[s011], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
                 ".Lqx_r2%=:\n\ts_cmp_eq_u32 %[rs], 2\n\ts_cbranch_scc0 .Lqx_r3%=\n\t"
-                "v_mov_b64 %[s002], %[n0]\n\tv_mov_b64 %[s012], %[n1]\n\ts_branch .Lqx_end%=\n"
-                ".Lqx_r3%=:\n\tv_mov_b64 %[s003], %[n0]\n\tv_mov_b64 %[s013], %[n1]\n\ts_branch .Lqx_end%=\n"
+                "v_mul_f64 %[s002], %[v0], -1.0\n\tv_mul_f64 %[s012], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r3%=:\n\tv_mul_f64 %[s003], %[v0], -1.0\n\tv_mul_f64 %[s013], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
                 ".Lqx_r4%=:\n\ts_cmp_gt_i32 %[rs], 5\n\ts_cbranch_scc1 .Lqx_r6%=\n\t"
                 "s_cmp_eq_u32 %[rs], 4\n\ts_cbranch_scc0 .Lqx_r5%=\n\t"
-                "v_mov_b64 %[s100], %[n0]\n\tv_mov_b64 %[s110], %[n1]\n\ts_branch .Lqx_end%=\n"
-                ".Lqx_r5%=:\n\tv_mov_b64 %[s101], %[n0]\n\tv_mov_b64 %[s111], %[n1]\n\ts_branch .Lqx_end%=\n"
+                "v_mul_f64 %[s100], %[v0], -1.0\n\tv_mul_f64 %[s110], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r5%=:\n\tv_mul_f64 %[s101], %[v0], -1.0\n\tv_mul_f64 %[s111], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
                 ".Lqx_r6%=:\n\ts_cmp_eq_u32 %[rs], 6\n\ts_cbranch_scc0 .Lqx_r7%=\n\t"
-                "v_mov_b64 %[s102], %[n0]\n\tv_mov_b64 %[s112], %[n1]\n\ts_branch .Lqx_end%=\n"
-                ".Lqx_r7%=:\n\tv_mov_b64 %[s103], %[n0]\n\tv_mov_b64 %[s113], %[n1]\n"
+                "v_mul_f64 %[s102], %[v0], -1.0\n\tv_mul_f64 %[s112], %[v1], -1.0\n\ts_branch .Lqx_end%=\n"
+                ".Lqx_r7%=:\n\tv_mul_f64 %[s103], %[v0], -1.0\n\tv_mul_f64 %[s113], %[v1], -1.0\n"
                 ".Lqx_end%=:\n\t"
                 "s_mov_b64 exec, -1"
                 : [s000] "+v"(SD(0, 0, 0)), [s001] "+v"(SD(0, 0, 1)), [s002] "+v"(SD(0, 0, 2)), [s003] "+v"(SD(0, 0, 3)),
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
                   [s100] "+v"(SD(1, 0, 0)), [s101] "+v"(SD(1, 0, 1)), [s102] "+v"(SD(1, 0, 2)), [s103] "+v"(SD(1, 0, 3)),
                   [s110] "+v"(SD(1, 1, 0)), [s111] "+v"(SD(1, 1, 1)), [s112] "+v"(SD(1, 1, 2)), [s113] "+v"(SD(1, 1, 3))
                 : [u0] "v"(ua[0]), [u1] "v"(ua[1]), [u2] "v"(ua[2]), [u3] "v"(ua[3]), [u4] "v"(ub[0]), [u5] "v"(ub[1]),
-                  [u6] "v"(ub[2]), [u7] "v"(ub[3]), [v0] "v"(v0), [v1] "v"(v1), [n0] "v"(nv0), [n1] "v"(nv1), [iv] "v"(inv),
+                  [u6] "v"(ub[2]), [u7] "v"(ub[3]), [v0] "v"(v0), [v1] "v"(v1), [iv] "s"(inv_s),
                   [mcol] "s"(mcol), [mrow] "s"(mrow), [c] "s"(cx), [rs] "s"(rsel)
                 : "scc");
         }
