@@ -57,6 +57,7 @@ class Engine:
             raise QpnError(f"qpn_ctx_create({device}) failed: {self.lib.qpn_strerror(rc).decode()}")
         self.ctx = h
         self.use_torch_stream = use_torch_stream
+        self._bound = "own"                      # which stream the context launches on (a new context: its own)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -80,9 +81,13 @@ class Engine:
         # ordered with the kernels (cuda_stream == 0 is the legacy default stream, a real stream)
         if dev and self.use_torch_stream:
             s = torch.cuda.current_stream(self.device).cuda_stream
-            self.lib.qpn_ctx_set_stream(self.ctx, C.c_void_p(s))
+            if s != self._bound:                 # (the binding call is skipped while the stream stays what it was)
+                self.lib.qpn_ctx_set_stream(self.ctx, C.c_void_p(s))
+                self._bound = s
         elif not dev:
-            self.lib.qpn_ctx_use_own_stream(self.ctx)
+            if self._bound != "own":
+                self.lib.qpn_ctx_use_own_stream(self.ctx)
+                self._bound = "own"
 
     def synchronize(self):
         self._chk(self.lib.qpn_ctx_synchronize(self.ctx), "qpn_ctx_synchronize")
@@ -540,6 +545,7 @@ class Nodes:
                                       _ptr(Bc), _ptr(l), _ptr(u), MEM_DEVICE if dev else MEM_HOST, C.byref(h))
         eng._chk(rc, "qpn_nodes_upload")
         self.h = h
+        self._fast = None
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.eng, "ctx", None):
@@ -576,6 +582,15 @@ class Nodes:
         """One sweep over the resident nodes with parameters w ((p,) shared or (batch, p)); cold duals.  `want` names the
         optional outputs (status always comes back); x_out as in Engine.solve_nodes."""
         eng = self.eng
+        # the sweep loop's call (same output buffers as the previous sweep, device parameters): everything but w's address is
+        # what it was -- the checks and conversions below were done when these buffers were first seen
+        fast = self._fast
+        if fast is not None and out is fast[0] and x_out is fast[1] and opts is None and _is_dev(w) and w.dtype is torch.float64 \
+                and w.stride(-1) == 1:
+            eng._bind_stream(True)
+            rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, w.data_ptr(), 0 if w.ndim == 1 else w.stride(0), *fast[2])
+            eng._chk(rc, "qpn_solve_nodes_h")
+            return out
         dev = eng._mode(w, x_out)
         eng._bind_stream(dev)
         if not dev:
@@ -593,10 +608,12 @@ class Nodes:
                        pivots=eng._alloc(dev, (self.batch,), np.int32) if "pivots" in want else None,
                        active=eng._alloc(dev, (self.batch, N), np.uint8) if "active" in want else None)
         sx = eng._x_stride(x_out, dev, self.batch, self.n)
-        rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, _ptr(w), sw, _ptr(out["z"]), _ptr(out["status"]), _ptr(out["resid"]),
-                                       _ptr(out["pivots"]), _ptr(out["active"]), C.byref(o),
-                                       MEM_DEVICE if dev else MEM_HOST, _ptr(x_out), sx)
+        tail = (_ptr(out["z"]), _ptr(out["status"]), _ptr(out["resid"]), _ptr(out["pivots"]), _ptr(out["active"]), C.byref(o),
+                MEM_DEVICE if dev else MEM_HOST, _ptr(x_out), sx)
+        rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, _ptr(w), sw, *tail)
         eng._chk(rc, "qpn_solve_nodes_h")
+        if dev and opts is None:
+            self._fast = (out, x_out, tail, o)   # (o is kept alive: tail holds a reference to it)
         return out
 
     def verify(self, xd, w, tol=1e-4):
