@@ -684,7 +684,7 @@ void nodes_poll_declines(qpn_nodes *h)
 // general path (null only when h knows that no node declines).
 int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_t m, int32_t p, const NodeDev &d,
                        int64_t stride_w, const qpn_avi_opts &o, double *x_dev, int64_t stride_x, double *wM, double *wq,
-                       double *wl, double *wu, uint8_t *wk, double *wbig)
+                       double *wl, double *wu, uint8_t *wk, double *wbig, void *wmid)
 {
     hipStream_t s = ctx->stream;
     const int N = n + m;
@@ -763,6 +763,35 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
             }
             ctx->auto_calls++;
         }
+    } else if (wmid) {
+        // mid-size nodes (n, m <= 64): four wavefronts per node straight from the records (qpn_avi_schur_mid.hip); what it
+        // declines (status = -1) is assembled and solved by the general kernels in gated launches
+        bool need_general = true;
+        if (h) {
+            nodes_poll_declines(h);
+            need_general = h->decl_state != 2;
+            if (h->decl_state == 0) {
+                HIPCHK(ctx, hipMemsetAsync(h->decl_dev, 0, 4, s));
+                a.decl_count = h->decl_dev;
+            }
+        }
+        HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
+        if (need_general) {
+            if (!wM) return fail_arg(ctx, "qpn_solve_nodes: internal error (no workspace for the general path)");
+            HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
+                                                  wu, wk, s, d.st, -1));
+            AviBatchArgs g = a;
+            g.decl_count = nullptr;
+            g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
+            g.only_if = d.st; g.only_if_value = -1;
+            if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
+            else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
+        }
+        if (h && h->decl_state == 0) {
+            HIPCHK(ctx, hipMemcpyAsync(h->decl_host, h->decl_dev, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipEventRecord(h->decl_ev, s));
+            h->decl_state = 1;
+        }
     } else {
         HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
                                               wu, wk, s));
@@ -799,12 +828,18 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
     // the handle may already know that the general path has nothing to do: no workspace for it then
     nodes_poll_declines(h);
-    const bool need_ws = !(h && mfma_shape && h->decl_state == 2);
+    // mid-size nodes (QPN_NODES_MID=0: the route of the large nodes, for A/B runs)
+    const char *mid_env = getenv("QPN_NODES_MID");            // read per call: tests switch routes inside one process
+    const bool mid_off = mid_env && mid_env[0] == '0';
+    const bool mid_shape = !mid_off && qpn_schur_mid_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
+    const bool need_ws = !(h && (mfma_shape || mid_shape) && h->decl_state == 2);
 
     NodeDev d{Qd, R, qd, Ad, B, l, u, w, z, status, resid, pivots, active};
     double *wM = nullptr, *wq = nullptr, *wl = nullptr, *wu = nullptr, *wbig = nullptr; uint8_t *wk = nullptr;
+    void *wmid = nullptr;
     double *hQ, *hR, *hq, *hA, *hB, *hl, *hu, *hw, *hz = nullptr, *hres, *hx = nullptr; int32_t *hst, *hpv; uint8_t *hact;
     Carver cv(ctx);
+    if (mid_shape) cv.add(&wmid, qpn_schur_mid_workspace_bytes(batch, n, m));
     if (need_ws) {
         cv.add((void **)&wM, bN * N * 8); cv.add((void **)&wq, bN * 8); cv.add((void **)&wl, bN * 8);
         cv.add((void **)&wu, bN * 8); cv.add((void **)&wk, bN);
@@ -845,7 +880,7 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
 
     double *x_dev = host ? hx : x;
     const int64_t sx_dev = host ? (int64_t)n : stride_x;
-    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig);
+    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig, wmid);
     if (rc != QPN_OK) return rc;
     if (host) {
         if (z) HIPCHK(ctx, hipMemcpyAsync(z, d.z, bN * 8, hipMemcpyDeviceToHost, s));

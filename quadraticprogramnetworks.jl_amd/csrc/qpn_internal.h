@@ -94,6 +94,17 @@ hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBi
 hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
 hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream);
 
+// qpn_avi_schur_mid.hip: node records with n, m <= 64 (one of them > 32): four wavefronts per node, no assembled M
+struct SchurMidWs {
+    double *W, *S, *c, *lam, *gq;      // W~ column-major [m_pad][n_pad] then h [n_pad] (stride w_stride); S m x m; c, lam (m); q (n+m)
+    int32_t *st2, *piv2;
+    uint8_t *ones;
+    int64_t w_stride;
+};
+bool qpn_schur_mid_shape(int n, int m);
+size_t qpn_schur_mid_workspace_bytes(int batch, int n, int m);
+hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream_t stream);   // a.nd set; declined nodes keep status -1
+
 // qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
 hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,
                                       double *dbgh, hipStream_t stream);

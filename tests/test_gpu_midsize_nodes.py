@@ -1,0 +1,132 @@
+"""Mid-size node records (n, m <= 64, one of them > 32): the four-wavefronts-per-node path of
+csrc/qpn_avi_schur_mid.hip (crash on the matrix cores straight from the records, Schur problem on the register kernel,
+post-check from the records) against
+* the oracle (status, active-set masks bit-exact, primals within 1e-9 relative: the bar of DESIGN.md section 2),
+* the route these sizes took before (QPN_NODES_MID=0: assembled blocks + the workgroup crash of the large nodes): same
+  statuses and masks, primals within 1e-9 (summation order differs),
+* the independent check kernel on stand-alone assembled blocks (A3, src/avi.jl:148-156),
+and its decline handling: nodes whose leading 4 x 4 block of Qd fails the no-pivoting test, and nodes with an equality
+row, go to the general kernel inside the same call."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(seed, cnt, n, m, p):
+    from qpn_amd.engine import colmajor
+    Q, R, qd, A, B, l, u = P.synth_nodes(seed, cnt, n, m, max(p, 1))
+    rng = np.random.default_rng(seed)
+    if p == 0:
+        R = np.zeros((cnt, n, 0)); B = np.zeros((cnt, m, 0))
+    else:
+        R = R[:, :, :p]; B = rng.standard_normal((cnt, m, p)) * 0.1
+    return (Q, R, qd, A, B, l, u), [colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u]
+
+
+def _oracle(oracle, rec, w):
+    M, q, lo, hi, kind = P.reduced_blocks(*rec, w)
+    return oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+
+
+def _same(res, ref, tol=1e-9):
+    assert np.array_equal(np.asarray(res["status"]), ref["status"])
+    assert np.array_equal(np.asarray(res["active"]), ref["active"])
+    z, zr = np.asarray(res["z"]), ref["z"]
+    assert np.max(np.abs(z - zr)) <= tol * max(1.0, np.max(np.abs(zr)))
+
+
+SHAPES = [(33, 33, 8), (40, 50, 3), (48, 48, 8), (64, 64, 8), (64, 5, 2), (5, 64, 2), (40, 20, 4), (33, 1, 0), (17, 64, 8),
+          (64, 33, 1), (49, 31, 5)]
+
+
+@pytest.mark.parametrize("n,m,p", SHAPES)
+def test_mid_nodes_against_oracle_and_previous_route(engine, oracle, n, m, p):
+    cnt = 10
+    rec, abi = _records(900 + n + m, cnt, n, m, p)
+    w = np.random.default_rng(n).standard_normal(p)
+    res = engine.solve_nodes(*abi, w)
+    assert np.all(res["status"] == 1)
+    ref = _oracle(oracle, rec, w)
+    _same(res, ref)
+    os.environ["QPN_NODES_MID"] = "0"
+    try:
+        old = engine.solve_nodes(*abi, w)
+    finally:
+        del os.environ["QPN_NODES_MID"]
+    assert np.array_equal(res["status"], old["status"]) and np.array_equal(res["active"], old["active"])
+    assert np.max(np.abs(res["z"] - old["z"])) <= 1e-9 * max(1.0, np.max(np.abs(old["z"])))
+    assert np.max(res["resid"]) <= 1e-8
+    # independent certificate: check kernel on blocks from the stand-alone assembly kernel
+    Mc, q, lo, hi, kind = engine.assemble_nodes(*abi, w)
+    degree, _ = engine.check_avi_batch(Mc, q, lo, hi, res["z"], kind=kind, tol=1e-6)
+    assert int(np.asarray(degree).sum()) == 0
+
+
+def test_mid_nodes_per_node_parameters_handle_and_primal_blocks(engine, oracle):
+    n, m, p, cnt = 48, 40, 6, 40
+    rec, abi = _records(77, cnt, n, m, p)
+    W = np.random.default_rng(3).standard_normal((cnt, p))
+    ref = _oracle(oracle, rec, W)
+    nodes = engine.upload_nodes(*abi)
+    x = np.zeros((cnt, n + 3))
+    for sweep in range(3):                       # the handle learns after the first sweep that nothing declines
+        out = nodes.solve(W, x_out=x)
+        _same(out, ref)
+        assert np.array_equal(x[:, :n], out["z"][:, :n]) and np.all(x[:, n:] == 0)
+    info = nodes.info()
+    assert info["decline_state"] == 2 and info["declined"] == 0
+    per_call = engine.solve_nodes(*abi, W)
+    for k in ("z", "status", "resid", "pivots", "active"):
+        assert np.array_equal(out[k], per_call[k]), k
+    nodes.close()
+
+
+def test_mid_nodes_declines_go_to_the_general_kernel(engine, oracle):
+    n, m, p, cnt = 40, 36, 4, 12
+    rec, abi = _records(31, cnt, n, m, p)
+    Q, R, qd, A, B, l, u = [a.copy() for a in rec]
+    # node 2: a tiny leading pivot (the 4 x 4 block fails the no-pivoting test)
+    Qs = Q[2].copy(); Qs[0, 0] = 1e-9; Qs[0, 1:] *= 1e-3; Qs[1:, 0] *= 1e-3
+    Q[2] = 0.5 * (Qs + Qs.T) + np.diag([0.0] + [0.5] * (n - 1))
+    # node 7: an equality row
+    u[7, 4] = l[7, 4]
+    from qpn_amd.engine import colmajor
+    abi2 = [colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u]
+    w = np.random.default_rng(9).standard_normal(p)
+    res = engine.solve_nodes(*abi2, w)
+    ref = _oracle(oracle, (Q, R, qd, A, B, l, u), w)
+    _same(res, ref)
+    nodes = engine.upload_nodes(*abi2)
+    for sweep in range(3):
+        out = nodes.solve(w)
+        _same(out, ref)
+    info = nodes.info()
+    assert info["decline_state"] == 3 and info["declined"] == 2
+    nodes.close()
+
+
+def test_mid_nodes_device_buffers_and_shards(engine):
+    import torch
+    n, m, p, cnt = 64, 64, 8, 300
+    rec, abi = _records(5, cnt, n, m, p)
+    w = P.shared_params(p)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    dev = [t(a) for a in abi] + [t(w)]
+    x = torch.zeros((cnt, n), dtype=torch.float64, device="cuda:0")
+    res = engine.solve_nodes(*dev, x_out=x)
+    torch.cuda.synchronize()
+    host = engine.solve_nodes(*abi, w)
+    for k in ("z", "status", "active", "pivots"):
+        assert np.array_equal(res[k].cpu().numpy(), host[k]), k
+    assert np.all(host["status"] == 1) and np.array_equal(x.cpu().numpy(), host["z"][:, :n])
+    for lo_, hi_ in [(0, 7), (123, 300), (299, 300)]:          # node ranges solved alone give identical rows
+        part = [a[lo_:hi_] for a in dev[:-1]] + [dev[-1]]
+        r = engine.solve_nodes(*part)
+        torch.cuda.synchronize()
+        assert np.array_equal(r["z"].cpu().numpy(), host["z"][lo_:hi_])
+        assert np.array_equal(r["active"].cpu().numpy(), host["active"][lo_:hi_])
