@@ -163,8 +163,9 @@ int qpn_assemble_pools(qpn_ctx *ctx, const qpn_pool_shape *shape, int form, int3
  * identical results to calling the two in sequence, without materialising M in HBM: one pass of the
  * hot path per outer sweep (src/algorithm.jl:95 -> solve_qep -> src/avi.jl:399-409 for single-node
  * pools).  z: in z0 (ignored with QPN_AVI_FLAG_COLD_START), out solution.  n, m <= 32 run on the fused
- * matrix-core kernel; larger nodes (n+m <= 1024) are assembled and take the blocked matrix-core path for
- * large node-shaped items (n, m <= 512) or the general kernels. */
+ * matrix-core kernel (one wavefront per node); n, m <= 64 on the four-wavefronts-per-node path (crash on the
+ * matrix cores straight from the records, cold duals); larger nodes (n+m <= 1024) are assembled and take the
+ * blocked matrix-core path for large node-shaped items (n, m <= 512) or the general kernels. */
 int qpn_solve_nodes(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
                     const double *R, const double *qd, const double *Ad, const double *B,
                     const double *l, const double *u, const double *w, int64_t stride_w, double *z,
