@@ -280,6 +280,18 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
         prewarm_steps = PREWARM_STEPS
     for i in range(warmup):
         res = step()
+    if handle is not None and steps < 64 and prewarm:
+        # The handle re-sorts its longest-first schedule every 64 sweeps once settled (a 14 us launch = 0.2 % of the sweeps
+        # it serves).  A timed window shorter than that period would carry it either at 64/steps times its true share or not
+        # at all; a short window is therefore placed right behind a re-sort (same count on every rank: all handles have seen
+        # the same number of sweeps).  The extra untimed steps are part of "prewarm_steps"; the default K = 1000 carries
+        # the re-sorts at their true rate.
+        sw = handle.info()["sweeps"]
+        nxt = -(-sw // 64) * 64
+        if sw >= 128 and nxt < sw + steps:
+            for i in range(nxt - sw + 1):
+                res = step()
+            prewarm_steps += nxt - sw + 1
     barrier()
     if shared is not None:
         p2p_poll("warm-up")

@@ -880,6 +880,10 @@ hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream)
     if (a.N <= 8) hipLaunchKernelGGL(avi_solve_reg<1>, grid, block, 0, stream, a);
     else if (a.N <= 16) hipLaunchKernelGGL(avi_solve_reg<2>, grid, block, 0, stream, a);
     else if (a.N <= 32) hipLaunchKernelGGL(avi_solve_reg<4>, grid, block, 0, stream, a);
+    // sizes between the powers of two: fewer dictionary entries per lane (25 / 36 / 49 instead of 64) and a third wave per SIMD
+    else if (a.N <= 40) hipLaunchKernelGGL(avi_solve_reg<5>, grid, block, 0, stream, a);
+    else if (a.N <= 48) hipLaunchKernelGGL(avi_solve_reg<6>, grid, block, 0, stream, a);
+    else if (a.N <= 56) hipLaunchKernelGGL(avi_solve_reg<7>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(avi_solve_reg<8>, grid, block, 0, stream, a);
     return hipGetLastError();
 }

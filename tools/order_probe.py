@@ -49,6 +49,94 @@ def timed(label, fixed=False):
     return ms
 
 
+def planned_order(dur, P=4096, mode="closed"):
+    """Static plan (slot -> list of jobs, longest first inside a slot) from predicted durations, returned as the
+    dispatch order = jobs by planned start time.  closed: slots with q jobs take the largest items (snake pairs),
+    slots with q + 1 the rest in balanced groups; ffd: first-fit-decreasing into P bins of the smallest capacity
+    that works."""
+    B = len(dur)
+    desc = np.argsort(-dur, kind="stable")
+    a = dur[desc]
+    slots = [[] for _ in range(P)]
+    if mode == "closed":
+        q, r = divmod(B, P)
+        assert q == 2
+        k3, k2 = r, P - r
+        for j in range(k2):
+            slots[j] = [desc[j], desc[2 * k2 - 1 - j]]
+        c = desc[2 * k2:]
+        h2 = k3 // 2
+        for j in range(k3):
+            if j < h2: s_, t_ = k3 - 1 - 2 * j, j + h2
+            else: jp = j - h2; s_, t_ = k3 - 2 - 2 * jp, jp
+            s_ = min(max(s_, 0), k3 - 1); t_ = min(t_, k3 - 1)
+            slots[k2 + j] = [c[j], c[k3 + s_], c[2 * k3 + t_]]
+        used = np.zeros(B, bool)
+        for sl in slots:
+            for v in sl: used[v] = True
+        missing = list(np.nonzero(~used)[0])          # odd k3: the formulas may leave a few out / double: repair
+        seen = set(); fixed = []
+        for sl in slots:
+            out_ = []
+            for v in sl:
+                if v in seen: out_.append(missing.pop())
+                else: out_.append(v)
+                seen.add(out_[-1])
+            fixed.append(out_)
+        slots = fixed
+    else:
+        import bisect
+        lo_, hi_ = a.sum() / P, a.sum() / P * 1.5
+        def pack(T):
+            loads = []; bins = []
+            # first fit decreasing with a sorted list of (remaining capacity) is best-fit; use plain first-fit over open bins
+            rem = np.full(P, T); cnt_ = 0; res = [[] for _ in range(P)]
+            ptr = 0
+            for idx, d in zip(desc, a):
+                # first bin with rem >= d
+                cand = np.nonzero(rem[:max(cnt_, 1) + 1 if cnt_ < P else P] >= d)[0]
+                if len(cand) == 0: return None
+                b_ = cand[0]
+                if b_ >= P: return None
+                rem[b_] -= d; res[b_].append(idx); cnt_ = max(cnt_, b_ + 1)
+            return res
+        for _ in range(12):
+            mid_ = 0.5 * (lo_ + hi_)
+            r_ = pack(mid_)
+            if r_ is None: lo_ = mid_
+            else: hi_ = mid_; slots = r_
+    start = np.zeros(B); slot_of = np.zeros(B, int)
+    sums = []
+    for si, sl in enumerate(slots):
+        sl = sorted(sl, key=lambda v: -dur[v]); t_ = 0.0
+        for v in sl:
+            start[v] = t_; slot_of[v] = si; t_ += dur[v]
+        sums.append(t_)
+    sums = np.array(sums)
+    order = np.lexsort((slot_of, start)).astype(np.int32)
+    return order, sums
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "plan":
+    h.set_schedule(16)
+    timed("handle schedule: longest-first, refresh/16 (ring)")
+    timed("handle schedule: longest-first, refresh/16 (fixed w)", fixed=True)
+    h.set_schedule(0)
+    out = h.solve(ring[0], out=out, x_out=x); torch.cuda.synchronize()
+    piv0 = out["pivots"].cpu().numpy().astype(np.float64)
+    for c0 in (12.0, 20.0, 26.0):
+        for mode in ("closed", "ffd"):
+            order, sums = planned_order(piv0 - c0, mode=mode)
+            assert sorted(order.tolist()) == list(range(cnt))
+            eng.set_node_order(order)
+            timed(f"planned starts ({mode}, dur = piv - {c0:.0f}), exact counts, fixed w  [slot sums {sums.min():.0f}..{sums.max():.0f}]", fixed=True)
+            order, sums = planned_order(mean_piv - c0, mode=mode)
+            eng.set_node_order(order)
+            timed(f"planned starts ({mode}, dur = piv - {c0:.0f}), ring-mean counts, ring")
+    eng.set_node_order(np.argsort(-piv0, kind="stable").astype(np.int32))
+    timed("static longest-first, exact counts, fixed w", fixed=True)
+    sys.exit(0)
+
 h.set_schedule(0); eng.set_node_order(None)
 timed("natural order")
 timed("natural order, fixed w", fixed=True)

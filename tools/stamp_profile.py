@@ -11,7 +11,7 @@ csrc = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc")
 out = "/tmp/libqpn_hip_stamps.so"
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQPN_STAMPS", "-ffp-contract=off",
                        "-o", out] + [os.path.join(csrc, f) for f in
-                       ("qpn_capi.hip", "qpn_avi_solve.hip", "qpn_avi_reg.hip", "qpn_avi_big.hip", "qpn_avi_schur.hip", "qpn_avi_schur_big.hip", "qpn_kkt.hip", "qpn_verify.hip")])
+                       ("qpn_capi.hip", "qpn_avi_solve.hip", "qpn_avi_reg.hip", "qpn_avi_big.hip", "qpn_avi_schur.hip", "qpn_avi_schur_big.hip", "qpn_avi_schur_mid.hip", "qpn_kkt.hip", "qpn_verify.hip")])
 import numpy as np, torch
 import qpn_amd
 from qpn_amd import _lib, synthetic
