@@ -80,6 +80,9 @@ __host__ __device__ constexpr int mid_lds_doubles(int n, int n_pad, int m_pad)
     return OFF_BIG + big;
 }
 
+// TM: upper bound of the tile counts of a launch (n_pad / 16 and m_pad / 16 <= TM): the 48-class (TM = 3) carries neither the
+// registers nor the guards of the fourth tiles
+template <int TM>
 __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, SchurMidWs w)
 {
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -115,8 +118,9 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
 #define M_LOADC(J, T)                                                                               \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * v + 4 * g + lq, ck = 16 * (J) + lc;                                     \
-        const bool valid = rr < n && ck < m;                                                        \
-        const double t_ = A_[valid ? (size_t)rr * m + ck : 0];                                      \
+        const bool valid = (J) < TM && rr < n && ck < m;                                            \
+        double t_ = 0.0;                                                                            \
+        if ((J) < TM) t_ = A_[valid ? (size_t)rr * m + ck : 0];                                     \
         T[g] = valid ? t_ : 0.0;                                                                    \
     }
     M_LOADC(0, tc0) M_LOADC(1, tc1) M_LOADC(2, tc2) M_LOADC(3, tc3)
@@ -131,8 +135,9 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int j = v + 4 * t;
-            const bool ok = j < n && l < n;
-            const double t_ = Q_[ok ? (size_t)j * n + l : 0];
+            const bool ok = t < 4 * TM && j < n && l < n;
+            double t_ = 0.0;
+            if (t < 4 * TM) t_ = Q_[ok ? (size_t)j * n + l : 0];
             vq[t] = ok ? t_ : 0.0;
         }
 #pragma unroll
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
             const int j = v + 4 * t;
             mabs = fmax(mabs, fabs(vq[t]));
             if (j == l && l >= n) vq[t] = 1.0;
-            if (j < n_pad && l < n_pad) sQd[j * LDQ + l] = vq[t];
+            if (t < 4 * TM && j < n_pad && l < n_pad) sQd[j * LDQ + l] = vq[t];
         }
     }
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
     const d4 z4 = {0.0, 0.0, 0.0, 0.0};
 #define M_LOADH(J, T)                                                                               \
     T = z4;                                                                                         \
-    if (v < nht && (J) < nht) {                                                                     \
+    if ((J) < TM && v < nht && (J) < nht) {                                                         \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) T[g] = sQd[(16 * (J) + lc) * LDQ + 16 * v + 4 * g + lq]; \
     }
     M_LOADH(0, th0) M_LOADH(1, th1) M_LOADH(2, th2) M_LOADH(3, th3)
@@ -193,12 +198,12 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
 
     // ---- rank-4 block pivots ---------------------------------------------------------------------------------
     bool fail = false;
-#define M_PUB(J, T, GP) if ((J) < nht) sVp[lq * VLD + 16 * (J) + lc] = T[GP];
-#define M_PUBC(J, T, GP) if ((J) < mct) sVp[lq * VLD + 64 + 16 * (J) + lc] = T[GP];
-#define M_UPD(J, T) if ((J) < nht) { const double vr_ = sVp[lq * VLD + 16 * (J) + lc]; T = MFMA_NEGA(au, vr_, T); }
-#define M_UPDC(J, T) if ((J) < mct) { const double vr_ = sVp[lq * VLD + 64 + 16 * (J) + lc]; T = MFMA_NEGA(au, vr_, T); }
+#define M_PUB(J, T, GP) if ((J) < TM && (J) < nht) sVp[lq * VLD + 16 * (J) + lc] = T[GP];
+#define M_PUBC(J, T, GP) if ((J) < TM && (J) < mct) sVp[lq * VLD + 64 + 16 * (J) + lc] = T[GP];
+#define M_UPD(J, T) if ((J) < TM && (J) < nht) { const double vr_ = sVp[lq * VLD + 16 * (J) + lc]; T = MFMA_NEGA(au, vr_, T); }
+#define M_UPDC(J, T) if ((J) < TM && (J) < mct) { const double vr_ = sVp[lq * VLD + 64 + 16 * (J) + lc]; T = MFMA_NEGA(au, vr_, T); }
 #define M_STEP(KB, THJP)                                                                            \
-    if (!fail && 4 * (KB) < n) {                                                                    \
+    if ((KB) / 4 < TM && !fail && 4 * (KB) < n) {                                                   \
         constexpr int JP = (KB) / 4, GP = (KB) % 4, cq = 4 * GP, par = (KB) & 1;                    \
         double *const sVp = sV + par * 4 * VLD;                                                     \
         double *const sPp = sP + par * 16;              /* P^-1 transposed: [column][row] */          \
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
         const int r = 4 * kk + lq;                                  // k index: column of Ad, row of W~
-        const bool valid = v < mct && r < n && arow < m;
+        const bool valid = kk < 4 * TM && v < mct && r < n && arow < m;
         const double t_ = A_[valid ? (size_t)r * m + arow : 0];
         aop[kk] = valid ? t_ : 0.0;
     }
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
     double *const Wg = w.W + (size_t)b * (size_t)w.w_stride;       // W~ column-major [m_pad][n_pad], then h [n_pad]
     if (v < nht) {
 #define M_WOUT(J, T)                                                                                \
-    if ((J) < mct) {                                                                                \
+    if ((J) < TM && (J) < mct) {                                                                    \
         int jj = (J) + rot; if (jj >= mct) jj -= mct;                                               \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
             const int rr = 16 * v + 4 * g + lq;                                                     \
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
     __syncthreads();
     if (v < nht) {                  // the workspace copies drain behind the S product (no barrier after them)
 #define M_WOUT(J, T)                                                                                \
-    if ((J) < mct) {                                                                                \
+    if ((J) < TM && (J) < mct) {                                                                    \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                               \
             Wg[(size_t)(16 * (J) + lc) * n_pad + 16 * v + 4 * g + lq] = T[g];                       \
     }
@@ -348,21 +353,21 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
         if (j3 >= mct) j3 -= mct;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            if (4 * kk < n_pad) {
+            if (kk < 4 * TM && 4 * kk < n_pad) {
                 const int r = 4 * kk + lq;
                 const double a_ = aop[kk];
                 const double *wr = sW + r * m_pad + lc;
                 s0 = MFMA(a_, wr[16 * j0], s0);
                 if (mct > 1) s1 = MFMA(a_, wr[16 * j1], s1);
                 if (mct > 2) s2 = MFMA(a_, wr[16 * j2], s2);
-                if (mct > 3) s3 = MFMA(a_, wr[16 * j3], s3);
+                if (TM > 3 && mct > 3) s3 = MFMA(a_, wr[16 * j3], s3);
                 const double hb = lc == 0 ? sH[r] : 0.0;
                 sx = MFMA_NEGA(a_, hb, sx);
             }
         }
         double *Sg = w.S + (size_t)b * (size_t)m * m;
 #define M_SOUT(J, T)                                                                                \
-    if ((J) < mct) {                                                                                \
+    if ((J) < TM && (J) < mct) {                                                                    \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
             const int ri = 16 * v + 4 * g + lq, cj = 16 * (J) + lc;                                 \
             if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = T[g];                                   \
@@ -524,7 +529,8 @@ hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream
     w.ones = reinterpret_cast<uint8_t *>(ip);
     const size_t lds_a = (size_t)mid_lds_doubles(n, (int)n_pad, (int)m_pad) * sizeof(double);
     const size_t lds_f = (136 + (size_t)n * (size_t)(m | 1)) * sizeof(double);
-    hipLaunchKernelGGL(schur_mid_stage_a, dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
+    if (n_pad <= 48 && m_pad <= 48) hipLaunchKernelGGL(schur_mid_stage_a<3>, dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
+    else hipLaunchKernelGGL(schur_mid_stage_a<4>, dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     AviBatchArgs r{};
