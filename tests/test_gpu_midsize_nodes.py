@@ -130,3 +130,28 @@ def test_mid_nodes_device_buffers_and_shards(engine):
         torch.cuda.synchronize()
         assert np.array_equal(r["z"].cpu().numpy(), host["z"][lo_:hi_])
         assert np.array_equal(r["active"].cpu().numpy(), host["active"][lo_:hi_])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mid_nodes_mixed_bound_kinds_random_shapes(engine, oracle, seed):
+    """Random shapes of the class with one-sided, free and equal bounds mixed in (equal bounds send a node to the general
+    kernel inside the same call): everything against the oracle."""
+    from qpn_amd.engine import colmajor
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 65)); m = int(rng.integers(1, 65))
+    if max(n, m) <= 32:
+        n = 33 + seed
+    p = int(rng.integers(0, 7)); cnt = 8
+    rec, _ = _records(seed, cnt, n, m, p)
+    Q, R, qd, A, B, l, u = [a.copy() for a in rec]
+    kind = rng.integers(0, 6, size=l.shape)
+    l = np.where(kind == 1, -np.inf, l); u = np.where(kind == 2, np.inf, u)
+    l = np.where(kind == 3, -np.inf, l); u = np.where(kind == 3, np.inf, u)
+    eq = (kind == 4) & (rng.random(l.shape) < 0.1)
+    u = np.where(eq, l, u)
+    abi = [colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u]
+    w = rng.standard_normal(p)
+    res = engine.solve_nodes(*abi, w)
+    ref = _oracle(oracle, (Q, R, qd, A, B, l, u), w)
+    _same(res, ref)
+    assert np.max(res["resid"][res["status"] == 1], initial=0.0) <= 1e-8
