@@ -422,12 +422,19 @@ __global__ __launch_bounds__(TPF) void schur_mid_finish(AviBatchArgs a, SchurMid
     if (tid < n) {
         double s = -Wg[(size_t)m_pad * n_pad + tid];
         int k = 0;
-        for (; k + 8 <= m; k += 8) {
-            double wv[8];
+        for (; k + 16 <= m; k += 16) {                             // sixteen loads in flight (each batch is one round trip)
+            double wv[16];
 #pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) wv[q8] = Wg[(size_t)(k + q8) * n_pad + tid];
+            for (int q8 = 0; q8 < 16; ++q8) wv[q8] = Wg[(size_t)(k + q8) * n_pad + tid];
 #pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) s = fma(wv[q8], zs[n + k + q8], s);
+            for (int q8 = 0; q8 < 16; ++q8) s = fma(wv[q8], zs[n + k + q8], s);
+        }
+        for (; k + 4 <= m; k += 4) {
+            double wv[4];
+#pragma unroll
+            for (int q8 = 0; q8 < 4; ++q8) wv[q8] = Wg[(size_t)(k + q8) * n_pad + tid];
+#pragma unroll
+            for (int q8 = 0; q8 < 4; ++q8) s = fma(wv[q8], zs[n + k + q8], s);
         }
         for (; k < m; ++k) s = fma(Wg[(size_t)k * n_pad + tid], zs[n + k], s);
         zs[tid] = s;
@@ -442,12 +449,19 @@ __global__ __launch_bounds__(TPF) void schur_mid_finish(AviBatchArgs a, SchurMid
         // row k of [[Qd, -Ad'],[Ad, 0]] times z, columns ascending; a zero z_j contributes nothing (as in the general finish)
         if (!gk) {
             int j = 0;
-            for (; j + 8 <= n; j += 8) {
-                double mv[8];
+            for (; j + 16 <= n; j += 16) {
+                double mv[16];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = Q_[(size_t)(j + q8) * n + k];
+                for (int q8 = 0; q8 < 16; ++q8) mv[q8] = Q_[(size_t)(j + q8) * n + k];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) { const double zj = zs[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
+                for (int q8 = 0; q8 < 16; ++q8) { const double zj = zs[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
+            }
+            for (; j + 4 <= n; j += 4) {
+                double mv[4];
+#pragma unroll
+                for (int q8 = 0; q8 < 4; ++q8) mv[q8] = Q_[(size_t)(j + q8) * n + k];
+#pragma unroll
+                for (int q8 = 0; q8 < 4; ++q8) { const double zj = zs[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
             }
             for (; j < n; ++j) { const double zj = zs[j]; if (zj != 0.0) rk = fma(Q_[(size_t)j * n + k], zj, rk); }
             for (int i = 0; i < m; ++i) { const double zj = zs[n + i]; if (zj != 0.0) rk = fma(-sAd[k * LDA + i], zj, rk); }
