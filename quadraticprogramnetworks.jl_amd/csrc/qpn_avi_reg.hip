@@ -227,10 +227,25 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
 #define M_LOAD_FULL(k, l)                                                                       \
     if constexpr ((k) < BS && (l) < BS) E(k, l) = stage[(l) * NP + ra * PB + (k)];
     const bool full = N == WAVE && BS == 8;
+    const bool blocked = (a.flags & QPN_AVI_IFLAG_BLOCKED_M) != 0;        // wave-uniform
+    if (blocked) {
+        // the caller wrote M in this kernel's own register-block layout, lane fastest: entry (k, l) of lane's block at
+        // [(l BS + k) 64 + lane] -- every load instruction reads 512 consecutive bytes
+        const double *Sb = Mg + lane;
+#define M_LOADB(k, l)                                                                           \
+    if constexpr ((k) < BS && (l) < BS) {                                                       \
+        const double t_ = Sb[((l) * BS + (k)) * 64];                                            \
+        E(k, l) = (BS * ra + (k) < N && BS * cb + (l) < N) ? t_ : 0.0;                          \
+    }
+        QPN_FOR_KL(M_LOADB)
+#undef M_LOADB
+        mabs = 1.0;
+    } else {
     QPN_ISSUE(a, 0)
     QPN_ISSUE(b, 1)
     QPN_ROUND(a, 0) QPN_ROUND(b, 1) QPN_ROUND(a, 2) QPN_ROUND(b, 3)
     QPN_ROUND(a, 4) QPN_ROUND(b, 5) QPN_ROUND(a, 6) QPN_ROUND(b, 7)
+    }
 #undef M_LOAD_FULL
 #undef QPN_PUT_FULL
 #undef M_LOAD
@@ -738,6 +753,20 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
     __syncthreads();
     const double zk = act ? snb[gk ? N + lane : lane] : 0.0;
     __syncthreads();
+    if (blocked) {
+        // reduced problem of a caller that checks on its own original blocks: the point, the status and the pivot count
+        if (act) a.z[vo + lane] = zk;
+        if (lane == 0) {
+            a.status[b] = status;
+            if (a.pivots) a.pivots[b] = pivots;
+        }
+        STAMP(5);
+#ifdef QPN_STAMPS
+        if (a.stamps && lane == 0)
+            for (int i = 0; i < 8; ++i) a.stamps[(size_t)b * 8 + i] = stamp_acc[i];
+#endif
+        return;
+    }
     if (act) ucol[lane] = zk;   // z, broadcast source for the post-check mat-vec (NB <= NP)
     __syncthreads();
 
@@ -863,6 +892,11 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg_scan(AviBatchArgs a)
 }
 
 } // namespace
+
+int qpn_avi_reg_block_size(int N)
+{
+    return N <= 8 ? 1 : N <= 16 ? 2 : N <= 32 ? 4 : N <= 40 ? 5 : N <= 48 ? 6 : N <= 56 ? 7 : 8;
+}
 
 hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream)
 {

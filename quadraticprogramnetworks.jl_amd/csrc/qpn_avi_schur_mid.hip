@@ -82,7 +82,7 @@ __host__ __device__ constexpr int mid_lds_doubles(int n, int n_pad, int m_pad)
 
 // TM: upper bound of the tile counts of a launch (n_pad / 16 and m_pad / 16 <= TM): the 48-class (TM = 3) carries neither the
 // registers nor the guards of the fourth tiles
-template <int TM>
+template <int TM, bool BLK>
 __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, SchurMidWs w)
 {
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -365,12 +365,21 @@ __global__ __launch_bounds__(TPB, 4) void schur_mid_stage_a(AviBatchArgs a, Schu
                 sx = MFMA_NEGA(a_, hb, sx);
             }
         }
-        double *Sg = w.S + (size_t)b * (size_t)m * m;
+        double *Sg = w.S + (size_t)b * 4096;
+        // S for the Lemke kernel: its register-block layout [cj % bs][ri % bs][lane = 8 (ri / bs) + cj / bs] (s_bs > 0), else
+        // column-major; x / bs as a multiply-shift (x < 64)
+        const int sbs = BLK ? w.s_bs : 1;
+        const unsigned minv = (65536u + (unsigned)sbs - 1u) / (unsigned)sbs;
 #define M_SOUT(J, T)                                                                                \
     if ((J) < TM && (J) < mct) {                                                                    \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
             const int ri = 16 * v + 4 * g + lq, cj = 16 * (J) + lc;                                 \
-            if (ri < m && cj < m) Sg[(size_t)cj * m + ri] = T[g];                                   \
+            int ib_ = cj * m + ri;                                                                  \
+            if constexpr (BLK) {                                                                    \
+                const int rb_ = (int)(((unsigned)ri * minv) >> 16), cb_ = (int)(((unsigned)cj * minv) >> 16); \
+                ib_ = ((cj - cb_ * sbs) * sbs + (ri - rb_ * sbs)) * 64 + rb_ * 8 + cb_;            \
+            }                                                                                       \
+            if (ri < m && cj < m) Sg[ib_] = T[g];                                                   \
         }                                                                                           \
     }
         M_SOUT(0, s0) M_SOUT(1, s1) M_SOUT(2, s2) M_SOUT(3, s3)
@@ -422,12 +431,12 @@ __global__ __launch_bounds__(TPF) void schur_mid_finish(AviBatchArgs a, SchurMid
     if (tid < n) {
         double s = -Wg[(size_t)m_pad * n_pad + tid];
         int k = 0;
-        for (; k + 16 <= m; k += 16) {                             // sixteen loads in flight (each batch is one round trip)
-            double wv[16];
+        for (; k + 8 <= m; k += 8) {
+            double wv[8];
 #pragma unroll
-            for (int q8 = 0; q8 < 16; ++q8) wv[q8] = Wg[(size_t)(k + q8) * n_pad + tid];
+            for (int q8 = 0; q8 < 8; ++q8) wv[q8] = Wg[(size_t)(k + q8) * n_pad + tid];
 #pragma unroll
-            for (int q8 = 0; q8 < 16; ++q8) s = fma(wv[q8], zs[n + k + q8], s);
+            for (int q8 = 0; q8 < 8; ++q8) s = fma(wv[q8], zs[n + k + q8], s);
         }
         for (; k + 4 <= m; k += 4) {
             double wv[4];
@@ -449,12 +458,12 @@ __global__ __launch_bounds__(TPF) void schur_mid_finish(AviBatchArgs a, SchurMid
         // row k of [[Qd, -Ad'],[Ad, 0]] times z, columns ascending; a zero z_j contributes nothing (as in the general finish)
         if (!gk) {
             int j = 0;
-            for (; j + 16 <= n; j += 16) {
-                double mv[16];
+            for (; j + 8 <= n; j += 8) {
+                double mv[8];
 #pragma unroll
-                for (int q8 = 0; q8 < 16; ++q8) mv[q8] = Q_[(size_t)(j + q8) * n + k];
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = Q_[(size_t)(j + q8) * n + k];
 #pragma unroll
-                for (int q8 = 0; q8 < 16; ++q8) { const double zj = zs[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
+                for (int q8 = 0; q8 < 8; ++q8) { const double zj = zs[j + q8]; rk = (zj != 0.0) ? fma(mv[q8], zj, rk) : rk; }
             }
             for (; j + 4 <= n; j += 4) {
                 double mv[4];
@@ -520,7 +529,7 @@ bool qpn_schur_mid_shape(int n, int m)
 size_t qpn_schur_mid_workspace_bytes(int batch, int n, int m)
 {
     const size_t n_pad = (size_t)((n + 15) & ~15), m_pad = (size_t)((m + 15) & ~15);
-    const size_t per = n_pad * m_pad + n_pad + (size_t)m * m + 2 * (size_t)m + (size_t)(n + m);
+    const size_t per = n_pad * m_pad + n_pad + 4096 + 2 * (size_t)m + (size_t)(n + m);
     return (size_t)batch * per * sizeof(double) + (size_t)batch * 2 * sizeof(int32_t) + 512;
 }
 
@@ -534,7 +543,8 @@ hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream
     w.w_stride = (int64_t)(n_pad * m_pad + n_pad);
     double *p = static_cast<double *>(ws);
     w.W = p; p += (size_t)batch * w.w_stride;
-    w.S = p; p += (size_t)batch * m * m;
+    w.S = p; p += (size_t)batch * 4096;
+    w.s_bs = qpn_avi_reg_block_size(m) < 8 ? qpn_avi_reg_block_size(m) : 0;     // (the 8 x 8 class has its own full-width staged load)
     w.c = p; p += (size_t)batch * m;
     w.lam = p; p += (size_t)batch * m;
     w.gq = p; p += (size_t)batch * (n + m);
@@ -543,17 +553,20 @@ hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream
     w.ones = reinterpret_cast<uint8_t *>(ip);
     const size_t lds_a = (size_t)mid_lds_doubles(n, (int)n_pad, (int)m_pad) * sizeof(double);
     const size_t lds_f = (136 + (size_t)n * (size_t)(m | 1)) * sizeof(double);
-    if (n_pad <= 48 && m_pad <= 48) hipLaunchKernelGGL(schur_mid_stage_a<3>, dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
-    else hipLaunchKernelGGL(schur_mid_stage_a<4>, dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
+    const bool t3 = n_pad <= 48 && m_pad <= 48, blk = w.s_bs > 0;
+    if (t3 && blk) hipLaunchKernelGGL((schur_mid_stage_a<3, true>), dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
+    else if (t3) hipLaunchKernelGGL((schur_mid_stage_a<3, false>), dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
+    else if (blk) hipLaunchKernelGGL((schur_mid_stage_a<4, true>), dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
+    else hipLaunchKernelGGL((schur_mid_stage_a<4, false>), dim3((unsigned)batch), dim3(TPB), lds_a, stream, a, w);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     AviBatchArgs r{};
     r.batch = batch; r.N = m; r.vec_stride = m;
-    r.M = w.S; r.strideM = (int64_t)m * m; r.q = w.c; r.l = a.nd.l; r.u = a.nd.u; r.kind = w.ones; r.stride_kind = 0;
+    r.M = w.S; r.strideM = 4096; r.q = w.c; r.l = a.nd.l; r.u = a.nd.u; r.kind = w.ones; r.stride_kind = 0;
     r.z = w.lam; r.status = w.st2; r.pivots = w.piv2; r.resid = nullptr; r.active = nullptr;
     r.check_tol = a.check_tol; r.piv_tol = a.piv_tol; r.feas_tol = a.feas_tol; r.comp_tol = a.comp_tol;
     r.max_pivots = (a.max_pivots > 0 ? a.max_pivots : 50 * (n + m) + 100) - n;        // the crash pivots count
-    r.flags = a.flags | QPN_AVI_FLAG_COLD_START;
+    r.flags = a.flags | QPN_AVI_FLAG_COLD_START | (w.s_bs > 0 ? QPN_AVI_IFLAG_BLOCKED_M : 0);
     r.only_if = a.status; r.only_if_value = -2;
 #ifdef QPN_STAMPS
     if (getenv("QPN_MID_STAMP_REG")) r.stamps = a.stamps;          // diagnostic builds: the Lemke kernel's phases instead

@@ -217,7 +217,7 @@ int qpn_solve_avi_batch(qpn_ctx *ctx, int32_t batch, int32_t N, const double *M,
     a.batch = batch; a.N = N; a.strideM = strideM; a.stride_kind = kind ? stride_kind : 0;
     a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
     a.max_pivots = o.max_pivots;
-    a.flags = o.flags;
+    a.flags = o.flags & 0xFFFF;           // (the upper bits are internal: QPN_AVI_IFLAG_*)
 
     if (mem == QPN_MEM_DEVICE) {
         a.M = M; a.q = q; a.l = l; a.u = u; a.kind = kind; a.z = z; a.status = status;
@@ -691,7 +691,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
     AviBatchArgs a{};
     a.batch = batch; a.N = N; a.z = d.z; a.status = d.st; a.resid = d.res; a.pivots = d.pv; a.active = d.act;
     a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
-    a.max_pivots = o.max_pivots; a.flags = o.flags;
+    a.max_pivots = o.max_pivots; a.flags = o.flags & 0xFFFF;
     a.nd = NodeSrc{n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w};
 #ifdef QPN_STAMPS
     a.stamps = g_stamps;

@@ -14,6 +14,14 @@ struct NodeSrc {
     int64_t stride_w;
 };
 
+// internal flag bits of AviBatchArgs::flags (above the ABI's QPN_AVI_FLAG_*)
+// register kernel only: M is given in the register-block layout of avi_solve_reg<BS> -- lane fastest, [l][k][lane] with BS x BS
+// entries per lane, item stride strideM --, every row is a GAVI row, cold start; the kernel then loads its dictionary with
+// plain coalesced loads (no LDS staging), and returns z / status / pivots without the post-check (the caller checks on its
+// own original blocks)
+#define QPN_AVI_IFLAG_BLOCKED_M (1 << 16)
+int qpn_avi_reg_block_size(int N);      // BS of the instantiation qpn_launch_avi_solve_reg picks for size N
+
 struct AviBatchArgs {
     int32_t batch;
     int32_t N;
@@ -100,6 +108,7 @@ struct SchurMidWs {
     int32_t *st2, *piv2;
     uint8_t *ones;
     int64_t w_stride;
+    int32_t s_bs;            // > 0: S in the register-block layout of avi_solve_reg<s_bs> (stride 4096 doubles per node)
 };
 bool qpn_schur_mid_shape(int n, int m);
 size_t qpn_schur_mid_workspace_bytes(int batch, int n, int m);
