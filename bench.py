@@ -300,21 +300,27 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
             for i in range(min(warmup, 5)):
                 res = step()
             barrier()
-    # ONE pair of HIP events brackets the whole timed region on the launch stream (a pair per step costs two barrier packets
-    # per step, ~10 us of pipeline bubbles -- measured); the per-launch duration reported in "roofline" is elapsed / steps,
-    # i.e. it also carries the launch gaps, the schedule refresh every 16th step (and, for N > 1, the exchange): an upper
-    # bound of the solve kernel's own duration.
+    # HIP events on the launch stream bracket the timed region (a pair per step costs two barrier packets per step, ~10 us of
+    # pipeline bubbles -- measured): ev0 before the first step, evm behind the first step, ev1 behind the last.  `value` is the
+    # wall clock over all K steps.  The per-launch duration reported in "roofline" is (ev1 - evm) / (K - 1): the launches that
+    # run back to back -- the first launch of the region starts on a GPU the synchronize() before it left idle, behind the
+    # host's launch latency, and that gap is not the kernel's.  It still carries the launch gaps, the schedule refreshes (and,
+    # for N > 1, the exchange): an upper bound of the solve kernel's own duration.  ("kernel_ms_all" = (ev1 - ev0) / K.)
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    evm = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(steps):
         res = step()
+        if i == 0:
+            evm.record()
         if shared is not None and i % REFRESH == REFRESH - 1:
             p2p_poll("timed region")
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / max(steps, 1)
+    kern_ms_all = ev0.elapsed_time(ev1) / max(steps, 1)
+    kern_ms = evm.elapsed_time(ev1) / (steps - 1) if steps >= 2 else kern_ms_all
 
     sweep_ok = shared is None or float(shared.out[3]) == 0.0        # no barrier of the timed region was missed
     solved_local = int((res["status"] == 1).sum().item()) if sweep_ok else 0      # a missed barrier voids the run
@@ -361,6 +367,7 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "kernel": "avi_solve_schur<nodes>" if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
+                     "kernel_ms_all": kern_ms_all, "launches_averaged": max(steps - 1, 1),
                      "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt} | committed_counters(),
     }
     if with_cpu and rank == 0:
