@@ -606,7 +606,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         // factors negated exactly: the same bits as the two-sided form, with one subtraction and two compares less
         const bool gneg = __double2hiint(gdir) < 0;
         const double tb = gneg ? lo : hi;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
         const bool cnd = (actb & (fabs(gdir) > ptol)) & (fabs(tb) < QINF);       // (no short circuit: three lane masks and two s_and)
+#pragma clang diagnostic pop
         const double arc = fabs(rc);
         // the ratio of a row that is no candidate is +inf from here on (inf stays inf through the slack term), so neither the
         // minimum nor the tie set needs the candidate flag again: the tie set is ONE compare
