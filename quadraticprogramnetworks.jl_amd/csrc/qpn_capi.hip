@@ -709,7 +709,10 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
     }
     if (mfma_shape) {
         // schedule hint (longest first): the handle's own, else the context's
-        if (h && h->period > 0 && batch > 4096) a.sched_key = h->key;      // every sweep feeds the smoothed counts
+        // the smoothed counts are fed by every sweep while the schedule settles (128 sweeps), by every fourth one afterwards:
+        // a sample of the sweeps tells the order as well, and the solve kernel's read-modify-write of its node's key is
+        // 0.5 % of the sweep
+        if (h && h->period > 0 && batch > 4096 && (h->calls < 128 || (h->calls & 3) == 0)) a.sched_key = h->key;
         if (h && h->order_valid) a.order = h->order;
         else if (ctx->order_count == batch && (!h || ctx->order_user)) a.order = ctx->order;     // a caller-installed order also serves handles
         bool need_general = true;
