@@ -155,3 +155,39 @@ def test_mid_nodes_mixed_bound_kinds_random_shapes(engine, oracle, seed):
     ref = _oracle(oracle, (Q, R, qd, A, B, l, u), w)
     _same(res, ref)
     assert np.max(res["resid"][res["status"] == 1], initial=0.0) <= 1e-8
+
+
+def test_mid_nodes_full_batch_properties(engine, oracle):
+    """4 000 nodes of n = m = 48 (the size the mid-size probe quotes): every node solved and certified by the independent
+    check kernel on stand-alone assembled blocks, multipliers only on rows at a bound, resident-records route == per-call
+    route bit for bit, a seeded subset against the oracle."""
+    import torch
+    n, m, p, cnt = 48, 48, 8, 4000
+    rec, abi = _records(4848, cnt, n, m, p)
+    w = P.shared_params(p)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    dev = [t(a) for a in abi] + [t(w)]
+    res = engine.solve_nodes(*dev)
+    torch.cuda.synchronize()
+    host = {k: v.cpu().numpy() for k, v in res.items()}
+    assert np.all(host["status"] == 1) and np.max(host["resid"]) <= 1e-8
+    Mc, q, lo, hi, kind = engine.assemble_nodes(*dev)
+    degree, r = engine.check_avi_batch(Mc, q, lo, hi, res["z"], kind=kind, tol=1e-6)
+    torch.cuda.synchronize()
+    assert int(degree.sum().item()) == 0
+    lam = host["z"][:, n:]; s = r.cpu().numpy()[:, n:]
+    l, u = rec[5], rec[6]
+    at_bound = (np.abs(s - l) <= 1e-6) | (np.abs(s - u) <= 1e-6)
+    assert np.all(at_bound[np.abs(lam) > 1e-9])
+    nodes = engine.upload_nodes(*dev[:-1])
+    for sweep in range(2):
+        out = nodes.solve(dev[-1])
+        torch.cuda.synchronize()
+    for k in ("z", "status", "active", "pivots"):
+        assert np.array_equal(out[k].cpu().numpy(), host[k]), k
+    assert nodes.info()["decline_state"] == 2
+    nodes.close()
+    idx = np.sort(np.random.default_rng(1).choice(cnt, 40, replace=False))
+    ref = _oracle(oracle, tuple(a[idx] for a in rec), w)
+    assert np.array_equal(host["status"][idx], ref["status"]) and np.array_equal(host["active"][idx], ref["active"])
+    assert np.max(np.abs(host["z"][idx] - ref["z"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["z"])))
