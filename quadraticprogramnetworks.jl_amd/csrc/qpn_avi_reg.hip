@@ -83,7 +83,9 @@ __device__ __forceinline__ void interval_uni(int v, int N, const double *sl, con
 }
 
 // One item, one wavefront (the whole kernel body; see avi_solve_reg below for how items are picked).
-template <int BS>
+// LEAN: the reduced problems of the mid-size node path (QPN_AVI_IFLAG_BLOCKED_M: every row a GAVI row with l < u, cold start,
+// M in the register-block layout) -- no crash stage, no staged load, no post-check: compiled out, not branched around
+template <int BS, bool LEAN = false>
 __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const int b)
 {
     using G = Geo<BS>;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
 #define M_LOAD_FULL(k, l)                                                                       \
     if constexpr ((k) < BS && (l) < BS) E(k, l) = stage[(l) * NP + ra * PB + (k)];
     const bool full = N == WAVE && BS == 8;
-    const bool blocked = (a.flags & QPN_AVI_IFLAG_BLOCKED_M) != 0;        // wave-uniform
+    const bool blocked = LEAN || (a.flags & QPN_AVI_IFLAG_BLOCKED_M) != 0;        // wave-uniform
     if (blocked) {
         // the caller wrote M in this kernel's own register-block layout, lane fastest: entry (k, l) of lane's block at
         // [(l BS + k) 64 + lane] -- every load instruction reads 512 consecutive bytes
@@ -289,7 +291,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
     // general loop below, which takes over at the first variable that does not qualify.
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
-    bool fast_ok = true;
+    bool fast_ok = !LEAN;
     int pivots_blk = 0;
     // ---- blocked variant (BS = 8): four consecutive diagonal crash pivots e0..e0+3 per step -----
     // The 4 pivot columns / rows are copied to LDS once; the 64 row/column lanes run the sequential
@@ -844,12 +846,12 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
 }
 
 // Item selection.  Plain kernel: block b solves item b (optionally gated on only_if[b]).
-template <int BS>
+template <int BS, bool LEAN = false>
 __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg(AviBatchArgs a)
 {
     const int b = blockIdx.x;
     if (a.only_if && a.only_if[b] != a.only_if_value) return;   // wave-uniform gate
-    avi_solve_reg_item<BS>(a, b);
+    avi_solve_reg_item<BS, LEAN>(a, b);
 }
 
 // Scan kernel (a.scan): the grid is small and fixed; block g looks at items g, g + G, g + 2G, ... (64 at
@@ -911,6 +913,18 @@ hipError_t qpn_launch_avi_solve_reg(const AviBatchArgs &a, hipStream_t stream)
         return hipGetLastError();
     }
     const dim3 grid((unsigned)a.batch);
+    if (a.flags & QPN_AVI_IFLAG_BLOCKED_M) {               // reduced problems of the mid-size node path: the lean instantiations
+        switch (qpn_avi_reg_block_size(a.N)) {
+        case 1: hipLaunchKernelGGL((avi_solve_reg<1, true>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((avi_solve_reg<2, true>), grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((avi_solve_reg<4, true>), grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((avi_solve_reg<5, true>), grid, block, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL((avi_solve_reg<6, true>), grid, block, 0, stream, a); break;
+        case 7: hipLaunchKernelGGL((avi_solve_reg<7, true>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((avi_solve_reg<8, true>), grid, block, 0, stream, a); break;
+        }
+        return hipGetLastError();
+    }
     if (a.N <= 8) hipLaunchKernelGGL(avi_solve_reg<1>, grid, block, 0, stream, a);
     else if (a.N <= 16) hipLaunchKernelGGL(avi_solve_reg<2>, grid, block, 0, stream, a);
     else if (a.N <= 32) hipLaunchKernelGGL(avi_solve_reg<4>, grid, block, 0, stream, a);
