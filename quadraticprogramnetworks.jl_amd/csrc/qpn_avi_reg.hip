@@ -37,6 +37,16 @@ constexpr int WAVE = 64;
 #define STAMP(slot) do { } while (0)
 #endif
 
+// Every workgroup of this file is ONE wavefront: LDS operations of a wave execute in issue order, so ordering between a
+// lane's store and another lane's load needs no s_barrier and no drain of the memory counters -- only that the compiler
+// keeps the program order of the LDS accesses and does not move them across this point (as in qpn_avi_schur.hip).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int BS> struct Geo {
     static constexpr int NB = 8 * BS;        // padded dimension held in registers
     static constexpr int PB = BS + 2;        // padded block stride (doubles) in the LDS vectors
@@ -154,7 +164,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
     }
     }
     double nbval = v0;
-    __syncthreads();
+    wave_sync();
 
     // ---- load M: coalesced HBM -> LDS stage (BS columns at a time) -> register blocks ------
 #define M_DECL(k, l) double E(k, l) = 0.0;
@@ -214,14 +224,14 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
             QPN_PUT(B, 4) QPN_PUT(B, 5) QPN_PUT(B, 6) QPN_PUT(B, 7)                             \
         }                                                                                       \
         if ((cbk) + 2 < 8) QPN_ISSUE(B, (cbk) + 2)                                              \
-        __syncthreads();                                                                        \
+        wave_sync();                                                                        \
         /* initial basic values xb = q + M z_nb, columns in ascending order (as the checker) */ \
         for (int l = 0; l < ncols; ++l) {                                                       \
             const double zj = snb[col0 + l];                                                    \
             if (zj != 0.0 && act) xb = fma(stage[l * NP + G::pidx(lane)], zj, xb);              \
         }                                                                                       \
         if (cb == (cbk)) { if (full) { QPN_FOR_KL(M_LOAD_FULL) } else { QPN_FOR_KL(M_LOAD) } }  \
-        __syncthreads();                                                                        \
+        wave_sync();                                                                        \
     }
 #define M_LOAD(k, l)                                                                            \
     if constexpr ((k) < BS && (l) < BS)                                                         \
@@ -279,7 +289,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
             elist[pos] = gk ? N + lane : lane;
         }
     }
-    __syncthreads();
+    wave_sync();
     int budget = 4 * N + 4;
     int stage_ = 0, idx = 0;
     int status = QPN_FAILURE;
@@ -358,22 +368,22 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
                              QPN_FOR_K(M_B_XC, L2) QPN_FOR_K(M_B_XC, L3) }                          \
             if (ra == jbk) { QPN_FOR_L(M_B_XR, L0) QPN_FOR_L(M_B_XR, L1)                            \
                              QPN_FOR_L(M_B_XR, L2) QPN_FOR_L(M_B_XR, L3) }                          \
-            __syncthreads();                                                                        \
+            wave_sync();                                                                        \
             double cp0 = stage[0 * NP + G::pidx(lane)], cp1 = stage[1 * NP + G::pidx(lane)];        \
             double cp2 = stage[2 * NP + G::pidx(lane)], cp3 = stage[3 * NP + G::pidx(lane)];        \
             double rp0 = stage[4 * NP + G::pidx(lane)], rp1 = stage[5 * NP + G::pidx(lane)];        \
             double rp2 = stage[6 * NP + G::pidx(lane)], rp3 = stage[7 * NP + G::pidx(lane)];        \
-            __syncthreads();                                                                        \
+            wave_sync();                                                                        \
             double inv0 = 0.0, inv1 = 0.0, inv2 = 0.0, inv3 = 0.0;                                  \
             int nk = 0;                                                                             \
             M_B_PANEL(0) M_B_PANEL(1) M_B_PANEL(2) M_B_PANEL(3)                                     \
             (void)cp0; (void)rp0;                                                                   \
-            __syncthreads();                                                                        \
+            wave_sync();                                                                        \
             M_B_APPLY(0, L0) M_B_APPLY(1, L1)                                                       \
             M_B_APPLY(2, L2) M_B_APPLY(3, L3)                                                       \
             pivots_blk += nk; idx += nk; budget -= nk;                                              \
             if (nk < 4) fast_ok = false;                                                            \
-            __syncthreads();                                                                        \
+            wave_sync();                                                                        \
         }                                                                                           \
     }
         for (int jbk = 0; jbk < 8 && fast_ok; ++jbk) {
@@ -404,7 +414,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
             else {                                                                                  \
                 if (cb == (JB)) { QPN_FOR_K(M_FXC, JJ) }                                            \
                 if (ra == (JB)) { QPN_FOR_L(M_FXR, JJ) }                                            \
-                __syncthreads();                                                                    \
+                wave_sync();                                                                    \
                 /* one LDS round trip: pivot, this row-lane's column entry, u and raw v blocks */   \
                 const double pivr = ucol[G::pidx(e_)];                                              \
                 const double cmf = lane < NB ? ucol[G::pidx(lane)] : 0.0;                           \
@@ -424,7 +434,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
                     if (cb == (JB)) { QPN_FOR_K(M_FFC, JJ) }                                        \
                     if (ra == (JB)) { QPN_FOR_L(M_FFR, JJ) }                                        \
                     pivots_fast++; idx++; budget--;                                                 \
-                    __syncthreads();                                                                \
+                    wave_sync();                                                                \
                 }                                                                                   \
             }                                                                                       \
         }                                                                                           \
@@ -516,7 +526,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
 #undef QPN_LEAF
 #undef M_XC
         }
-        __syncthreads();
+        wave_sync();
             cm = lane < NB ? ucol[G::pidx(lane)] : 0.0;
         }
         STAMP(2);   // column extraction
@@ -613,7 +623,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
                 sigma = au ? -1.0 : 1.0;
                 self_lim = QINF;
                 if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }   // d_k of an ordinary pair
-                __syncthreads();
+                wave_sync();
                 continue;
             }
             if (__popcll(bal) == 1) {
@@ -650,7 +660,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
 #undef M_XR
         }
         if (lane == r) vrow[NP] = tcol;
-        __syncthreads();
+        wave_sync();
         {
             // one LDS round trip: extra-column entry of the pivot row, u = pivot column block,
             // v = raw pivot row block
@@ -707,7 +717,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
         if (lane == r) { rowvar = ve; lo = nlo; hi = nhi; }
         if (c == XC) { cNvar = vl; cNval = leave_u; }
         else if (lane == c) { colvar = vl; nbval = leave_u; }
-        __syncthreads();
+        wave_sync();
         }
         STAMP(4);   // rank-1 update
         pivots++;
@@ -742,19 +752,19 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
             }
             c = col_of(vn);
             if (c < 0) { status = QPN_FAILURE; break; }
-            __syncthreads();
+            wave_sync();
         }
     }
     STAMP(1);
 
     // ---- read the point back ----------------------------------------------------------------
-    __syncthreads();
+    wave_sync();
     gk = (act && a.kind) ? (int)a.kind[(size_t)b * (size_t)a.stride_kind + lane] : 0;
     if (act) { snb[rowvar] = xb; snb[colvar] = nbval; }
     if (lane == 0) snb[cNvar] = cNval;
-    __syncthreads();
+    wave_sync();
     const double zk = act ? snb[gk ? N + lane : lane] : 0.0;
-    __syncthreads();
+    wave_sync();
     if (blocked) {
         // reduced problem of a caller that checks on its own original blocks: the point, the status and the pivot count
         if (act) a.z[vo + lane] = zk;
@@ -770,7 +780,7 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
         return;
     }
     if (act) ucol[lane] = zk;   // z, broadcast source for the post-check mat-vec (NB <= NP)
-    __syncthreads();
+    wave_sync();
 
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------
     double rk = act ? a.q[vo + lane] : 0.0;
@@ -885,10 +895,10 @@ __global__ __launch_bounds__(WAVE, 2) void avi_solve_reg_scan(AviBatchArgs a)
                                   const_cast<double *>(a.l), const_cast<double *>(a.u),
                                   const_cast<uint8_t *>(a.kind));
                 __threadfence();
-                __syncthreads();
+                wave_sync();
             }
             avi_solve_reg_item<BS>(a, b);
-            __syncthreads();
+            wave_sync();
         }
     }
 }
