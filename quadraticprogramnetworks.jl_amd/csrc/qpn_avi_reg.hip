@@ -590,7 +590,11 @@ __device__ __forceinline__ void avi_solve_reg_item(const AviBatchArgs &a, const 
             delta = (leave_val - readlane_f64(xb, r)) * inv;
         } else {
             const double g = sigma * cm;
-            const double rc = 1.0 / g;
+            // (LEAN: one Newton step on v_rcp_f64, <= 10 ulp, as in the fused kernels -- the general path keeps the IEEE quotient
+            //  of the oracle)
+            double rc;
+            if constexpr (LEAN) { const double r0 = __builtin_amdgcn_rcp(g); rc = fma(r0, fma(-g, r0, 1.0), r0); }
+            else rc = 1.0 / g;
             const bool cndlo = act && g < -ptol && lo > -QINF;
             const bool cndhi = act && g > ptol && hi < QINF;
             const bool cnd = cndlo || cndhi;
