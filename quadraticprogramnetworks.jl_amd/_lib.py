@@ -18,7 +18,7 @@ ABI_SYMBOLS = (
     "qpn_assemble_nodes", "qpn_solve_nodes", "qpn_solve_nodes_into", "qpn_order_nodes_by_pivots",
     "qpn_set_node_order", "qpn_verify_nodes",
     "qpn_shared_alloc", "qpn_shared_open", "qpn_shared_close", "qpn_shared_free", "qpn_set_primal_mirrors",
-    "qpn_sweep_status", "qpn_ctx_set_auto_schedule",
+    "qpn_sweep_status", "qpn_ctx_set_auto_schedule", "qpn_ctx_set_option",
     "qpn_nodes_upload", "qpn_nodes_update", "qpn_nodes_set_schedule", "qpn_nodes_free", "qpn_nodes_info", "qpn_solve_nodes_h",
     "qpn_verify_nodes_h", "qpn_pool_size", "qpn_assemble_pools", "qpn_local_pieces", "qpn_recipes_from_masks",
 )
@@ -29,6 +29,7 @@ MAX_MIRRORS = 7
 IPC_HANDLE_BYTES = 64
 SHARED_FINE_GRAINED = 1
 SWEEP_BOX_BYTES = 512
+OPT_MID_ROUTE = 1
 
 
 class LibraryMissing(RuntimeError):
@@ -97,6 +98,7 @@ def load_library():
     lib.qpn_order_nodes_by_pivots.argtypes = [vp, vp, C.c_int32, C.c_int]
     lib.qpn_set_node_order.argtypes = [vp, vp, C.c_int32, C.c_int]
     lib.qpn_ctx_set_auto_schedule.argtypes = [vp, C.c_int32]
+    lib.qpn_ctx_set_option.argtypes = [vp, C.c_int32, C.c_int32]
     lib.qpn_verify_nodes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, C.c_int64, C.c_double, vp, vp, vp, C.c_int]
     lib.qpn_shared_alloc.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp), vp]

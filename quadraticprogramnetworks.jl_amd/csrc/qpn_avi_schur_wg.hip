@@ -1,0 +1,850 @@
+// qpn_avi_schur_wg.hip -- ONE fused workgroup kernel for MID-SIZE node records (n, m <= 64, one of them > 32), gfx950.
+//
+// Round 2 solved these nodes with three kernels (qpn_avi_schur_mid.hip: crash on the matrix cores, the Schur problem on the
+// general register kernel, a finish kernel) that handed W~, S and c through an HBM workspace: ~600 MB per 4 000 nodes where
+// the records and the outputs are ~150 MB, and a Lemke phase at 5.3 K clocks per pivot.  Here the whole solve of a node --
+// KKT assembly (src/avi.jl:205-251, :305-377), crash, Lemke, read-back, post-check (src/avi.jl:71-76, :148-156), active
+// sets (src/avi_solutions.jl:511-562), primal write-back (src/avi.jl:440-443) -- is ONE workgroup of NW = n_pad/16 (3 or 4)
+// wavefronts; nothing but the records is read and nothing but the outputs is written.
+//
+//   Stage A (crash of the n free variables = block Gauss-Jordan on [H | C~ | g], C~ = +Ad'): wave v owns ROW TILE v
+//     (16 rows x up to 8 MFMA tiles = 64 VGPRs).  Per rank-4 block pivot (n/4 <= 16 of them) the owner of the pivot rows
+//     publishes them raw (B operands) and the raw 4 x 4 pivot block through LDS, every wave gathers its 16 x 4 panel of pivot
+//     columns: ONE workgroup barrier; then EVERY wave factors the pivot block itself (uniform, in registers: 4 x 4 LU without
+//     pivoting, every pivot must pass |u_ss| >= 1e-4 max(1, max|M|), else the node is declined) and forms its entry of
+//     U' = U P^-1 in the A-operand layout: no second hand-over, one MFMA (NEG on A) per live tile.
+//   S = Ad W~ and c = b - Ad h: W~ crosses LDS once (it STAYS in the tile registers for the read-back), wave v computes row
+//     tile v of S; S is transposed through LDS into the Stage-B layout.
+//   Stage B (Lemke on the m x (m+1) Schur dictionary): wave v holds COLUMNS 16v .. 16v+15 with lane <-> row (16 entries per
+//     lane), every wave keeps the whole bookkeeping (row vectors lane <-> row, column vectors lane <-> column) and runs the
+//     ratio test itself on the entering column, which its owner publishes through LDS: ONE barrier per pivot and no
+//     cross-wave reduction -- all waves compute the same bits.  The exchange follows the scalar statement of the method
+//     (the CPU checker's do_pivot) operation by operation: lane r scales its row in place (EXEC = that lane), the scaled
+//     row goes to SGPRs with v_readlane, every lane runs T_ij = fma(-u_i, p_j, T_ij) with u_r = 2 (p - 2 p = -p, exact).
+//   Read-back x = W~ lambda - h from the tile registers (DPP butterflies), post-check / residual / masks on the ORIGINAL
+//     blocks: Qd re-read column-wise (coalesced, L2 / Infinity Cache), Ad staged in LDS.
+// Declined nodes (a block pivot below the threshold, an equality row) keep status -1 and take the general path in gated
+// launches, exactly as for the 32-class kernel.  Arithmetic differs from the scalar crash by summation order (block
+// elimination) and one-step Newton reciprocals: parity bar DESIGN.md section 2.
+#include "qpn_internal.h"
+
+#define QINF __builtin_huge_val()
+
+namespace {
+
+constexpr int VLD = 144;                // row stride of the published pivot rows (128 columns; == 16 mod 32)
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d16 __attribute__((ext_vector_type(16)));
+#define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+#define MFMA_NEGA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 1)      // D = C - A B (gfx950 NEG bits)
+
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double rcp64(double x)      // one Newton step on v_rcp_f64: <= 10 ulp (tools/rcp_probe.hip)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ double max_abs_nc(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// min over all 64 lanes of v and the wave-uniform `lim`, returned wave-uniform: four DPP row stages, row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3, lane 63 read out (callers feed no NaNs; non-candidates carry +inf)
+__device__ __forceinline__ double wave_min64_with_limit_f64(double v, double lim)
+{
+    {
+        const double ls = udbl(lim);
+        double r;
+        asm("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(v), "s"(ls));
+        v = r;
+    }
+    v = min_f64_nc(v, dpp_f64<0xB1>(v));
+    v = min_f64_nc(v, dpp_f64<0x4E>(v));
+    v = min_f64_nc(v, dpp_f64<0x141>(v));
+    v = min_f64_nc(v, dpp_f64<0x140>(v));
+    {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xA, 0xF, false);      // rows 1, 3 <- lane 15 of rows 0, 2
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xA, 0xF, false);
+        v = min_f64_nc(v, __hiloint2double(hi, lo));
+    }
+    {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x143, 0xC, 0xF, false);      // rows 2, 3 <- lane 31
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x143, 0xC, 0xF, false);
+        v = min_f64_nc(v, __hiloint2double(hi, lo));
+    }
+    return readlane_f64(v, 63);
+}
+
+// lane id recomputed on the spot (v_mbcnt on the full EXEC mask; opaque, so the compiler does not keep the copy from the
+// start of the kernel alive -- and spill it -- across the phases): every phase derives its own lane coordinates
+__device__ __forceinline__ int lane_id_fresh()
+{
+    int x = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// v + (v of lane ^ 16) + (v of lane ^ 32) + (v of lane ^ 48): gfx950's row / half swaps (VALU, no LDS trip, no address registers)
+__device__ __forceinline__ double xsum_rows(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(s); hi = __double2hiint(s);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+
+#ifdef QPN_STAMPS
+#define STAMP(slot)                                                     \
+    do {                                                                \
+        unsigned long long now__ = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        stamp_acc[slot] += now__ - stamp_last;                          \
+        stamp_last = now__;                                             \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
+// LDS map (doubles).  The big area is, in turn: the Qd staging block [n_pad][n_pad + 2], the published pivot rows
+// [2][4][VLD], W~ for the S product [n_pad][m_pad], S on its way into the Stage-B layout [m_pad][m_pad + 1], Ad for the
+// post-check [n][m | 1].
+constexpr int OFF_Q = 0;                // q = [g ; b] in item order                              [128]
+constexpr int OFF_U = 128;              // Stage A: per wave its 16 x 4 panel of pivot columns    [4][64]
+constexpr int OFF_PR = 384;             // Stage A: raw pivot block + x_piv, two buffers          [2][24]
+constexpr int OFF_VAL = 128;            // read-back: values by variable id (over OFF_U)          [136]
+constexpr int OFF_Z = 264;              // read-back: z in item order (over OFF_U / OFF_PR)       [128]
+constexpr int OFF_RED = 432;            // block reduction                                        [8]
+constexpr int OFF_H = 440;              // h (the eliminated extra column)                        [64]
+constexpr int OFF_COL = 504;            // Stage B: entering column, two buffers; [64..127] first carries c   [2][64]
+constexpr int OFF_BIG = 632;
+__host__ __device__ constexpr int wg_lds_doubles(int n, int m, int n_pad, int m_pad)
+{
+    int big = 2 * 4 * VLD;
+    if (n_pad * m_pad > big) big = n_pad * m_pad;
+    if (n_pad * (n_pad + 2) > big) big = n_pad * (n_pad + 2);
+    if (m_pad * (m_pad + 1) > big) big = m_pad * (m_pad + 1);
+    if (n * (m | 1) > big) big = n * (m | 1);
+    return OFF_BIG + big;
+}
+
+// NT, MT: the tile counts of a launch (n <= 16 NT, m <= 16 MT; sizes inside a class are padded: identity rows in H, zero
+// rows / columns elsewhere); the workgroup has NW = max(NT, MT) wavefronts.  Everything that depends on the tile counts is
+// resolved at compile time: the tile code is straight-line.
+template <int NT, int MT>
+__global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 4) void schur_wg_nodes(AviBatchArgs a)
+{
+    constexpr int NW = NT > MT ? NT : MT;
+
+    const int b = blockIdx.x;
+    const int v = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int l = (int)threadIdx.x & 63, lc = l & 15, lq = l >> 4, tid = 64 * v + l;
+    const int n = a.nd.n, m = a.nd.m, np_ = a.nd.p, N = n + m;
+    constexpr int n_pad = 16 * NT, m_pad = 16 * MT, nht = NT, mct = MT;
+    extern __shared__ __attribute__((aligned(32))) double sm[];
+    double *const sQ = sm + OFF_Q, *const sUv = sm + OFF_U + 64 * v, *const sPr = sm + OFF_PR;
+    double *const sRed = sm + OFF_RED, *const sH = sm + OFF_H, *const sV = sm + OFF_BIG, *const sW = sm + OFF_BIG;
+    double *const sucol = sm + OFF_COL, *const sval = sm + OFF_VAL, *const sz = sm + OFF_Z;
+
+    const double *Q_ = a.nd.Qd + (size_t)b * n * n;
+    const double *A_ = a.nd.Ad + (size_t)b * m * n;
+    const double *R_ = a.nd.R + (size_t)b * n * np_;
+    const double *B_ = a.nd.B + (size_t)b * m * np_;
+    const double *w_ = a.nd.w + (size_t)b * (size_t)a.nd.stride_w;
+    auto decline = [&]() {
+        if (tid == 0) {
+            a.status[b] = -1;
+            if (a.decl_count) atomicAdd(a.decl_count, 1);
+        }
+    };
+#ifdef QPN_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- load: wave v takes row tile v of [H | C~] straight into the MFMA C/D layout --------------------------
+    // H(r, c) = Qd[c * n + r] (padded rows: identity), C~(r, k) = Ad[r * m + k] (Ad is m x n column-major)
+    d4 th0, th1, th2, th3, tc0, tc1, tc2, tc3;
+    double mabs = 0.0;
+#define M_LOADC(J, T)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * v + 4 * g + lq, ck = 16 * (J) + lc;                                     \
+        const bool valid = (J) < MT && v < NT && rr < n && ck < m;                                  \
+        double t_ = 0.0;                                                                            \
+        if ((J) < MT) t_ = A_[valid ? (size_t)rr * m + ck : 0];                                     \
+        T[g] = valid ? t_ : 0.0;                                                                    \
+    }
+    M_LOADC(0, tc0) M_LOADC(1, tc1) M_LOADC(2, tc2) M_LOADC(3, tc3)
+#undef M_LOADC
+    // Qd: whole columns with coalesced loads (lane <-> row, the NW waves take every NW-th column, all loads of a thread
+    // in flight together) into LDS, column stride n_pad + 2 (conflict-free tile reads); tiles from there
+    constexpr int LDQ = n_pad + 2;
+    double *const sQd = sm + OFF_BIG;
+    {
+        double vq[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = v + NW * t;
+            const bool ok = j < n && l < n;
+            const double t_ = Q_[ok ? (size_t)j * n + l : 0];
+            vq[t] = ok ? t_ : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = v + NW * t;
+            mabs = max_abs_nc(mabs, vq[t]);
+            if (j == l && l >= n) vq[t] = 1.0;                      // padded rows pivot on themselves
+            if (j < n_pad && l < n_pad) sQd[j * LDQ + l] = vq[t];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        mabs = max_abs_nc(max_abs_nc(mabs, tc0[g]), tc1[g]);
+        mabs = max_abs_nc(max_abs_nc(mabs, tc2[g]), tc3[g]);
+    }
+    // q = [qd + R w; B w], the p terms in ascending order (the fma chain of the assembly kernel), eight loads in flight
+    if (tid < N) {
+        const bool isx = tid < n;
+        const double *col = isx ? R_ + tid : B_ + (tid - n);
+        const size_t cs = isx ? (size_t)n : (size_t)m;
+        double s = isx ? a.nd.qd[(size_t)b * n + tid] : 0.0;
+        for (int k0 = 0; k0 < np_; k0 += 8) {
+            double rv[8], wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = k0 + k < np_;
+                rv[k] = col[ok ? (size_t)(k0 + k) * cs : 0];
+                wv[k] = w_[ok ? k0 + k : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = (k0 + k < np_) ? fma(rv[k], wv[k], s) : s;
+        }
+        sQ[tid] = s;
+    }
+    // bounds of pair l (every wave keeps the whole bookkeeping of Stage B); equality GAVI rows need their multiplier
+    // crashed in: left to the general kernel
+    const bool actb = l < m;
+    bool eqrow = false;
+    if (actb) eqrow = a.nd.l[(size_t)b * m + l] == a.nd.u[(size_t)b * m + l];
+    {
+        double r = mabs;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(r, off, 64); r = o > r ? o : r; }
+        if (l == 0) sRed[v] = r;
+    }
+    if (__syncthreads_or(eqrow ? 1 : 0)) { decline(); return; }
+    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+#define M_LOADH(J, T)                                                                               \
+    T = z4;                                                                                         \
+    if ((J) < NT && v < nht) {                                                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) T[g] = sQd[(16 * (J) + lc) * LDQ + 16 * v + 4 * g + lq]; \
+    }
+    M_LOADH(0, th0) M_LOADH(1, th1) M_LOADH(2, th2) M_LOADH(3, th3)
+#undef M_LOADH
+    double mscale = sRed[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) mscale = fmax(mscale, sRed[k]);
+    const double diag_thr = udbl(1e-4 * (mscale > 1.0 ? mscale : 1.0));
+    double kx = (l < 16 && 16 * v + l < n) ? sQ[16 * v + l] : 0.0;       // lane l <-> row 16 v + l of the extra column
+    __syncthreads();                    // the staged Qd has been read: the published pivot rows reuse its area
+    STAMP(0);   // load
+
+    // ---- rank-4 block pivots ---------------------------------------------------------------------------------
+    // M_PUB(KB): gather of this wave's panel of pivot columns, and -- the owner of the pivot rows -- their raw values in
+    // every live column tile, the raw pivot block and the rows' extra-column entries;  M_ELIM(KB): behind the barrier,
+    // every wave factors the block and updates its row tile.
+    bool fail = false;
+#define M_PUBT(J, T, GP) if constexpr ((J) < NT) sVp[lq * VLD + 16 * (J) + lc] = T[GP];
+#define M_PUBC(J, T, GP) if constexpr ((J) < MT) sVp[lq * VLD + 64 + 16 * (J) + lc] = T[GP];
+#define M_PUB(KB, THJP)                                                                             \
+    if ((KB) / 4 < NT && !fail && 4 * (KB) < n) {                                                   \
+        constexpr int JP = (KB) / 4, GP = (KB) % 4, cq = 4 * GP, par = (KB) & 1;                    \
+        double *const sVp = sV + par * 4 * VLD;                                                     \
+        double *const sPp = sPr + par * 24;                                                         \
+        if (v < nht) {                                                                              \
+            const int kcol = lc - cq;                                                               \
+            if (kcol >= 0 && kcol < 4) {                                                            \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                     \
+                    double val = THJP[g];                                                           \
+                    if (v == JP && g == GP) { sPp[lq * 4 + kcol] = val; if (lq == kcol) val -= 1.0; } \
+                    sUv[(4 * g + lq) * 4 + kcol] = val;                                             \
+                }                                                                                   \
+            }                                                                                       \
+            if (v == JP) {          /* the owner of the pivot rows */                               \
+                if constexpr (JP <= 0) M_PUBT(0, th0, GP)                                           \
+                if constexpr (JP <= 1) M_PUBT(1, th1, GP)                                           \
+                if constexpr (JP <= 2) M_PUBT(2, th2, GP)                                           \
+                M_PUBT(3, th3, GP)                                                                  \
+                M_PUBC(0, tc0, GP) M_PUBC(1, tc1, GP) M_PUBC(2, tc2, GP) M_PUBC(3, tc3, GP)         \
+                if (l >= cq && l < cq + 4) sPp[16 + l - cq] = kx;       /* their extra-column entries x_piv */ \
+            }                                                                                       \
+        }                                                                                           \
+        __syncthreads();                                                                            \
+        STAMP(1);                                                                                   \
+    }
+#define M_UPD(J, T) if constexpr ((J) < NT) { const double vr_ = sVp[lq * VLD + 16 * (J) + lc]; T = MFMA_NEGA(au, vr_, T); }
+#define M_UPDC(J, T) if constexpr ((J) < MT) { const double vr_ = sVp[lq * VLD + 64 + 16 * (J) + lc]; T = MFMA_NEGA(au, vr_, T); }
+#define M_ELIM(KB)                                                                                  \
+    if ((KB) / 4 < NT && !fail && 4 * (KB) < n) {                                                   \
+        constexpr int JP = (KB) / 4, par = (KB) & 1;                                                \
+        const double *const sVp = sV + par * 4 * VLD;                                               \
+        const double *const sPp = sPr + par * 24;                                                   \
+        /* P = L U (unit lower L, no pivoting; uniform: every lane of every wave) */                \
+        double pm[4][4];                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+            const d4 row = *reinterpret_cast<const d4 *>(sPp + i * 4);                              \
+            pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];             \
+        }                                                                                           \
+        bool okp = true;                                                                            \
+        double rd[4];                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
+            okp = okp & (fabs(pm[s][s]) >= diag_thr);      /* (no short circuit: no branches in the factorization) */ \
+            rd[s] = rcp64(pm[s][s]);                                                                \
+            _Pragma("unroll") for (int i = s + 1; i < 4; ++i) {                                     \
+                const double f = pm[i][s] * rd[s];                                                  \
+                pm[i][s] = f;                                                                       \
+                _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]); \
+            }                                                                                       \
+        }                                                                                           \
+        if (!ubool(okp)) { fail = true; }                                                           \
+        else if (v < nht) {                                                                         \
+            /* column lq of P^-1 (L y = e_lq, U x = y): U' = U P^-1 straight in the A-operand layout -- lane (lc, lq) forms \
+               U'[row lc][column lq]; pivot rows hold P - I, so theirs is I - P^-1 and the update turns them into P^-1 V */ \
+            const double e0 = lq == 0 ? 1.0 : 0.0, e1 = lq == 1 ? 1.0 : 0.0, e2 = lq == 2 ? 1.0 : 0.0, e3 = lq == 3 ? 1.0 : 0.0; \
+            const double y1 = fma(-pm[1][0], e0, e1);                                               \
+            const double y2 = fma(-pm[2][1], y1, fma(-pm[2][0], e0, e2));                           \
+            const double y3 = fma(-pm[3][2], y2, fma(-pm[3][1], y1, fma(-pm[3][0], e0, e3)));       \
+            const double p3 = y3 * rd[3];                                                           \
+            const double p2 = fma(-pm[2][3], p3, y2) * rd[2];                                       \
+            const double p1 = fma(-pm[1][3], p3, fma(-pm[1][2], p2, y1)) * rd[1];                   \
+            const double p0 = fma(-pm[0][3], p3, fma(-pm[0][2], p2, fma(-pm[0][1], p1, e0))) * rd[0]; \
+            const d4 ur = *reinterpret_cast<const d4 *>(sUv + lc * 4);                              \
+            const double au = fma(ur[3], p3, fma(ur[2], p2, fma(ur[1], p1, ur[0] * p0)));           \
+            /* extra column: kx_l -= sum_q U'[l][q] x_piv[q] -- the four terms of row l sit in lanes l, l + 16, l + 32, l + 48 */ \
+            kx -= xsum_rows(au * sPp[16 + lq]);                                                     \
+            STAMP(2);                                                                               \
+            if constexpr (JP <= 0) M_UPD(0, th0)                                                    \
+            if constexpr (JP <= 1) M_UPD(1, th1)                                                    \
+            if constexpr (JP <= 2) M_UPD(2, th2)                                                    \
+            M_UPD(3, th3)                                                                           \
+            M_UPDC(0, tc0) M_UPDC(1, tc1) M_UPDC(2, tc2) M_UPDC(3, tc3)                             \
+            wave_sync();                                                                            \
+            STAMP(3);                                                                               \
+        }                                                                                           \
+    }
+    M_PUB(0, th0) M_ELIM(0) M_PUB(1, th0) M_ELIM(1) M_PUB(2, th0) M_ELIM(2) M_PUB(3, th0) M_ELIM(3)
+    M_PUB(4, th1) M_ELIM(4) M_PUB(5, th1) M_ELIM(5) M_PUB(6, th1) M_ELIM(6) M_PUB(7, th1) M_ELIM(7)
+    M_PUB(8, th2) M_ELIM(8) M_PUB(9, th2) M_ELIM(9) M_PUB(10, th2) M_ELIM(10) M_PUB(11, th2) M_ELIM(11)
+    M_PUB(12, th3) M_ELIM(12) M_PUB(13, th3) M_ELIM(13) M_PUB(14, th3) M_ELIM(14) M_PUB(15, th3) M_ELIM(15)
+#undef M_ELIM
+#undef M_PUB
+#undef M_PUBT
+#undef M_PUBC
+#undef M_UPD
+#undef M_UPDC
+    if (fail) { decline(); return; }
+
+    l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
+    // A operands of the S product (16 x 4 blocks of Ad, element (i = lc, k = lq)): all of them requested now, so that the
+    // round trip hides behind the W~ hand-over (the H tiles are dead: their registers are free)
+    const int arow = 16 * v + lc;
+    double aop[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int r = 4 * kk + lq;                                  // k index: column of Ad, row of W~
+        const bool valid = kk < 4 * NT && v < mct && r < n && arow < m;
+        const double t_ = A_[valid ? (size_t)r * m + arow : 0];
+        aop[kk] = valid ? t_ : 0.0;
+    }
+    // ---- W~ and h to LDS for the S product (the tiles keep W~ for the read-back) -----------------------------------
+    __syncthreads();                                   // the last step's pivot rows have been read (sW reuses them)
+    const int rot = mct == 4 ? lq : (mct == 3 ? (lq == 3 ? 0 : lq) : (mct == 2 ? (lq & 1) : 0));     // lq mod mct (compile-time mct)
+    if (v < nht) {
+#define M_WOUT(J, T)                                                                                \
+    if constexpr ((J) < MT) {                                                                       \
+        int jj = (J) + rot; if (jj >= mct) jj -= mct;                                               \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+            const int rr = 16 * v + 4 * g + lq;                                                     \
+            sW[rr * m_pad + 16 * jj + lc] = T[g];                                                   \
+        }                                                                                           \
+    }
+        M_WOUT(0, tc0) M_WOUT(1, tc1) M_WOUT(2, tc2) M_WOUT(3, tc3)
+#undef M_WOUT
+        if (l < 16) sH[16 * v + l] = kx;
+    }
+    __syncthreads();
+    STAMP(4);   // W~ hand-over
+
+    // ---- S = Ad W~ (row tile v), c = b - Ad h ------------------------------------------------------------------
+    d4 s0 = z4, s1 = z4, s2 = z4, s3 = z4, sx = z4;
+    if (v < mct) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ri = 16 * v + 4 * g + lq;
+            sx[g] = (lc == 0 && ri < m) ? sQ[n + ri] : 0.0;
+        }
+        int j0 = rot, j1 = 1 + rot, j2 = 2 + rot, j3 = 3 + rot;
+        if (j0 >= mct) j0 -= mct;
+        if (j1 >= mct) j1 -= mct;
+        if (j2 >= mct) j2 -= mct;
+        if (j3 >= mct) j3 -= mct;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            if (kk < 4 * NT) {
+                const int r = 4 * kk + lq;
+                const double a_ = aop[kk];
+                const double *wr = sW + r * m_pad + lc;
+                s0 = MFMA(a_, wr[16 * j0], s0);
+                if constexpr (MT > 1) s1 = MFMA(a_, wr[16 * j1], s1);
+                if constexpr (MT > 2) s2 = MFMA(a_, wr[16 * j2], s2);
+                if constexpr (MT > 3) s3 = MFMA(a_, wr[16 * j3], s3);
+                const double hb = lc == 0 ? sH[r] : 0.0;
+                sx = MFMA_NEGA(a_, hb, sx);
+            }
+        }
+    }
+    __syncthreads();                                   // W~ in LDS has been read: S goes through the same area
+    // S into the Stage-B layout: column-major with stride m_pad + 1 (odd in doubles: both the tile-layout stores and the
+    // lane <-> row loads are conflict-free); c into the second column buffer (the first pivot publishes into buffer 0)
+    constexpr int LDS_ = m_pad + 1;
+    double *const sS = sm + OFF_BIG;
+    if (v < mct) {
+#define M_SOUT(J, T)                                                                                \
+    if constexpr ((J) < MT) {                                                                       \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                               \
+            sS[(16 * (J) + lc) * LDS_ + 16 * v + 4 * g + lq] = T[g];                                \
+    }
+        M_SOUT(0, s0) M_SOUT(1, s1) M_SOUT(2, s2) M_SOUT(3, s3)
+#undef M_SOUT
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (lc == 0) sucol[64 + 16 * v + 4 * g + lq] = sx[g];
+    }
+    __syncthreads();
+    d16 T;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) T[j] = (v < mct && l < m_pad) ? sS[(16 * v + j) * LDS_ + l] : 0.0;
+    double xb = actb ? sucol[64 + l] : 0.0;
+    __syncthreads();                                   // S has been read: Ad for the post-check goes into the same area
+    STAMP(5);   // S product + transposition
+
+    l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
+    // Ad for the post-check: requested now (coalesced), parked in LDS
+    const int LDA = m | 1;
+    double *const sAd = sm + OFF_BIG;
+    {
+        constexpr int TPB_ = 64 * NW;
+        for (int e0 = tid; e0 < m * n; e0 += 4 * TPB_) {
+            double vv[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) { const int e = e0 + q4 * TPB_; vv[q4] = e < m * n ? A_[e] : 0.0; }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int e = e0 + q4 * TPB_;
+                const int j = e / m, i = e - j * m;
+                if (e < m * n) sAd[j * LDA + i] = vv[q4];
+            }
+        }
+    }
+
+    // ================= Stage B: Lemke on the Schur dictionary =================
+    // pair k (k < m) <-> item row n + k:  p_k = (S lambda + c)_k in [l_k, u_k],  d_k = lambda_k.
+    // ids: p_k -> k, d_k -> 64 + k, artificial -> 128; column index 64 = the extra (covering) column, kept as the row
+    // vector tcol (lane <-> row) with its bookkeeping in scalars (cvx, nbx).
+    constexpr int NBP = 64, XC = 64, VTH = 128;
+    // bounds of pair l: the row's current interval in registers; the fixed pair bounds, which the bookkeeping looks up by a
+    // wave-uniform pair index once per pivot, in LDS (over the Stage-A scratch: seven registers less across the loop)
+    double *const sLo = sm + OFF_U, *const sHi = sm + OFF_U + 64;
+    double lo = -QINF, hi = QINF;
+    if (actb) { lo = a.nd.l[(size_t)b * m + l]; hi = a.nd.u[(size_t)b * m + l]; }
+    if (v == 0) { sLo[l] = lo; sHi[l] = hi; }
+    int satv = 0;
+    __syncthreads();
+    int rowvar = actb ? l : -1, colvar = actb ? NBP + l : -1;
+    int cvx = VTH;
+    double nbx = 0.0, nbval = 0.0, tcol = 0.0;
+    int pivots = n;                       // the crash brought n free variables in (Stage A)
+    const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
+    int status = QPN_FAILURE;
+    int c = XC, par = 0;
+    bool sneg = true;
+    double self_lim = 0.0, elo = 0.0, ehi = QINF;
+    const double slack = 1e-10, ptol = a.piv_tol;
+    auto col_of = [&](int var) -> int {
+        const int cc = wave_first(colvar == var);
+        return cc >= 0 ? cc : (cvx == var ? XC : -1);
+    };
+    {
+        double viol = 0.0;
+        if (actb) viol = xb < lo ? lo - xb : (xb > hi ? xb - hi : 0.0);
+        const double theta0 = wave_max_f64(viol);
+        if (ubool(theta0 <= a.feas_tol)) status = QPN_SUCCESS;
+        else {
+            if (actb) {
+                double cov = 0.0;
+                if (xb < lo) {
+                    double tgt = lo + (theta0 - (lo - xb));
+                    if (hi < QINF) { double mid = 0.5 * (lo + hi); if (tgt > mid) tgt = mid; }
+                    cov = (tgt - xb) / theta0; xb = tgt;
+                } else if (xb > hi) {
+                    double tgt = hi - (theta0 - (xb - hi));
+                    if (lo > -QINF) { double mid = 0.5 * (lo + hi); if (tgt < mid) tgt = mid; }
+                    cov = (tgt - xb) / theta0; xb = tgt;
+                }
+                tcol = cov;
+            }
+            nbx = theta0;
+            self_lim = theta0;
+            status = QPN_MAX_ITERS;
+        }
+    }
+    while (status == QPN_MAX_ITERS) {
+        if (pivots >= max_piv) break;
+        c = uni(c);
+        // ---- entering column: its owner publishes it (lane <-> row), every wave reads it
+        double cm;
+        if (c == XC) cm = tcol;
+        else {
+            if (v == (c >> 4)) sucol[par * 64 + l] = T[c & 15];
+            __syncthreads();
+            cm = sucol[par * 64 + l];
+            par ^= 1;
+        }
+        STAMP(6);
+        // ---- ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
+        const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
+        const double rc = rcp64(gdir);
+        const bool gneg = __double2hiint(gdir) < 0;
+        const double tb = gneg ? lo : hi;                       // the bound the row's basic variable moves towards
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
+        const bool cnd = (actb & (fabs(gdir) > ptol)) & (fabs(tb) < QINF);
+#pragma clang diagnostic pop
+        const double arc = fabs(rc);
+        const double dd = cnd ? (tb - xb) * rc : QINF;
+        const double d1 = fma(slack, arc, dd);
+        const double dmax = wave_min64_with_limit_f64(d1, self_lim);
+        if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; break; }
+        const unsigned long long bal = qpn_ballot(dd <= dmax);
+        if (bal == 0ull) {
+            // the entering variable reaches its own opposite bound first: no basis change
+            const double dl = sneg ? -self_lim : self_lim;
+            if (actb) xb = fma(dl, cm, xb);
+            const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);
+            if (ve == VTH) {
+                if (c == XC) nbx = 0.0; else if (l == c) nbval = 0.0;
+                status = QPN_SUCCESS;
+                break;
+            }
+            const int k = ve;
+            const int au = sneg ? 0 : 1;
+            const double nbW = udbl(au ? sHi[k] : sLo[k]);
+            if (l == k) satv = au;
+            if (c == XC) nbx = nbW; else if (l == c) nbval = nbW;
+            pivots++;
+            c = col_of(NBP + k);
+            if (c < 0) { status = QPN_FAILURE; break; }
+            sneg = au != 0;
+            self_lim = QINF;
+            if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+            continue;
+        }
+        int r;
+        if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
+        else {
+            const bool cand = dd <= dmax;
+            double ag = cand ? fabs(gdir) : -1.0;
+            if (cand && rowvar == VTH) ag = QINF;
+            const double bestg = wave_max_f64(ag);
+            r = wave_first(cand && ag == bestg);
+        }
+        r = uni(r);
+        STAMP(7);
+        double step = readlane_f64(dd, r);
+        if (step < 0.0) step = 0.0;
+        const double leave_val = readlane_f64(tb, r);
+        const double rcr = readlane_f64(rc, r);
+        const double inv = sneg ? -rcr : rcr;                   // 1 / T[r][c]
+        const double delta = sneg ? -step : step;
+        const int vl = readlane_i32(rowvar, r);
+        const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);
+        const double enter_val = ((c == XC) ? nbx : readlane_f64(nbval, c)) + delta;
+        const bool isr = l == r;
+        // values and the extra column (scalar statement: prow = T[r][.] * inv; T[i][.] = fma(-cm_i, prow, T[i][.]); row r: -prow)
+        {
+            const double xbn = fma(delta, cm, xb);
+            xb = isr ? enter_val : xbn;
+            if (c == XC) {
+                const double tcn = cm * inv;
+                tcol = isr ? inv : tcn;
+            } else {
+                const double vx = readlane_f64(tcol, r) * inv;
+                const double tcn = fma(-cm, vx, tcol);
+                tcol = isr ? -vx : tcn;
+            }
+        }
+        // ---- the exchange on this wave's 16 columns
+        {
+            const unsigned long long mrow = 1ull << r;
+            const double inv_s = udbl(inv);
+            // lane r: its row times 1 / pivot, in place
+            asm volatile("s_mov_b64 exec, %[mr]\n\t"
+                         "v_mul_f64 %[t0], %[t0], %[iv]\n\tv_mul_f64 %[t1], %[t1], %[iv]\n\t"
+                         "v_mul_f64 %[t2], %[t2], %[iv]\n\tv_mul_f64 %[t3], %[t3], %[iv]\n\t"
+                         "v_mul_f64 %[t4], %[t4], %[iv]\n\tv_mul_f64 %[t5], %[t5], %[iv]\n\t"
+                         "v_mul_f64 %[t6], %[t6], %[iv]\n\tv_mul_f64 %[t7], %[t7], %[iv]\n\t"
+                         "v_mul_f64 %[t8], %[t8], %[iv]\n\tv_mul_f64 %[t9], %[t9], %[iv]\n\t"
+                         "v_mul_f64 %[t10], %[t10], %[iv]\n\tv_mul_f64 %[t11], %[t11], %[iv]\n\t"
+                         "v_mul_f64 %[t12], %[t12], %[iv]\n\tv_mul_f64 %[t13], %[t13], %[iv]\n\t"
+                         "v_mul_f64 %[t14], %[t14], %[iv]\n\tv_mul_f64 %[t15], %[t15], %[iv]\n\t"
+                         "s_mov_b64 exec, -1"
+                         : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
+                           [t6] "+v"(T[6]), [t7] "+v"(T[7]), [t8] "+v"(T[8]), [t9] "+v"(T[9]), [t10] "+v"(T[10]), [t11] "+v"(T[11]),
+                           [t12] "+v"(T[12]), [t13] "+v"(T[13]), [t14] "+v"(T[14]), [t15] "+v"(T[15])
+                         : [mr] "s"(mrow), [iv] "s"(inv_s));
+            const double um = isr ? 2.0 : cm;                   // lane r: p - 2 p = -p, exact
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double pj = readlane_f64(T[j], r);
+                T[j] = fma(-um, pj, T[j]);
+            }
+            // column c of the new dictionary: T[i][c] = cm_i * inv, T[r][c] = inv -- on its owner, behind a scalar dispatch
+            const int csel = (c != XC && v == (c >> 4)) ? (c & 15) : 16;
+            const double cv = isr ? inv : cm * inv;
+            asm volatile("s_cmp_gt_u32 %[cs], 7\n\ts_cbranch_scc1 .Lwgc_hi%=\n\t"
+                         "s_cmp_gt_u32 %[cs], 3\n\ts_cbranch_scc1 .Lwgc_4%=\n\t"
+                         "s_cmp_gt_u32 %[cs], 1\n\ts_cbranch_scc1 .Lwgc_2%=\n\t"
+                         "s_cmp_eq_u32 %[cs], 0\n\ts_cbranch_scc0 .Lwgc_1%=\n\t"
+                         "v_mov_b64 %[t0], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_1%=:\n\tv_mov_b64 %[t1], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_2%=:\n\ts_cmp_eq_u32 %[cs], 2\n\ts_cbranch_scc0 .Lwgc_3%=\n\t"
+                         "v_mov_b64 %[t2], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_3%=:\n\tv_mov_b64 %[t3], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_4%=:\n\ts_cmp_gt_u32 %[cs], 5\n\ts_cbranch_scc1 .Lwgc_6%=\n\t"
+                         "s_cmp_eq_u32 %[cs], 4\n\ts_cbranch_scc0 .Lwgc_5%=\n\t"
+                         "v_mov_b64 %[t4], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_5%=:\n\tv_mov_b64 %[t5], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_6%=:\n\ts_cmp_eq_u32 %[cs], 6\n\ts_cbranch_scc0 .Lwgc_7%=\n\t"
+                         "v_mov_b64 %[t6], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_7%=:\n\tv_mov_b64 %[t7], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_hi%=:\n\ts_cmp_gt_u32 %[cs], 15\n\ts_cbranch_scc1 .Lwgc_end%=\n\t"
+                         "s_cmp_gt_u32 %[cs], 11\n\ts_cbranch_scc1 .Lwgc_12%=\n\t"
+                         "s_cmp_gt_u32 %[cs], 9\n\ts_cbranch_scc1 .Lwgc_10%=\n\t"
+                         "s_cmp_eq_u32 %[cs], 8\n\ts_cbranch_scc0 .Lwgc_9%=\n\t"
+                         "v_mov_b64 %[t8], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_9%=:\n\tv_mov_b64 %[t9], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_10%=:\n\ts_cmp_eq_u32 %[cs], 10\n\ts_cbranch_scc0 .Lwgc_11%=\n\t"
+                         "v_mov_b64 %[t10], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_11%=:\n\tv_mov_b64 %[t11], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_12%=:\n\ts_cmp_gt_u32 %[cs], 13\n\ts_cbranch_scc1 .Lwgc_14%=\n\t"
+                         "s_cmp_eq_u32 %[cs], 12\n\ts_cbranch_scc0 .Lwgc_13%=\n\t"
+                         "v_mov_b64 %[t12], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_13%=:\n\tv_mov_b64 %[t13], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_14%=:\n\ts_cmp_eq_u32 %[cs], 14\n\ts_cbranch_scc0 .Lwgc_15%=\n\t"
+                         "v_mov_b64 %[t14], %[cv]\n\ts_branch .Lwgc_end%=\n"
+                         ".Lwgc_15%=:\n\tv_mov_b64 %[t15], %[cv]\n"
+                         ".Lwgc_end%=:"
+                         : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
+                           [t6] "+v"(T[6]), [t7] "+v"(T[7]), [t8] "+v"(T[8]), [t9] "+v"(T[9]), [t10] "+v"(T[10]), [t11] "+v"(T[11]),
+                           [t12] "+v"(T[12]), [t13] "+v"(T[13]), [t14] "+v"(T[14]), [t15] "+v"(T[15])
+                         : [cs] "s"(uni(csel)), [cv] "v"(cv)
+                         : "scc");
+        }
+        // ---- bookkeeping: row r now holds the entering variable, column c the leaving one
+        if (isr) { rowvar = ve; lo = elo; hi = ehi; }
+        if (c == XC) { cvx = vl; nbx = leave_val; }
+        else if (l == c) { colvar = vl; nbval = leave_val; }
+        pivots++;
+        if (vl == VTH) { status = QPN_SUCCESS; break; }
+        int vn;
+        {
+            const int k = vl < NBP ? vl : vl - NBP;
+            const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
+            const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
+            if (vl < NBP) {
+                // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters from 0
+                const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
+                if (l == k) satv = au;
+                vn = NBP + k;
+                sneg = au != 0;
+                self_lim = QINF;
+                if (cls == 2) { elo = 0.0; ehi = 0.0; }
+                else if (au) { elo = -QINF; ehi = 0.0; }
+                else { elo = 0.0; ehi = QINF; }
+            } else {
+                // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                const int au = readlane_i32(satv, k);
+                vn = k;
+                sneg = au != 0;
+                self_lim = udbl(hk0 - lk0);                     // +inf for a free pair
+                if (cls == 2) sneg = false;
+                elo = lk0; ehi = hk0;
+            }
+        }
+        c = col_of(vn);
+        if (c < 0) { status = QPN_FAILURE; break; }
+    }
+    STAMP(6);
+
+    // ---- read back: lambda_k, then x = W~ lambda - h -------------------------------------------------------------
+    // (everything below derives its lane coordinates and kernel arguments afresh: nothing of that stays in registers across
+    //  the pivot loop)
+    l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
+    typedef const AviBatchArgs __attribute__((address_space(4))) *kargs_t;
+    kargs_t kp = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    __syncthreads();                                   // every wave is out of the loop (sval / sz lie over Stage-A scratch only,
+                                                       // but the Ad stores above must have landed before the post-check)
+    if (v == 0) {
+        if (l < m) { sval[rowvar] = xb; sval[colvar] = nbval; }
+        else sval[NBP + l] = 0.0;                                       // multipliers of the padded columns of W~ (finite: 0 x 0)
+        if (l == 0) sval[cvx] = nbx;
+    }
+    __syncthreads();
+    if (v < nht) {
+        // (W~ lambda)_row = sum over the 16 lanes of a DPP row of this lane's partial over its column of each tile, for the
+        // 4 rows (g) a lane holds.  Folded butterfly: at each of the first two stages a lane gives half of its values to its
+        // partner and adds the partner's other half (4 -> 2 -> 1 values; lane bits 0, 1 of lc then name g), bits 2, 3 are
+        // summed by two full stages (xor 4, xor 8: ds_swizzle, the LDS crossbar)
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+        l0 = sval[NBP + lc];
+        if constexpr (MT > 1) l1 = sval[NBP + 16 + lc];
+        if constexpr (MT > 2) l2 = sval[NBP + 32 + lc];
+        if constexpr (MT > 3) l3 = sval[NBP + 48 + lc];
+        const double p0 = fma(tc3[0], l3, fma(tc2[0], l2, fma(tc1[0], l1, tc0[0] * l0)));
+        const double p1 = fma(tc3[1], l3, fma(tc2[1], l2, fma(tc1[1], l1, tc0[1] * l0)));
+        const double p2 = fma(tc3[2], l3, fma(tc2[2], l2, fma(tc1[2], l1, tc0[2] * l0)));
+        const double p3 = fma(tc3[3], l3, fma(tc2[3], l2, fma(tc1[3], l1, tc0[3] * l0)));
+        const bool b0 = (lc & 1) != 0, b1 = (lc & 2) != 0;
+        const double q0 = (b0 ? p1 : p0) + dpp_f64<0xB1>(b0 ? p0 : p1), q1 = (b0 ? p3 : p2) + dpp_f64<0xB1>(b0 ? p2 : p3);
+        double t0 = (b1 ? q1 : q0) + dpp_f64<0x4E>(b1 ? q0 : q1);       // g = b0 + 2 b1, summed over lc bits 0, 1
+        t0 += __shfl_xor(t0, 4, 64);
+        t0 += __shfl_xor(t0, 8, 64);
+        if (lc < 4) {
+            const int row = 16 * v + 4 * lc + lq;                       // g = lc for lc < 4
+            sz[row] = t0 - sH[row];
+        }
+    }
+    __syncthreads();
+    // item order: rows < n are x (already in sz), rows n.. are lambda
+    if (tid < m) sz[n + tid] = sval[NBP + tid];
+    __syncthreads();
+
+    // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------------
+    const double *const Qe_ = kp->nd.Qd + (size_t)b * n * n;
+    const double *const le_ = kp->nd.l, *const ue_ = kp->nd.u;
+    double *const ze_ = kp->z, *const xe_ = kp->x, *const re_ = kp->resid;
+    uint8_t *const ae_ = kp->active;
+    int32_t *const pe_ = kp->pivots;
+    int bad = 0;
+    double nres = 0.0;
+    if (tid < N) {
+        const int k = tid;
+        const int gk = k >= n;
+        double rk = sQ[k];
+        // row k of [[Qd, -Ad'],[Ad, 0]] times z, columns ascending (finite blocks: a zero z_j contributes exactly nothing)
+        if (!gk) {
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+                double mv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = Qe_[(size_t)(j + q8) * n + k];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) rk = fma(mv[q8], sz[j + q8], rk);
+            }
+            for (; j < n; ++j) rk = fma(Qe_[(size_t)j * n + k], sz[j], rk);
+            for (int i = 0; i < m; ++i) rk = fma(-sAd[k * LDA + i], sz[n + i], rk);
+        } else {
+            const int r = k - n;
+            for (int j = 0; j < n; ++j) rk = fma(sAd[j * LDA + r], sz[j], rk);
+        }
+        const double zk = sz[k];
+        const double lk = gk ? le_[(size_t)b * m + (k - n)] : -QINF, uk = gk ? ue_[(size_t)b * m + (k - n)] : QINF;
+        const double p = gk ? rk : zk, d = gk ? zk : rk;
+        const double tol = kp->check_tol;
+        if (d > tol && fabs(p - lk) > tol) bad++;
+        if (d < -tol && fabs(p - uk) > tol) bad++;
+        if (p - lk < -tol) bad++;
+        if (p - uk > tol) bad++;
+        if (isnan(p) || isnan(d)) bad++;
+        double tt = p - d;
+        if (tt < lk) tt = lk;
+        if (tt > uk) tt = uk;
+        double e = fabs(p - tt);
+        if (isnan(e)) e = QINF;
+        nres = e;
+        unsigned mask = 0;
+        const double ct = kp->comp_tol;
+        auto approx = [&](double x, double y) { return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= ct); };
+        if (!approx(lk, uk)) {
+            if (approx(p, lk) && d >= -ct) mask |= 1u;
+            if (lk - ct <= p && p <= uk + ct && fabs(d) <= ct) mask |= 2u;
+            if (approx(p, uk) && d <= ct) mask |= 4u;
+        } else mask = 8u;
+        if (gk) mask <<= 4;
+        ze_[(size_t)b * N + k] = zk;
+        if (xe_ && !gk) {                                                       // primal block -> the caller's iterate
+            const size_t xo = (size_t)b * (size_t)kp->stride_x + k;
+            xe_[xo] = zk;
+            for (int q = 0; q < kp->n_mirror; ++q) kp->mirror[q][xo] = zk;          // ... and its replicas on the peer GPUs
+        }
+        if (ae_) ae_[(size_t)b * N + k] = (uint8_t)mask;
+    }
+    const int badt = __syncthreads_count(bad > 0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(nres, off, 64); nres = o > nres ? o : nres; }
+    if (l == 0) sRed[v] = nres;
+    __syncthreads();
+    if (tid == 0) {
+        if (badt > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
+        kp->status[b] = status;
+        double rs = sRed[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) rs = sRed[k] > rs ? sRed[k] : rs;
+        if (re_) re_[b] = rs;
+        if (pe_) pe_[b] = pivots;
+    }
+    STAMP(7);
+#ifdef QPN_STAMPS
+    if (tid == 0 && a.stamps) {
+        for (int k = 0; k < 8; ++k) a.stamps[(size_t)b * 8 + k] = stamp_acc[k];
+    }
+#endif
+}
+
+} // namespace
+
+bool qpn_schur_wg_shape(int n, int m)
+{
+    return (n > 32 || m > 32) && n >= 1 && n <= 64 && m >= 1 && m <= 64;
+}
+
+// One launch: every node of the batch solved, checked and written back by its own workgroup.  Nodes the kernel declines
+// keep status -1.
+hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream)
+{
+    const int n = a.nd.n, m = a.nd.m, batch = a.batch;
+    if (batch <= 0) return hipSuccess;
+    // size classes: both tile counts rounded up to 3 or 4 (a dimension of 32 or less rides in the 48-class of the other)
+    const int NT = n <= 48 ? 3 : 4, MT = m <= 48 ? 3 : 4;
+    const size_t lds = (size_t)wg_lds_doubles(n, m, 16 * NT, 16 * MT) * sizeof(double);
+    const dim3 grid((unsigned)batch);
+    if (NT == 3 && MT == 3) hipLaunchKernelGGL((schur_wg_nodes<3, 3>), grid, dim3(192), lds, stream, a);
+    else if (NT == 3) hipLaunchKernelGGL((schur_wg_nodes<3, 4>), grid, dim3(256), lds, stream, a);
+    else if (MT == 3) hipLaunchKernelGGL((schur_wg_nodes<4, 3>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((schur_wg_nodes<4, 4>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}

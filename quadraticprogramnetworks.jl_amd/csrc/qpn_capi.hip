@@ -34,6 +34,10 @@ struct qpn_ctx {
     size_t mirror_bytes = 0;
     int32_t mirror_count = 0;
     double *mirror_peer[QPN_MAX_MIRRORS] = {};
+    // route of mid-size node records (qpn_ctx_set_option QPN_OPT_MID_ROUTE; the environment variable QPN_NODES_MID, read ONCE
+    // when the context is created, sets the default): 1 the fused workgroup kernel, 2 round 2's three kernels, 0 the route of
+    // the large nodes
+    int32_t mid_route = 1;
 };
 
 namespace {
@@ -130,8 +134,23 @@ int qpn_ctx_create(int device_id, qpn_ctx **out)
         delete ctx; return QPN_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    // developer default of the mid-size route, read ONCE here (never per call); qpn_ctx_set_option overrides it
+    if (const char *e = getenv("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '2' && !e[1]) ctx->mid_route = e[0] - '0'; }
     *out = ctx;
     return QPN_OK;
+}
+
+int qpn_ctx_set_option(qpn_ctx *ctx, int32_t option, int32_t value)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    switch (option) {
+    case QPN_OPT_MID_ROUTE:
+        if (value < 0 || value > 2) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_MID_ROUTE takes 0, 1 or 2");
+        ctx->mid_route = value;
+        return QPN_OK;
+    default:
+        return fail_arg(ctx, "qpn_ctx_set_option: unknown option");
+    }
 }
 
 int qpn_ctx_destroy(qpn_ctx *ctx)
@@ -684,7 +703,7 @@ void nodes_poll_declines(qpn_nodes *h)
 // general path (null only when h knows that no node declines).
 int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_t m, int32_t p, const NodeDev &d,
                        int64_t stride_w, const qpn_avi_opts &o, double *x_dev, int64_t stride_x, double *wM, double *wq,
-                       double *wl, double *wu, uint8_t *wk, double *wbig, void *wmid)
+                       double *wl, double *wu, uint8_t *wk, double *wbig, void *wmid, bool wg_shape)
 {
     hipStream_t s = ctx->stream;
     const int N = n + m;
@@ -697,6 +716,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
     a.stamps = g_stamps;
 #endif
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
+    bool x_in_kernel = false;
     if (x_dev && mfma_shape) { a.x = x_dev; a.stride_x = stride_x; }      // written by the solve kernels themselves
     // replicas on peer GPUs: only when the whole written range lies inside the registered buffer
     const size_t x_span = x_dev ? ((size_t)(batch - 1) * (size_t)stride_x + (size_t)n) * 8 : 0;
@@ -766,9 +786,10 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
             }
             ctx->auto_calls++;
         }
-    } else if (wmid) {
-        // mid-size nodes (n, m <= 64): four wavefronts per node straight from the records (qpn_avi_schur_mid.hip); what it
-        // declines (status = -1) is assembled and solved by the general kernels in gated launches
+    } else if (wmid || wg_shape) {
+        // mid-size nodes (n, m <= 64): one workgroup per node straight from the records, ONE launch (qpn_avi_schur_wg.hip;
+        // wmid: round 2's three kernels, qpn_avi_schur_mid.hip); what they decline (status = -1) is assembled and solved by
+        // the general kernels in gated launches
         bool need_general = true;
         if (h) {
             nodes_poll_declines(h);
@@ -778,7 +799,19 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                 a.decl_count = h->decl_dev;
             }
         }
-        HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
+        if (wg_shape) {
+            // the kernel writes the primal blocks into the iterate itself once it is known that nothing declines (the
+            // general kernels behind it do not); until then the strided copy below does
+            if (x_dev && !need_general) {
+                a.x = x_dev; a.stride_x = stride_x; x_in_kernel = true;
+                if (mirrored) {
+                    a.n_mirror = ctx->mirror_count;
+                    for (int k = 0; k < ctx->mirror_count; ++k) a.mirror[k] = ctx->mirror_peer[k] + x_off;
+                }
+            }
+            HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
+            a.x = nullptr; a.n_mirror = 0;
+        } else HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
         if (need_general) {
             if (!wM) return fail_arg(ctx, "qpn_solve_nodes: internal error (no workspace for the general path)");
             HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
@@ -803,7 +836,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
         if (N > 64) HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
         else HIPCHK(ctx, qpn_launch_avi_solve(g, s));
     }
-    if (x_dev && !mfma_shape) {     // general sizes: strided device copy of the primal blocks (and to the replicas)
+    if (x_dev && !mfma_shape && !x_in_kernel) {     // general sizes: strided device copy of the primal blocks (and to the replicas)
         HIPCHK(ctx, hipMemcpy2DAsync(x_dev, (size_t)stride_x * 8, d.z, (size_t)N * 8, (size_t)n * 8, (size_t)batch,
                                      hipMemcpyDeviceToDevice, s));
         for (int k = 0; mirrored && k < ctx->mirror_count; ++k)
@@ -831,11 +864,11 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
     // the handle may already know that the general path has nothing to do: no workspace for it then
     nodes_poll_declines(h);
-    // mid-size nodes (QPN_NODES_MID=0: the route of the large nodes, for A/B runs)
-    const char *mid_env = getenv("QPN_NODES_MID");            // read per call: tests switch routes inside one process
-    const bool mid_off = mid_env && mid_env[0] == '0';
-    const bool mid_shape = !mid_off && qpn_schur_mid_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
-    const bool need_ws = !(h && (mfma_shape || mid_shape) && h->decl_state == 2);
+    // mid-size nodes: the fused workgroup kernel (no workspace) or, for A/B runs, the routes it replaced (ctx->mid_route)
+    const bool mid_ok = qpn_schur_mid_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
+    const bool wg_shape = ctx->mid_route == 1 && mid_ok;
+    const bool mid_shape = ctx->mid_route == 2 && mid_ok;
+    const bool need_ws = !(h && (mfma_shape || mid_shape || wg_shape) && h->decl_state == 2);
 
     NodeDev d{Qd, R, qd, Ad, B, l, u, w, z, status, resid, pivots, active};
     double *wM = nullptr, *wq = nullptr, *wl = nullptr, *wu = nullptr, *wbig = nullptr; uint8_t *wk = nullptr;
@@ -883,7 +916,7 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
 
     double *x_dev = host ? hx : x;
     const int64_t sx_dev = host ? (int64_t)n : stride_x;
-    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig, wmid);
+    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig, wmid, wg_shape);
     if (rc != QPN_OK) return rc;
     if (host) {
         if (z) HIPCHK(ctx, hipMemcpyAsync(z, d.z, bN * 8, hipMemcpyDeviceToHost, s));

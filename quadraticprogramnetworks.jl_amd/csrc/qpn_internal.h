@@ -114,6 +114,10 @@ bool qpn_schur_mid_shape(int n, int m);
 size_t qpn_schur_mid_workspace_bytes(int batch, int n, int m);
 hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream_t stream);   // a.nd set; declined nodes keep status -1
 
+// qpn_avi_schur_wg.hip: the same node records in ONE fused workgroup kernel (crash, Lemke, read-back, post-check; no workspace)
+bool qpn_schur_wg_shape(int n, int m);
+hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream);              // a.nd set; declined nodes keep status -1
+
 // qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
 hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,
                                       double *dbgh, hipStream_t stream);

@@ -439,6 +439,10 @@ class Engine:
         GPU; 0 switches it off.  An explicit hint (order_nodes_by_pivots / set_node_order) takes precedence."""
         self._chk(self.lib.qpn_ctx_set_auto_schedule(self.ctx, int(period)), "qpn_ctx_set_auto_schedule")
 
+    def set_option(self, option, value):
+        """Per-context route option (include/qpn_hip.h: QPN_OPT_*), e.g. set_option(OPT_MID_ROUTE, 2)."""
+        self._chk(self.lib.qpn_ctx_set_option(self.ctx, int(option), int(value)), "qpn_ctx_set_option")
+
     def set_node_order(self, order=None):
         """Install a caller-made permutation of the nodes as the schedule (None clears the hint)."""
         if order is None:

@@ -1,9 +1,10 @@
-"""Mid-size node records (n, m <= 64, one of them > 32): the four-wavefronts-per-node path of
-csrc/qpn_avi_schur_mid.hip (crash on the matrix cores straight from the records, Schur problem on the register kernel,
-post-check from the records) against
+"""Mid-size node records (n, m <= 64, one of them > 32): the fused one-workgroup-per-node kernel of
+csrc/qpn_avi_schur_wg.hip (crash on the matrix cores straight from the records, Lemke spread over the workgroup's
+wavefronts, read-back and post-check from the records: ONE launch, no workspace) against
 * the oracle (status, active-set masks bit-exact, primals within 1e-9 relative: the bar of DESIGN.md section 2),
-* the route these sizes took before (QPN_NODES_MID=0: assembled blocks + the workgroup crash of the large nodes): same
-  statuses and masks, primals within 1e-9 (summation order differs),
+* the two routes these sizes took before (qpn_ctx_set_option QPN_OPT_MID_ROUTE = 2: round 2's three kernels with an HBM
+  workspace; = 0: assembled blocks + the workgroup crash of the large nodes): same statuses and masks, primals within 1e-9
+  (summation order differs),
 * the independent check kernel on stand-alone assembled blocks (A3, src/avi.jl:148-156),
 and its decline handling: nodes whose leading 4 x 4 block of Qd fails the no-pivoting test, and nodes with an equality
 row, go to the general kernel inside the same call."""
@@ -53,13 +54,16 @@ def test_mid_nodes_against_oracle_and_previous_route(engine, oracle, n, m, p):
     assert np.all(res["status"] == 1)
     ref = _oracle(oracle, rec, w)
     _same(res, ref)
-    os.environ["QPN_NODES_MID"] = "0"
-    try:
-        old = engine.solve_nodes(*abi, w)
-    finally:
-        del os.environ["QPN_NODES_MID"]
-    assert np.array_equal(res["status"], old["status"]) and np.array_equal(res["active"], old["active"])
-    assert np.max(np.abs(res["z"] - old["z"])) <= 1e-9 * max(1.0, np.max(np.abs(old["z"])))
+    from qpn_amd._lib import OPT_MID_ROUTE
+    for route in (2, 0):
+        engine.set_option(OPT_MID_ROUTE, route)
+        try:
+            old = engine.solve_nodes(*abi, w)
+        finally:
+            engine.set_option(OPT_MID_ROUTE, 1)
+        assert np.array_equal(res["status"], old["status"]) and np.array_equal(res["active"], old["active"]), route
+        assert np.max(np.abs(res["z"] - old["z"])) <= 1e-9 * max(1.0, np.max(np.abs(old["z"]))), route
+        assert np.array_equal(res["pivots"], old["pivots"]), route
     assert np.max(res["resid"]) <= 1e-8
     # independent certificate: check kernel on blocks from the stand-alone assembly kernel
     Mc, q, lo, hi, kind = engine.assemble_nodes(*abi, w)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: random node shapes of the mid-size class (n, m <= 64, one of them > 32), mixed bound kinds, the
-four-wavefronts-per-node route against the large-item route (QPN_NODES_MID=0) on the same records: statuses and
-active-set masks equal, primals within 1e-9 relative.  Usage: python tools/mid_fuzz.py [trials]"""
+fused one-workgroup-per-node kernel against round 2's three-kernel route (QPN_OPT_MID_ROUTE = 2) on the same records:
+statuses and active-set masks equal, primals within 1e-9 relative.  Usage: python tools/mid_fuzz.py [trials]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -9,6 +9,7 @@ import numpy as np
 import qpn_amd
 import problems as P
 from qpn_amd.engine import colmajor
+from qpn_amd._lib import OPT_MID_ROUTE
 eng = qpn_amd.Engine(0)
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(2024)
@@ -32,11 +33,11 @@ for t in range(trials):
     abi = [colmajor(Q), colmajor(Rm), qd, colmajor(A), colmajor(B), l, u]
     w = rng.standard_normal(p)
     new = eng.solve_nodes(*abi, w)
-    os.environ["QPN_NODES_MID"] = "0"
+    eng.set_option(OPT_MID_ROUTE, 2)
     try:
         old = eng.solve_nodes(*abi, w)
     finally:
-        del os.environ["QPN_NODES_MID"]
+        eng.set_option(OPT_MID_ROUTE, 1)
     assert np.array_equal(new["status"], old["status"]), (t, n, m, p, new["status"], old["status"])
     ok = new["status"] == 1
     assert np.array_equal(new["active"][ok], old["active"][ok]), (t, n, m, p)
