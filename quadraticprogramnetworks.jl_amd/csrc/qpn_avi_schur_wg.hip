@@ -386,7 +386,6 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
         if (l < 16) sH[16 * v + l] = kx;
     }
     __syncthreads();
-    STAMP(4);   // W~ hand-over
 
     // ---- S = Ad W~ (row tile v), c = b - Ad h ------------------------------------------------------------------
     d4 s0 = z4, s1 = z4, s2 = z4, s3 = z4, sx = z4;
@@ -434,12 +433,15 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
             if (lc == 0) sucol[64 + 16 * v + 4 * g + lq] = sx[g];
     }
     __syncthreads();
-    d16 T;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) T[j] = (v < mct && l < m_pad) ? sS[(16 * v + j) * LDS_ + l] : 0.0;
+    // the dictionary columns of this wave: sixteen NAMED scalars (never an array or a vector: every dynamic select of one of
+    // them happens inside an asm dispatch on a scalar index, so the compiler never copies or spills the set)
+#define TD(j) td_##j
+#define FOR_T(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define M_TLOAD(j) double TD(j) = (v < mct && l < m_pad) ? sS[(16 * v + (j)) * LDS_ + l] : 0.0;
+    FOR_T(M_TLOAD)
+#undef M_TLOAD
     double xb = actb ? sucol[64 + l] : 0.0;
     __syncthreads();                                   // S has been read: Ad for the post-check goes into the same area
-    STAMP(5);   // S product + transposition
 
     l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
     // Ad for the post-check: requested now (coalesced), parked in LDS
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
     if (v == 0) { sLo[l] = lo; sHi[l] = hi; }
     int satv = 0;
     __syncthreads();
+    STAMP(4);   // W~ hand-over, S product, transposition, Ad staging
     int rowvar = actb ? l : -1, colvar = actb ? NBP + l : -1;
     int cvx = VTH;
     double nbx = 0.0, nbval = 0.0, tcol = 0.0;
@@ -511,6 +514,41 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
             status = QPN_MAX_ITERS;
         }
     }
+    // sixteen-way scalar dispatch on a wave-uniform index (0..15; anything else: nothing): LEAF(k) names register k statically
+#define T_OPS_RW [t0] "+v"(TD(0)), [t1] "+v"(TD(1)), [t2] "+v"(TD(2)), [t3] "+v"(TD(3)), [t4] "+v"(TD(4)), [t5] "+v"(TD(5)),       \
+                 [t6] "+v"(TD(6)), [t7] "+v"(TD(7)), [t8] "+v"(TD(8)), [t9] "+v"(TD(9)), [t10] "+v"(TD(10)), [t11] "+v"(TD(11)),   \
+                 [t12] "+v"(TD(12)), [t13] "+v"(TD(13)), [t14] "+v"(TD(14)), [t15] "+v"(TD(15))
+#define T_OPS_R [t0] "v"(TD(0)), [t1] "v"(TD(1)), [t2] "v"(TD(2)), [t3] "v"(TD(3)), [t4] "v"(TD(4)), [t5] "v"(TD(5)),             \
+                [t6] "v"(TD(6)), [t7] "v"(TD(7)), [t8] "v"(TD(8)), [t9] "v"(TD(9)), [t10] "v"(TD(10)), [t11] "v"(TD(11)),         \
+                [t12] "v"(TD(12)), [t13] "v"(TD(13)), [t14] "v"(TD(14)), [t15] "v"(TD(15))
+#define DISPATCH16(P, L0, L1, L2, L3, L4, L5, L6, L7, L8, L9, L10, L11, L12, L13, L14, L15)                                        \
+    "s_cmp_gt_u32 %[cs], 7\n\ts_cbranch_scc1 ." P "_hi%=\n\t"                                                                      \
+    "s_cmp_gt_u32 %[cs], 3\n\ts_cbranch_scc1 ." P "_4%=\n\t"                                                                       \
+    "s_cmp_gt_u32 %[cs], 1\n\ts_cbranch_scc1 ." P "_2%=\n\t"                                                                       \
+    "s_cmp_eq_u32 %[cs], 0\n\ts_cbranch_scc0 ." P "_1%=\n\t"                                                                       \
+    L0 "\n\ts_branch ." P "_end%=\n"                                                                                               \
+    "." P "_1%=:\n\t" L1 "\n\ts_branch ." P "_end%=\n"                                                                             \
+    "." P "_2%=:\n\ts_cmp_eq_u32 %[cs], 2\n\ts_cbranch_scc0 ." P "_3%=\n\t" L2 "\n\ts_branch ." P "_end%=\n"                        \
+    "." P "_3%=:\n\t" L3 "\n\ts_branch ." P "_end%=\n"                                                                             \
+    "." P "_4%=:\n\ts_cmp_gt_u32 %[cs], 5\n\ts_cbranch_scc1 ." P "_6%=\n\t"                                                        \
+    "s_cmp_eq_u32 %[cs], 4\n\ts_cbranch_scc0 ." P "_5%=\n\t" L4 "\n\ts_branch ." P "_end%=\n"                                      \
+    "." P "_5%=:\n\t" L5 "\n\ts_branch ." P "_end%=\n"                                                                             \
+    "." P "_6%=:\n\ts_cmp_eq_u32 %[cs], 6\n\ts_cbranch_scc0 ." P "_7%=\n\t" L6 "\n\ts_branch ." P "_end%=\n"                        \
+    "." P "_7%=:\n\t" L7 "\n\ts_branch ." P "_end%=\n"                                                                             \
+    "." P "_hi%=:\n\ts_cmp_gt_u32 %[cs], 15\n\ts_cbranch_scc1 ." P "_end%=\n\t"                                                    \
+    "s_cmp_gt_u32 %[cs], 11\n\ts_cbranch_scc1 ." P "_12%=\n\t"                                                                     \
+    "s_cmp_gt_u32 %[cs], 9\n\ts_cbranch_scc1 ." P "_10%=\n\t"                                                                      \
+    "s_cmp_eq_u32 %[cs], 8\n\ts_cbranch_scc0 ." P "_9%=\n\t" L8 "\n\ts_branch ." P "_end%=\n"                                      \
+    "." P "_9%=:\n\t" L9 "\n\ts_branch ." P "_end%=\n"                                                                             \
+    "." P "_10%=:\n\ts_cmp_eq_u32 %[cs], 10\n\ts_cbranch_scc0 ." P "_11%=\n\t" L10 "\n\ts_branch ." P "_end%=\n"                    \
+    "." P "_11%=:\n\t" L11 "\n\ts_branch ." P "_end%=\n"                                                                           \
+    "." P "_12%=:\n\ts_cmp_gt_u32 %[cs], 13\n\ts_cbranch_scc1 ." P "_14%=\n\t"                                                     \
+    "s_cmp_eq_u32 %[cs], 12\n\ts_cbranch_scc0 ." P "_13%=\n\t" L12 "\n\ts_branch ." P "_end%=\n"                                   \
+    "." P "_13%=:\n\t" L13 "\n\ts_branch ." P "_end%=\n"                                                                           \
+    "." P "_14%=:\n\ts_cmp_eq_u32 %[cs], 14\n\ts_cbranch_scc0 ." P "_15%=\n\t" L14 "\n\ts_branch ." P "_end%=\n"                    \
+    "." P "_15%=:\n\t" L15 "\n"                                                                                                    \
+    "." P "_end%=:\n\t"
+    int cnext = XC;
     while (status == QPN_MAX_ITERS) {
         if (pivots >= max_piv) break;
         c = uni(c);
@@ -518,12 +556,23 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
         double cm;
         if (c == XC) cm = tcol;
         else {
-            if (v == (c >> 4)) sucol[par * 64 + l] = T[c & 15];
+            const int csel = uni(v == (c >> 4) ? (c & 15) : 16);
+            double *const dst = sucol + par * 64 + l;
+            asm volatile(DISPATCH16("Lwgp", "ds_write_b64 %[ad], %[t0]", "ds_write_b64 %[ad], %[t1]", "ds_write_b64 %[ad], %[t2]",
+                                    "ds_write_b64 %[ad], %[t3]", "ds_write_b64 %[ad], %[t4]", "ds_write_b64 %[ad], %[t5]",
+                                    "ds_write_b64 %[ad], %[t6]", "ds_write_b64 %[ad], %[t7]", "ds_write_b64 %[ad], %[t8]",
+                                    "ds_write_b64 %[ad], %[t9]", "ds_write_b64 %[ad], %[t10]", "ds_write_b64 %[ad], %[t11]",
+                                    "ds_write_b64 %[ad], %[t12]", "ds_write_b64 %[ad], %[t13]", "ds_write_b64 %[ad], %[t14]",
+                                    "ds_write_b64 %[ad], %[t15]")
+                         "s_waitcnt lgkmcnt(0)"         /* the compiler does not see this store: the barrier below must */
+                         :
+                         : T_OPS_R, [cs] "s"(csel), [ad] "v"((unsigned)(size_t)(__attribute__((address_space(3))) double *)dst)
+                         : "scc", "memory");
             __syncthreads();
             cm = sucol[par * 64 + l];
             par ^= 1;
         }
-        STAMP(6);
+        STAMP(5);   // entering column through LDS + the barrier
         // ---- ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
         const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
         const double rc = rcp64(gdir);
@@ -539,68 +588,110 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
         const double dmax = wave_min64_with_limit_f64(d1, self_lim);
         if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; break; }
         const unsigned long long bal = qpn_ballot(dd <= dmax);
+        // Both outcomes below end in the SAME exchange tail (a bound flip runs it with an empty lane mask, a zero multiplier
+        // and no column to rewrite: a no-op), so every dictionary register and every bookkeeping vector has ONE definition
+        // per iteration -- nothing is copied around a branch.
+        const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);      // the entering variable
+        const double eloW = elo, ehiW = ehi;                            // ... and the interval it lives in once basic
+        unsigned long long mrow = 0ull;
+        double inv = 1.0, delta, vx = 0.0, tc0 = tcol, enter_val = 0.0;
+        int rs = 0, rW = -1, cW = -1, kW = -1, auW = 0, vlW = 0, csel = 16;
+        double nbW = 0.0;
+        bool stop = false, newx = false;
         if (bal == 0ull) {
             // the entering variable reaches its own opposite bound first: no basis change
-            const double dl = sneg ? -self_lim : self_lim;
-            if (actb) xb = fma(dl, cm, xb);
-            const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);
-            if (ve == VTH) {
-                if (c == XC) nbx = 0.0; else if (l == c) nbval = 0.0;
-                status = QPN_SUCCESS;
-                break;
+            delta = sneg ? -self_lim : self_lim;
+            vlW = ve;
+            if (ve == VTH) { cW = c; nbW = 0.0; newx = c == XC; status = QPN_SUCCESS; stop = true; }
+            else {
+                const int k = ve;
+                const int au = sneg ? 0 : 1;
+                nbW = udbl(au ? sHi[k] : sLo[k]);
+                kW = k; auW = au; cW = c; newx = c == XC;
+                pivots++;
+                sneg = au != 0;
+                self_lim = QINF;
+                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+                // (the column of d_k: the bookkeeping vectors do not change in a flip, so the search can run here)
+                cnext = col_of(NBP + k);
+                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
             }
-            const int k = ve;
-            const int au = sneg ? 0 : 1;
-            const double nbW = udbl(au ? sHi[k] : sLo[k]);
-            if (l == k) satv = au;
-            if (c == XC) nbx = nbW; else if (l == c) nbval = nbW;
+        } else {
+            int r;
+            if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
+            else {
+                const bool cand = dd <= dmax;
+                double ag = cand ? fabs(gdir) : -1.0;
+                if (cand && rowvar == VTH) ag = QINF;
+                const double bestg = wave_max_f64(ag);
+                r = wave_first(cand && ag == bestg);
+            }
+            r = uni(r);
+            double step = readlane_f64(dd, r);
+            if (step < 0.0) step = 0.0;
+            const double leave_val = readlane_f64(tb, r);
+            const double rcr = readlane_f64(rc, r);
+            inv = sneg ? -rcr : rcr;                            // 1 / T[r][c]
+            delta = sneg ? -step : step;
+            const int vl = readlane_i32(rowvar, r);
+            enter_val = ((c == XC) ? nbx : readlane_f64(nbval, c)) + delta;
+            // the extra column (scalar statement: prow = T[r][.] * inv; T[i][.] = fma(-cm_i, prow, T[i][.]); row r: -prow; the
+            // pivot column's own entries start from 0 and its slot in the row carries -inv)
+            if (c == XC) { vx = -inv; tc0 = 0.0; } else vx = readlane_f64(tcol, r) * inv;
+            mrow = 1ull << r; rs = r;
+            csel = (c != XC && v == (c >> 4)) ? (c & 15) : 16;
+            rW = r; cW = c; vlW = vl; nbW = leave_val; newx = c == XC;
             pivots++;
-            c = col_of(NBP + k);
-            if (c < 0) { status = QPN_FAILURE; break; }
-            sneg = au != 0;
-            self_lim = QINF;
-            if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
-            continue;
+            if (vl == VTH) { status = QPN_SUCCESS; stop = true; }
+            else {
+                int vn;
+                const int k = vl < NBP ? vl : vl - NBP;
+                const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
+                const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
+                if (vl < NBP) {
+                    // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters from 0
+                    const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
+                    kW = k; auW = au;
+                    vn = NBP + k;
+                    sneg = au != 0;
+                    self_lim = QINF;
+                    if (cls == 2) { elo = 0.0; ehi = 0.0; }
+                    else if (au) { elo = -QINF; ehi = 0.0; }
+                    else { elo = 0.0; ehi = QINF; }
+                } else {
+                    // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                    const int au = readlane_i32(satv, k);
+                    vn = k;
+                    sneg = au != 0;
+                    self_lim = udbl(hk0 - lk0);                 // +inf for a free pair
+                    if (cls == 2) sneg = false;
+                    elo = lk0; ehi = hk0;
+                }
+                // (colvar / cvx still hold the entering id at column c here -- the write-back is below --, which is never vn's;
+                //  the id that lands there, vl, is never its own complement vn either)
+                cnext = (vn == ve) ? -1 : col_of(vn);
+                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
+            }
         }
-        int r;
-        if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
-        else {
-            const bool cand = dd <= dmax;
-            double ag = cand ? fabs(gdir) : -1.0;
-            if (cand && rowvar == VTH) ag = QINF;
-            const double bestg = wave_max_f64(ag);
-            r = wave_first(cand && ag == bestg);
-        }
-        r = uni(r);
-        STAMP(7);
-        double step = readlane_f64(dd, r);
-        if (step < 0.0) step = 0.0;
-        const double leave_val = readlane_f64(tb, r);
-        const double rcr = readlane_f64(rc, r);
-        const double inv = sneg ? -rcr : rcr;                   // 1 / T[r][c]
-        const double delta = sneg ? -step : step;
-        const int vl = readlane_i32(rowvar, r);
-        const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);
-        const double enter_val = ((c == XC) ? nbx : readlane_f64(nbval, c)) + delta;
-        const bool isr = l == r;
-        // values and the extra column (scalar statement: prow = T[r][.] * inv; T[i][.] = fma(-cm_i, prow, T[i][.]); row r: -prow)
+        // ---- the tail: values, the extra column, bookkeeping write-backs, the exchange
+        const bool isr = l == rW;
         {
             const double xbn = fma(delta, cm, xb);
+            const double tcn = fma(-cm, vx, tc0);
             xb = isr ? enter_val : xbn;
-            if (c == XC) {
-                const double tcn = cm * inv;
-                tcol = isr ? inv : tcn;
-            } else {
-                const double vx = readlane_f64(tcol, r) * inv;
-                const double tcn = fma(-cm, vx, tcol);
-                tcol = isr ? -vx : tcn;
-            }
+            tcol = isr ? -vx : tcn;
         }
-        // ---- the exchange on this wave's 16 columns
+        if (isr) { rowvar = ve; lo = eloW; hi = ehiW; }
         {
-            const unsigned long long mrow = 1ull << r;
+            const bool isc = !newx && l == cW;
+            if (isc) { colvar = vlW; nbval = nbW; }
+            if (newx) { cvx = vlW; nbx = nbW; }
+            if (l == kW) satv = auW;
+        }
+        if (stop) break;
+        {
+            // lane r: its row times 1 / pivot, in place (EXEC = that lane; none in a flip)
             const double inv_s = udbl(inv);
-            // lane r: its row times 1 / pivot, in place
             asm volatile("s_mov_b64 exec, %[mr]\n\t"
                          "v_mul_f64 %[t0], %[t0], %[iv]\n\tv_mul_f64 %[t1], %[t1], %[iv]\n\t"
                          "v_mul_f64 %[t2], %[t2], %[iv]\n\tv_mul_f64 %[t3], %[t3], %[iv]\n\t"
@@ -611,92 +702,36 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
                          "v_mul_f64 %[t12], %[t12], %[iv]\n\tv_mul_f64 %[t13], %[t13], %[iv]\n\t"
                          "v_mul_f64 %[t14], %[t14], %[iv]\n\tv_mul_f64 %[t15], %[t15], %[iv]\n\t"
                          "s_mov_b64 exec, -1"
-                         : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
-                           [t6] "+v"(T[6]), [t7] "+v"(T[7]), [t8] "+v"(T[8]), [t9] "+v"(T[9]), [t10] "+v"(T[10]), [t11] "+v"(T[11]),
-                           [t12] "+v"(T[12]), [t13] "+v"(T[13]), [t14] "+v"(T[14]), [t15] "+v"(T[15])
+                         : T_OPS_RW
                          : [mr] "s"(mrow), [iv] "s"(inv_s));
-            const double um = isr ? 2.0 : cm;                   // lane r: p - 2 p = -p, exact
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double pj = readlane_f64(T[j], r);
-                T[j] = fma(-um, pj, T[j]);
-            }
-            // column c of the new dictionary: T[i][c] = cm_i * inv, T[r][c] = inv -- on its owner, behind a scalar dispatch
-            const int csel = (c != XC && v == (c >> 4)) ? (c & 15) : 16;
+            // every lane: T[i][j] = fma(-cm_i, prow_j, T[i][j]); lane r runs it with 2 (p - 2 p = -p, exact), a flip with 0
+            double um = isr ? 2.0 : cm;
+            if (mrow == 0ull) um = 0.0;
+            const int rl = uni(rs);
+#define M_TX(j) { const double pj = readlane_f64(TD(j), rl); TD(j) = fma(-um, pj, TD(j)); }
+            FOR_T(M_TX)
+#undef M_TX
+            // column c of the new dictionary: T[i][c] = cm_i * inv, T[r][c] = inv -- on its owner, behind the scalar dispatch
             const double cv = isr ? inv : cm * inv;
-            asm volatile("s_cmp_gt_u32 %[cs], 7\n\ts_cbranch_scc1 .Lwgc_hi%=\n\t"
-                         "s_cmp_gt_u32 %[cs], 3\n\ts_cbranch_scc1 .Lwgc_4%=\n\t"
-                         "s_cmp_gt_u32 %[cs], 1\n\ts_cbranch_scc1 .Lwgc_2%=\n\t"
-                         "s_cmp_eq_u32 %[cs], 0\n\ts_cbranch_scc0 .Lwgc_1%=\n\t"
-                         "v_mov_b64 %[t0], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_1%=:\n\tv_mov_b64 %[t1], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_2%=:\n\ts_cmp_eq_u32 %[cs], 2\n\ts_cbranch_scc0 .Lwgc_3%=\n\t"
-                         "v_mov_b64 %[t2], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_3%=:\n\tv_mov_b64 %[t3], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_4%=:\n\ts_cmp_gt_u32 %[cs], 5\n\ts_cbranch_scc1 .Lwgc_6%=\n\t"
-                         "s_cmp_eq_u32 %[cs], 4\n\ts_cbranch_scc0 .Lwgc_5%=\n\t"
-                         "v_mov_b64 %[t4], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_5%=:\n\tv_mov_b64 %[t5], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_6%=:\n\ts_cmp_eq_u32 %[cs], 6\n\ts_cbranch_scc0 .Lwgc_7%=\n\t"
-                         "v_mov_b64 %[t6], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_7%=:\n\tv_mov_b64 %[t7], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_hi%=:\n\ts_cmp_gt_u32 %[cs], 15\n\ts_cbranch_scc1 .Lwgc_end%=\n\t"
-                         "s_cmp_gt_u32 %[cs], 11\n\ts_cbranch_scc1 .Lwgc_12%=\n\t"
-                         "s_cmp_gt_u32 %[cs], 9\n\ts_cbranch_scc1 .Lwgc_10%=\n\t"
-                         "s_cmp_eq_u32 %[cs], 8\n\ts_cbranch_scc0 .Lwgc_9%=\n\t"
-                         "v_mov_b64 %[t8], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_9%=:\n\tv_mov_b64 %[t9], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_10%=:\n\ts_cmp_eq_u32 %[cs], 10\n\ts_cbranch_scc0 .Lwgc_11%=\n\t"
-                         "v_mov_b64 %[t10], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_11%=:\n\tv_mov_b64 %[t11], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_12%=:\n\ts_cmp_gt_u32 %[cs], 13\n\ts_cbranch_scc1 .Lwgc_14%=\n\t"
-                         "s_cmp_eq_u32 %[cs], 12\n\ts_cbranch_scc0 .Lwgc_13%=\n\t"
-                         "v_mov_b64 %[t12], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_13%=:\n\tv_mov_b64 %[t13], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_14%=:\n\ts_cmp_eq_u32 %[cs], 14\n\ts_cbranch_scc0 .Lwgc_15%=\n\t"
-                         "v_mov_b64 %[t14], %[cv]\n\ts_branch .Lwgc_end%=\n"
-                         ".Lwgc_15%=:\n\tv_mov_b64 %[t15], %[cv]\n"
-                         ".Lwgc_end%=:"
-                         : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
-                           [t6] "+v"(T[6]), [t7] "+v"(T[7]), [t8] "+v"(T[8]), [t9] "+v"(T[9]), [t10] "+v"(T[10]), [t11] "+v"(T[11]),
-                           [t12] "+v"(T[12]), [t13] "+v"(T[13]), [t14] "+v"(T[14]), [t15] "+v"(T[15])
+            asm volatile(DISPATCH16("Lwgc", "v_mov_b64 %[t0], %[cv]", "v_mov_b64 %[t1], %[cv]", "v_mov_b64 %[t2], %[cv]",
+                                    "v_mov_b64 %[t3], %[cv]", "v_mov_b64 %[t4], %[cv]", "v_mov_b64 %[t5], %[cv]",
+                                    "v_mov_b64 %[t6], %[cv]", "v_mov_b64 %[t7], %[cv]", "v_mov_b64 %[t8], %[cv]",
+                                    "v_mov_b64 %[t9], %[cv]", "v_mov_b64 %[t10], %[cv]", "v_mov_b64 %[t11], %[cv]",
+                                    "v_mov_b64 %[t12], %[cv]", "v_mov_b64 %[t13], %[cv]", "v_mov_b64 %[t14], %[cv]",
+                                    "v_mov_b64 %[t15], %[cv]")
+                         "s_nop 0"
+                         : T_OPS_RW
                          : [cs] "s"(uni(csel)), [cv] "v"(cv)
                          : "scc");
         }
-        // ---- bookkeeping: row r now holds the entering variable, column c the leaving one
-        if (isr) { rowvar = ve; lo = elo; hi = ehi; }
-        if (c == XC) { cvx = vl; nbx = leave_val; }
-        else if (l == c) { colvar = vl; nbval = leave_val; }
-        pivots++;
-        if (vl == VTH) { status = QPN_SUCCESS; break; }
-        int vn;
-        {
-            const int k = vl < NBP ? vl : vl - NBP;
-            const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
-            const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
-            if (vl < NBP) {
-                // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters from 0
-                const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
-                if (l == k) satv = au;
-                vn = NBP + k;
-                sneg = au != 0;
-                self_lim = QINF;
-                if (cls == 2) { elo = 0.0; ehi = 0.0; }
-                else if (au) { elo = -QINF; ehi = 0.0; }
-                else { elo = 0.0; ehi = QINF; }
-            } else {
-                // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
-                const int au = readlane_i32(satv, k);
-                vn = k;
-                sneg = au != 0;
-                self_lim = udbl(hk0 - lk0);                     // +inf for a free pair
-                if (cls == 2) sneg = false;
-                elo = lk0; ehi = hk0;
-            }
-        }
-        c = col_of(vn);
-        if (c < 0) { status = QPN_FAILURE; break; }
+        c = cnext;
+        STAMP(6);   // ratio test, exchange, bookkeeping
     }
+#undef DISPATCH16
+#undef T_OPS_R
+#undef T_OPS_RW
+#undef FOR_T
+#undef TD
     STAMP(6);
 
     // ---- read back: lambda_k, then x = W~ lambda - h -------------------------------------------------------------
