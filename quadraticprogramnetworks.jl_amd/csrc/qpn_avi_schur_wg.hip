@@ -14,13 +14,14 @@
 //     pivoting, every pivot must pass |u_ss| >= 1e-4 max(1, max|M|), else the node is declined) and forms its entry of
 //     U' = U P^-1 in the A-operand layout: no second hand-over, one MFMA (NEG on A) per live tile.
 //   S = Ad W~ and c = b - Ad h: W~ crosses LDS once (it STAYS in the tile registers for the read-back), wave v computes row
-//     tile v of S; S is transposed through LDS into the Stage-B layout.
-//   Stage B (Lemke on the m x (m+1) Schur dictionary): wave v holds COLUMNS 16v .. 16v+15 with lane <-> row (16 entries per
-//     lane), every wave keeps the whole bookkeeping (row vectors lane <-> row, column vectors lane <-> column) and runs the
-//     ratio test itself on the entering column, which its owner publishes through LDS: ONE barrier per pivot and no
-//     cross-wave reduction -- all waves compute the same bits.  The exchange follows the scalar statement of the method
-//     (the CPU checker's do_pivot) operation by operation: lane r scales its row in place (EXEC = that lane), the scaled
-//     row goes to SGPRs with v_readlane, every lane runs T_ij = fma(-u_i, p_j, T_ij) with u_r = 2 (p - 2 p = -p, exact).
+//     tile v of S; the tiles change hands through LDS (row tiles -> column tiles) for Stage B.
+//   Stage B (Lemke on the m x (m+1) Schur dictionary): wave v holds COLUMN TILE v (all rows, columns 16v .. 16v+15) in the
+//     MFMA tile layout (4 MT entries per lane), as the 32-class kernel holds its 32 x 32 dictionary.  Wave 0 is the leader:
+//     it alone keeps the bookkeeping and runs the ratio test on the entering column, which the 4 lanes that hold it publish
+//     through LDS; the other waves wait for its decision {row, 1 / pivot, next column}: two barriers per pivot.  The rank-1
+//     exchange of a wave is 4 MT v_fma_f64 plus lane-masked fix-ups of the pivot column and row -- its piece of the pivot row
+//     travels through a wave-private LDS vector, no cross-lane instruction -- so a pivot costs the workgroup ~100 + 35 NW
+//     vector instructions instead of ~200 NW for a layout in which every wave runs the ratio test itself.
 //   Read-back x = W~ lambda - h from the tile registers (DPP butterflies), post-check / residual / masks on the ORIGINAL
 //     blocks: Qd re-read column-wise (coalesced, L2 / Infinity Cache), Ad staged in LDS.
 // Declined nodes (a block pivot below the threshold, an equality row) keep status -1 and take the general path in gated
@@ -416,31 +417,31 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
         }
     }
     __syncthreads();                                   // W~ in LDS has been read: S goes through the same area
-    // S into the Stage-B layout: column-major with stride m_pad + 1 (odd in doubles: both the tile-layout stores and the
-    // lane <-> row loads are conflict-free); c into the second column buffer (the first pivot publishes into buffer 0)
-    constexpr int LDS_ = m_pad + 1;
-    double *const sS = sm + OFF_BIG;
+    // ---- S from row tiles to COLUMN tiles: wave v hands tile (v, J) to wave J (lane-contiguous blocks: no transposition
+    // arithmetic, no bank conflicts); c goes to the leader
+    double *const sX = sm + OFF_BIG;
+    double *const colP = sm + OFF_COL;          // entering column, two buffers: row i at [i & 3][i >> 2], 16 doubles per i & 3
     if (v < mct) {
 #define M_SOUT(J, T)                                                                                \
     if constexpr ((J) < MT) {                                                                       \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                               \
-            sS[(16 * (J) + lc) * LDS_ + 16 * v + 4 * g + lq] = T[g];                                \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) sX[((v * MT + (J)) * 4 + g) * 64 + l] = T[g]; \
     }
         M_SOUT(0, s0) M_SOUT(1, s1) M_SOUT(2, s2) M_SOUT(3, s3)
 #undef M_SOUT
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            if (lc == 0) sucol[64 + 16 * v + 4 * g + lq] = sx[g];
+            if (lc == 0) colP[64 + 16 * v + 4 * g + lq] = sx[g];
     }
     __syncthreads();
-    // the dictionary columns of this wave: sixteen NAMED scalars (never an array or a vector: every dynamic select of one of
-    // them happens inside an asm dispatch on a scalar index, so the compiler never copies or spills the set)
+    // the dictionary tiles of this wave -- column tile v, rows 16 I + 4 g + lq, column 16 v + lc at register 4 I + g --:
+    // sixteen NAMED scalars (never an array or a vector: every dynamic select of one of them happens inside an asm dispatch
+    // on a scalar index, so the compiler never copies or spills the set)
 #define TD(j) td_##j
 #define FOR_T(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
-#define M_TLOAD(j) double TD(j) = (v < mct && l < m_pad) ? sS[(16 * v + (j)) * LDS_ + l] : 0.0;
+#define M_TLOAD(j) double TD(j) = ((j) < 4 * MT && v < mct) ? sX[((((j) >> 2) * MT + v) * 4 + ((j) & 3)) * 64 + l] : 0.0;
     FOR_T(M_TLOAD)
 #undef M_TLOAD
-    double xb = actb ? sucol[64 + l] : 0.0;
+    double xb = (v == 0 && actb) ? colP[64 + l] : 0.0;
     __syncthreads();                                   // S has been read: Ad for the post-check goes into the same area
 
     l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
@@ -464,18 +465,25 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
 
     // ================= Stage B: Lemke on the Schur dictionary =================
     // pair k (k < m) <-> item row n + k:  p_k = (S lambda + c)_k in [l_k, u_k],  d_k = lambda_k.
-    // ids: p_k -> k, d_k -> 64 + k, artificial -> 128; column index 64 = the extra (covering) column, kept as the row
-    // vector tcol (lane <-> row) with its bookkeeping in scalars (cvx, nbx).
+    // ids: p_k -> k, d_k -> 64 + k, artificial -> 128; column index 64 = the extra (covering) column.
+    // Wave 0 is the LEADER: it alone keeps the bookkeeping (row vectors lane <-> row, column vectors lane <-> column, the extra
+    // column as the row vector tcol) and runs the ratio test; the other waves only hold their tiles.  Per pivot:
+    //   the owner of the entering column publishes it (the 4 lanes that hold it; the leader for the extra column) -- barrier A --
+    //   the leader reads it lane <-> row, picks the row, does the bookkeeping and posts {what, row, 1 / pivot, next column} --
+    //   barrier B -- every wave runs the rank-1 exchange on its tiles as in the 32-class kernel: its piece of the pivot row
+    //   through a wave-private LDS vector (no barrier), its 4 MT column entries from the published column, 4 MT v_fma_f64, the
+    //   pivot column rescaled on its 4 owner lanes and the pivot row rewritten on its 16 owner lanes under EXEC masks.
     constexpr int NBP = 64, XC = 64, VTH = 128;
-    // bounds of pair l: the row's current interval in registers; the fixed pair bounds, which the bookkeeping looks up by a
-    // wave-uniform pair index once per pivot, in LDS (over the Stage-A scratch: seven registers less across the loop)
-    double *const sLo = sm + OFF_U, *const sHi = sm + OFF_U + 64;
+    constexpr int CODE_PIVOT = 0, CODE_FLIP = 1, CODE_STOP = 2;
+    double *const sLo = sm + OFF_U, *const sHi = sm + OFF_U + 64;      // fixed pair bounds (looked up by a uniform index)
+    double *const rowbuf = sm + OFF_U + 128 + 16 * v;                  // this wave's piece of the pivot row             [16]
+    double *const sDecD = sm + OFF_U + 192;                            // the leader's decision: 1 / pivot                [1]
+    int *const sDecI = reinterpret_cast<int *>(sm + OFF_U + 194);      // ... what, row, next column                      [4]
+    const bool lead = v == 0;
     double lo = -QINF, hi = QINF;
-    if (actb) { lo = a.nd.l[(size_t)b * m + l]; hi = a.nd.u[(size_t)b * m + l]; }
-    if (v == 0) { sLo[l] = lo; sHi[l] = hi; }
+    if (lead && actb) { lo = a.nd.l[(size_t)b * m + l]; hi = a.nd.u[(size_t)b * m + l]; }
+    if (lead) { sLo[l] = lo; sHi[l] = hi; }
     int satv = 0;
-    __syncthreads();
-    STAMP(4);   // W~ hand-over, S product, transposition, Ad staging
     int rowvar = actb ? l : -1, colvar = actb ? NBP + l : -1;
     int cvx = VTH;
     double nbx = 0.0, nbval = 0.0, tcol = 0.0;
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
         const int cc = wave_first(colvar == var);
         return cc >= 0 ? cc : (cvx == var ? XC : -1);
     };
-    {
+    if (lead) {
         double viol = 0.0;
         if (actb) viol = xb < lo ? lo - xb : (xb > hi ? xb - hi : 0.0);
         const double theta0 = wave_max_f64(viol);
@@ -513,8 +521,12 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
             self_lim = theta0;
             status = QPN_MAX_ITERS;
         }
+        if (l == 0) sDecI[0] = status == QPN_MAX_ITERS ? CODE_PIVOT : CODE_STOP;
     }
-    // sixteen-way scalar dispatch on a wave-uniform index (0..15; anything else: nothing): LEAF(k) names register k statically
+    __syncthreads();
+    STAMP(4);   // W~ hand-over, S product, tile hand-over, Ad staging
+    int code = uni(sDecI[0]);
+    // sixteen-way scalar dispatch on a wave-uniform index (0..15; anything else: nothing): leaf k names register k statically
 #define T_OPS_RW [t0] "+v"(TD(0)), [t1] "+v"(TD(1)), [t2] "+v"(TD(2)), [t3] "+v"(TD(3)), [t4] "+v"(TD(4)), [t5] "+v"(TD(5)),       \
                  [t6] "+v"(TD(6)), [t7] "+v"(TD(7)), [t8] "+v"(TD(8)), [t9] "+v"(TD(9)), [t10] "+v"(TD(10)), [t11] "+v"(TD(11)),   \
                  [t12] "+v"(TD(12)), [t13] "+v"(TD(13)), [t14] "+v"(TD(14)), [t15] "+v"(TD(15))
@@ -548,191 +560,220 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
     "." P "_14%=:\n\ts_cmp_eq_u32 %[cs], 14\n\ts_cbranch_scc0 ." P "_15%=\n\t" L14 "\n\ts_branch ." P "_end%=\n"                    \
     "." P "_15%=:\n\t" L15 "\n"                                                                                                    \
     "." P "_end%=:\n\t"
-    int cnext = XC;
-    while (status == QPN_MAX_ITERS) {
-        if (pivots >= max_piv) break;
+    while (code != CODE_STOP) {
         c = uni(c);
-        // ---- entering column: its owner publishes it (lane <-> row), every wave reads it
-        double cm;
-        if (c == XC) cm = tcol;
-        else {
-            const int csel = uni(v == (c >> 4) ? (c & 15) : 16);
-            double *const dst = sucol + par * 64 + l;
-            asm volatile(DISPATCH16("Lwgp", "ds_write_b64 %[ad], %[t0]", "ds_write_b64 %[ad], %[t1]", "ds_write_b64 %[ad], %[t2]",
-                                    "ds_write_b64 %[ad], %[t3]", "ds_write_b64 %[ad], %[t4]", "ds_write_b64 %[ad], %[t5]",
-                                    "ds_write_b64 %[ad], %[t6]", "ds_write_b64 %[ad], %[t7]", "ds_write_b64 %[ad], %[t8]",
-                                    "ds_write_b64 %[ad], %[t9]", "ds_write_b64 %[ad], %[t10]", "ds_write_b64 %[ad], %[t11]",
-                                    "ds_write_b64 %[ad], %[t12]", "ds_write_b64 %[ad], %[t13]", "ds_write_b64 %[ad], %[t14]",
-                                    "ds_write_b64 %[ad], %[t15]")
-                         "s_waitcnt lgkmcnt(0)"         /* the compiler does not see this store: the barrier below must */
-                         :
-                         : T_OPS_R, [cs] "s"(csel), [ad] "v"((unsigned)(size_t)(__attribute__((address_space(3))) double *)dst)
-                         : "scc", "memory");
-            __syncthreads();
-            cm = sucol[par * 64 + l];
-            par ^= 1;
+        // ---- the entering column, published by the lanes that hold it: row i goes to [i & 3][i >> 2]
+        {
+            double *const cp = colP + par * 64;
+            if (c == XC) { if (lead) cp[(l & 3) * 16 + (l >> 2)] = tcol; }
+            else if (v == (c >> 4) && lc == (c & 15)) {
+                d4 *const dst = reinterpret_cast<d4 *>(cp + lq * 16);
+                dst[0] = d4{TD(0), TD(1), TD(2), TD(3)};
+                if constexpr (MT > 1) dst[1] = d4{TD(4), TD(5), TD(6), TD(7)};
+                if constexpr (MT > 2) dst[2] = d4{TD(8), TD(9), TD(10), TD(11)};
+                if constexpr (MT > 3) dst[3] = d4{TD(12), TD(13), TD(14), TD(15)};
+            }
         }
-        STAMP(5);   // entering column through LDS + the barrier
-        // ---- ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
-        const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
-        const double rc = rcp64(gdir);
-        const bool gneg = __double2hiint(gdir) < 0;
-        const double tb = gneg ? lo : hi;                       // the bound the row's basic variable moves towards
+        __syncthreads();                                // barrier A
+        STAMP(5);   // entering column through LDS + barrier A
+        if (lead) {
+            // ================= the leader's turn: ratio test, bookkeeping, decision =================
+            const double cm = colP[par * 64 + (l & 3) * 16 + (l >> 2)];
+            // ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
+            const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
+            const double rc = rcp64(gdir);
+            const bool gneg = __double2hiint(gdir) < 0;
+            const double tb = gneg ? lo : hi;                   // the bound the row's basic variable moves towards
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
-        const bool cnd = (actb & (fabs(gdir) > ptol)) & (fabs(tb) < QINF);
+            const bool cnd = (actb & (fabs(gdir) > ptol)) & (fabs(tb) < QINF);
 #pragma clang diagnostic pop
-        const double arc = fabs(rc);
-        const double dd = cnd ? (tb - xb) * rc : QINF;
-        const double d1 = fma(slack, arc, dd);
-        const double dmax = wave_min64_with_limit_f64(d1, self_lim);
-        if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; break; }
-        const unsigned long long bal = qpn_ballot(dd <= dmax);
-        // Both outcomes below end in the SAME exchange tail (a bound flip runs it with an empty lane mask, a zero multiplier
-        // and no column to rewrite: a no-op), so every dictionary register and every bookkeeping vector has ONE definition
-        // per iteration -- nothing is copied around a branch.
-        const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);      // the entering variable
-        const double eloW = elo, ehiW = ehi;                            // ... and the interval it lives in once basic
-        unsigned long long mrow = 0ull;
-        double inv = 1.0, delta, vx = 0.0, tc0 = tcol, enter_val = 0.0;
-        int rs = 0, rW = -1, cW = -1, kW = -1, auW = 0, vlW = 0, csel = 16;
-        double nbW = 0.0;
-        bool stop = false, newx = false;
-        if (bal == 0ull) {
-            // the entering variable reaches its own opposite bound first: no basis change
-            delta = sneg ? -self_lim : self_lim;
-            vlW = ve;
-            if (ve == VTH) { cW = c; nbW = 0.0; newx = c == XC; status = QPN_SUCCESS; stop = true; }
+            const double arc = fabs(rc);
+            const double dd = cnd ? (tb - xb) * rc : QINF;
+            const double d1 = fma(slack, arc, dd);
+            const double dmax = wave_min64_with_limit_f64(d1, self_lim);
+            int dcode = CODE_PIVOT, r = 0, cnext = XC;
+            double inv = 0.0;
+            if (pivots >= max_piv) dcode = CODE_STOP;          // status stays MAX_ITERS
+            else if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; dcode = CODE_STOP; }
             else {
-                const int k = ve;
-                const int au = sneg ? 0 : 1;
-                nbW = udbl(au ? sHi[k] : sLo[k]);
-                kW = k; auW = au; cW = c; newx = c == XC;
-                pivots++;
-                sneg = au != 0;
-                self_lim = QINF;
-                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
-                // (the column of d_k: the bookkeeping vectors do not change in a flip, so the search can run here)
-                cnext = col_of(NBP + k);
-                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
-            }
-        } else {
-            int r;
-            if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
-            else {
-                const bool cand = dd <= dmax;
-                double ag = cand ? fabs(gdir) : -1.0;
-                if (cand && rowvar == VTH) ag = QINF;
-                const double bestg = wave_max_f64(ag);
-                r = wave_first(cand && ag == bestg);
-            }
-            r = uni(r);
-            double step = readlane_f64(dd, r);
-            if (step < 0.0) step = 0.0;
-            const double leave_val = readlane_f64(tb, r);
-            const double rcr = readlane_f64(rc, r);
-            inv = sneg ? -rcr : rcr;                            // 1 / T[r][c]
-            delta = sneg ? -step : step;
-            const int vl = readlane_i32(rowvar, r);
-            enter_val = ((c == XC) ? nbx : readlane_f64(nbval, c)) + delta;
-            // the extra column (scalar statement: prow = T[r][.] * inv; T[i][.] = fma(-cm_i, prow, T[i][.]); row r: -prow; the
-            // pivot column's own entries start from 0 and its slot in the row carries -inv)
-            if (c == XC) { vx = -inv; tc0 = 0.0; } else vx = readlane_f64(tcol, r) * inv;
-            mrow = 1ull << r; rs = r;
-            csel = (c != XC && v == (c >> 4)) ? (c & 15) : 16;
-            rW = r; cW = c; vlW = vl; nbW = leave_val; newx = c == XC;
-            pivots++;
-            if (vl == VTH) { status = QPN_SUCCESS; stop = true; }
-            else {
-                int vn;
-                const int k = vl < NBP ? vl : vl - NBP;
-                const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
-                const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
-                if (vl < NBP) {
-                    // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters from 0
-                    const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
-                    kW = k; auW = au;
-                    vn = NBP + k;
-                    sneg = au != 0;
-                    self_lim = QINF;
-                    if (cls == 2) { elo = 0.0; ehi = 0.0; }
-                    else if (au) { elo = -QINF; ehi = 0.0; }
-                    else { elo = 0.0; ehi = QINF; }
+                const unsigned long long bal = qpn_ballot(dd <= dmax);
+                const int ve = (c == XC) ? cvx : readlane_i32(colvar, c);      // the entering variable
+                const double eloW = elo, ehiW = ehi;                            // ... and the interval it lives in once basic
+                double delta, vx = 0.0, tc0 = tcol, enter_val = 0.0, nbW = 0.0;
+                int rW = -1, cW = -1, kW = -1, auW = 0, vlW = ve;
+                const bool newx = c == XC;
+                if (bal == 0ull) {
+                    // the entering variable reaches its own opposite bound first: no basis change
+                    dcode = CODE_FLIP;
+                    delta = sneg ? -self_lim : self_lim;
+                    cW = c;
+                    if (ve == VTH) { nbW = 0.0; status = QPN_SUCCESS; dcode = CODE_STOP; }
+                    else {
+                        const int k = ve;
+                        const int au = sneg ? 0 : 1;
+                        nbW = udbl(au ? sHi[k] : sLo[k]);
+                        kW = k; auW = au;
+                        pivots++;
+                        sneg = au != 0;
+                        self_lim = QINF;
+                        if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+                        // (the column of d_k: the bookkeeping vectors do not change in a flip, so the search can run here)
+                        cnext = col_of(NBP + k);
+                        if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
+                    }
                 } else {
-                    // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
-                    const int au = readlane_i32(satv, k);
-                    vn = k;
-                    sneg = au != 0;
-                    self_lim = udbl(hk0 - lk0);                 // +inf for a free pair
-                    if (cls == 2) sneg = false;
-                    elo = lk0; ehi = hk0;
+                    if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
+                    else {
+                        const bool cand = dd <= dmax;
+                        double ag = cand ? fabs(gdir) : -1.0;
+                        if (cand && rowvar == VTH) ag = QINF;
+                        const double bestg = wave_max_f64(ag);
+                        r = wave_first(cand && ag == bestg);
+                    }
+                    r = uni(r);
+                    double step = readlane_f64(dd, r);
+                    if (step < 0.0) step = 0.0;
+                    const double leave_val = readlane_f64(tb, r);
+                    const double rcr = readlane_f64(rc, r);
+                    inv = sneg ? -rcr : rcr;                    // 1 / T[r][c]
+                    delta = sneg ? -step : step;
+                    const int vl = readlane_i32(rowvar, r);
+                    enter_val = (newx ? nbx : readlane_f64(nbval, c)) + delta;
+                    // the extra column (scalar statement: prow = T[r][.] * inv; T[i][.] = fma(-cm_i, prow, T[i][.]); row r:
+                    // -prow; the pivot column's own entries start from 0 and its slot in the row carries -inv)
+                    if (newx) { vx = -inv; tc0 = 0.0; } else vx = readlane_f64(tcol, r) * inv;
+                    rW = r; cW = c; vlW = vl; nbW = leave_val;
+                    pivots++;
+                    if (vl == VTH) { status = QPN_SUCCESS; dcode = CODE_STOP; }
+                    else {
+                        int vn;
+                        const int k = vl < NBP ? vl : vl - NBP;
+                        const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
+                        const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
+                        if (vl < NBP) {
+                            // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters
+                            const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
+                            kW = k; auW = au;
+                            vn = NBP + k;
+                            sneg = au != 0;
+                            self_lim = QINF;
+                            if (cls == 2) { elo = 0.0; ehi = 0.0; }
+                            else if (au) { elo = -QINF; ehi = 0.0; }
+                            else { elo = 0.0; ehi = QINF; }
+                        } else {
+                            // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                            const int au = readlane_i32(satv, k);
+                            vn = k;
+                            sneg = au != 0;
+                            self_lim = udbl(hk0 - lk0);         // +inf for a free pair
+                            if (cls == 2) sneg = false;
+                            elo = lk0; ehi = hk0;
+                        }
+                        // (colvar / cvx still hold the entering id at column c here -- the write-back is below --, which is
+                        //  never vn's; the id that lands there, vl, is never its own complement vn either)
+                        cnext = (vn == ve) ? -1 : col_of(vn);
+                        if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
+                    }
                 }
-                // (colvar / cvx still hold the entering id at column c here -- the write-back is below --, which is never vn's;
-                //  the id that lands there, vl, is never its own complement vn either)
-                cnext = (vn == ve) ? -1 : col_of(vn);
-                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
+                // values, the extra column, bookkeeping write-backs (one definition of every vector per iteration)
+                const bool isr = l == rW;
+                {
+                    const double xbn = fma(delta, cm, xb);
+                    const double tcn = fma(-cm, vx, tc0);
+                    xb = isr ? enter_val : xbn;
+                    tcol = isr ? -vx : tcn;
+                }
+                if (isr) { rowvar = ve; lo = eloW; hi = ehiW; }
+                {
+                    const bool isc = !newx && l == cW;
+                    if (isc) { colvar = vlW; nbval = nbW; }
+                    if (newx) { cvx = vlW; nbx = nbW; }
+                    if (l == kW) satv = auW;
+                }
             }
+            if (l == 0) { sDecI[0] = dcode; sDecI[1] = r; sDecI[2] = cnext; sDecD[0] = inv; }
         }
-        // ---- the tail: values, the extra column, bookkeeping write-backs, the exchange
-        const bool isr = l == rW;
+        __syncthreads();                                // barrier B
+        STAMP(6);   // the leader's turn + barrier B
+        code = uni(sDecI[0]);
+        const int r = uni(sDecI[1]), cnext = uni(sDecI[2]);
+        const double inv = udbl(sDecD[0]);
+        if (code == CODE_STOP) break;
+        // ---- the exchange (a flip runs it with empty lane masks and a zero row: a no-op, so the tile registers have one
+        // definition per iteration)
         {
-            const double xbn = fma(delta, cm, xb);
-            const double tcn = fma(-cm, vx, tc0);
-            xb = isr ? enter_val : xbn;
-            tcol = isr ? -vx : tcn;
-        }
-        if (isr) { rowvar = ve; lo = eloW; hi = ehiW; }
-        {
-            const bool isc = !newx && l == cW;
-            if (isc) { colvar = vlW; nbval = nbW; }
-            if (newx) { cvx = vlW; nbx = nbW; }
-            if (l == kW) satv = auW;
-        }
-        if (stop) break;
-        {
-            // lane r: its row times 1 / pivot, in place (EXEC = that lane; none in a flip)
+            const bool piv = code == CODE_PIVOT;
+            const int rq = r & 3, rsel = piv ? (r >> 2) : 16;
+            const bool own = piv && c != XC && v == (c >> 4);
+            const unsigned long long mrow = piv ? 0xFFFFull << (16 * rq) : 0ull;
+            const unsigned long long mcol = own ? 0x0001000100010001ull << (c & 15) : 0ull;
+            // this wave's piece of the pivot row: the 16 lanes that hold it pick the register under the scalar dispatch
+            {
+                double *const dst = rowbuf + lc;
+                asm volatile("s_mov_b64 exec, %[mr]\n\t"
+                             DISPATCH16("Lwgr", "ds_write_b64 %[ad], %[t0]", "ds_write_b64 %[ad], %[t1]", "ds_write_b64 %[ad], %[t2]",
+                                        "ds_write_b64 %[ad], %[t3]", "ds_write_b64 %[ad], %[t4]", "ds_write_b64 %[ad], %[t5]",
+                                        "ds_write_b64 %[ad], %[t6]", "ds_write_b64 %[ad], %[t7]", "ds_write_b64 %[ad], %[t8]",
+                                        "ds_write_b64 %[ad], %[t9]", "ds_write_b64 %[ad], %[t10]", "ds_write_b64 %[ad], %[t11]",
+                                        "ds_write_b64 %[ad], %[t12]", "ds_write_b64 %[ad], %[t13]", "ds_write_b64 %[ad], %[t14]",
+                                        "ds_write_b64 %[ad], %[t15]")
+                             "s_mov_b64 exec, -1"
+                             :
+                             : T_OPS_R, [cs] "s"(uni(rsel)), [mr] "s"(mrow),
+                               [ad] "v"((unsigned)(size_t)(__attribute__((address_space(3))) double *)dst)
+                             : "scc", "memory");
+                // the entry of the pivot column itself is replaced by -1, so that row * inv carries -inv there (what the
+                // exchange needs) without any select
+                if (own && l == 16 * rq + (c & 15)) rowbuf[c & 15] = -1.0;
+            }
+            wave_sync();
+            const double pv = piv ? rowbuf[lc] * inv : 0.0;
+            // this lane's column entries: rows lq + 4 k, k = 4 I + g
+            const d4 *const up = reinterpret_cast<const d4 *>(colP + par * 64 + lq * 16);
+            const d4 u0 = up[0], u1 = MT > 1 ? up[1] : z4, u2 = MT > 2 ? up[2] : z4, u3 = MT > 3 ? up[3] : z4;
             const double inv_s = udbl(inv);
+#define M_XCHG8(A0, A1, A2, A3, A4, A5, A6, A7, UA, UB)                                                                                                    \
+            asm volatile("v_fma_f64 %[a0], -%[u0], %[pv], %[a0]\n\tv_fma_f64 %[a1], -%[u1], %[pv], %[a1]\n\t"                      \
+                         "v_fma_f64 %[a2], -%[u2], %[pv], %[a2]\n\tv_fma_f64 %[a3], -%[u3], %[pv], %[a3]\n\t"                      \
+                         "v_fma_f64 %[a4], -%[u4], %[pv], %[a4]\n\tv_fma_f64 %[a5], -%[u5], %[pv], %[a5]\n\t"                      \
+                         "v_fma_f64 %[a6], -%[u6], %[pv], %[a6]\n\tv_fma_f64 %[a7], -%[u7], %[pv], %[a7]\n\t"                      \
+                         /* column c: T[i][c] = u_i * inv on the 4 lanes that own it */                                            \
+                         "s_mov_b64 exec, %[mc]\n\ts_cbranch_execz .Lwgx_e%=\n\t"                                                  \
+                         "v_mul_f64 %[a0], %[u0], %[iv]\n\tv_mul_f64 %[a1], %[u1], %[iv]\n\t"                                      \
+                         "v_mul_f64 %[a2], %[u2], %[iv]\n\tv_mul_f64 %[a3], %[u3], %[iv]\n\t"                                      \
+                         "v_mul_f64 %[a4], %[u4], %[iv]\n\tv_mul_f64 %[a5], %[u5], %[iv]\n\t"                                      \
+                         "v_mul_f64 %[a6], %[u6], %[iv]\n\tv_mul_f64 %[a7], %[u7], %[iv]\n"                                        \
+                         ".Lwgx_e%=:\n\ts_mov_b64 exec, -1"                                                                        \
+                         : [a0] "+v"(TD(A0)), [a1] "+v"(TD(A1)), [a2] "+v"(TD(A2)), [a3] "+v"(TD(A3)),                             \
+                           [a4] "+v"(TD(A4)), [a5] "+v"(TD(A5)), [a6] "+v"(TD(A6)), [a7] "+v"(TD(A7))                              \
+                         : [u0] "v"(UA[0]), [u1] "v"(UA[1]), [u2] "v"(UA[2]), [u3] "v"(UA[3]), [u4] "v"(UB[0]), [u5] "v"(UB[1]),  \
+                           [u6] "v"(UB[2]), [u7] "v"(UB[3]), [pv] "v"(pv), [iv] "s"(inv_s), [mc] "s"(mcol));
+            M_XCHG8(0, 1, 2, 3, 4, 5, 6, 7, u0, u1)
+            if constexpr (MT > 2) { M_XCHG8(8, 9, 10, 11, 12, 13, 14, 15, u2, u3) }
+#undef M_XCHG8
+            // row r: T[r][j] = -pv_j on the 16 lanes that own it (pv carries -inv at column c)
             asm volatile("s_mov_b64 exec, %[mr]\n\t"
-                         "v_mul_f64 %[t0], %[t0], %[iv]\n\tv_mul_f64 %[t1], %[t1], %[iv]\n\t"
-                         "v_mul_f64 %[t2], %[t2], %[iv]\n\tv_mul_f64 %[t3], %[t3], %[iv]\n\t"
-                         "v_mul_f64 %[t4], %[t4], %[iv]\n\tv_mul_f64 %[t5], %[t5], %[iv]\n\t"
-                         "v_mul_f64 %[t6], %[t6], %[iv]\n\tv_mul_f64 %[t7], %[t7], %[iv]\n\t"
-                         "v_mul_f64 %[t8], %[t8], %[iv]\n\tv_mul_f64 %[t9], %[t9], %[iv]\n\t"
-                         "v_mul_f64 %[t10], %[t10], %[iv]\n\tv_mul_f64 %[t11], %[t11], %[iv]\n\t"
-                         "v_mul_f64 %[t12], %[t12], %[iv]\n\tv_mul_f64 %[t13], %[t13], %[iv]\n\t"
-                         "v_mul_f64 %[t14], %[t14], %[iv]\n\tv_mul_f64 %[t15], %[t15], %[iv]\n\t"
+                         DISPATCH16("Lwgf", "v_mul_f64 %[t0], %[pv], -1.0", "v_mul_f64 %[t1], %[pv], -1.0", "v_mul_f64 %[t2], %[pv], -1.0",
+                                    "v_mul_f64 %[t3], %[pv], -1.0", "v_mul_f64 %[t4], %[pv], -1.0", "v_mul_f64 %[t5], %[pv], -1.0",
+                                    "v_mul_f64 %[t6], %[pv], -1.0", "v_mul_f64 %[t7], %[pv], -1.0", "v_mul_f64 %[t8], %[pv], -1.0",
+                                    "v_mul_f64 %[t9], %[pv], -1.0", "v_mul_f64 %[t10], %[pv], -1.0", "v_mul_f64 %[t11], %[pv], -1.0",
+                                    "v_mul_f64 %[t12], %[pv], -1.0", "v_mul_f64 %[t13], %[pv], -1.0", "v_mul_f64 %[t14], %[pv], -1.0",
+                                    "v_mul_f64 %[t15], %[pv], -1.0")
                          "s_mov_b64 exec, -1"
                          : T_OPS_RW
-                         : [mr] "s"(mrow), [iv] "s"(inv_s));
-            // every lane: T[i][j] = fma(-cm_i, prow_j, T[i][j]); lane r runs it with 2 (p - 2 p = -p, exact), a flip with 0
-            double um = isr ? 2.0 : cm;
-            if (mrow == 0ull) um = 0.0;
-            const int rl = uni(rs);
-#define M_TX(j) { const double pj = readlane_f64(TD(j), rl); TD(j) = fma(-um, pj, TD(j)); }
-            FOR_T(M_TX)
-#undef M_TX
-            // column c of the new dictionary: T[i][c] = cm_i * inv, T[r][c] = inv -- on its owner, behind the scalar dispatch
-            const double cv = isr ? inv : cm * inv;
-            asm volatile(DISPATCH16("Lwgc", "v_mov_b64 %[t0], %[cv]", "v_mov_b64 %[t1], %[cv]", "v_mov_b64 %[t2], %[cv]",
-                                    "v_mov_b64 %[t3], %[cv]", "v_mov_b64 %[t4], %[cv]", "v_mov_b64 %[t5], %[cv]",
-                                    "v_mov_b64 %[t6], %[cv]", "v_mov_b64 %[t7], %[cv]", "v_mov_b64 %[t8], %[cv]",
-                                    "v_mov_b64 %[t9], %[cv]", "v_mov_b64 %[t10], %[cv]", "v_mov_b64 %[t11], %[cv]",
-                                    "v_mov_b64 %[t12], %[cv]", "v_mov_b64 %[t13], %[cv]", "v_mov_b64 %[t14], %[cv]",
-                                    "v_mov_b64 %[t15], %[cv]")
-                         "s_nop 0"
-                         : T_OPS_RW
-                         : [cs] "s"(uni(csel)), [cv] "v"(cv)
+                         : [cs] "s"(uni(rsel)), [mr] "s"(mrow), [pv] "v"(pv)
                          : "scc");
         }
         c = cnext;
-        STAMP(6);   // ratio test, exchange, bookkeeping
+        par ^= 1;
+        STAMP(7);   // the exchange
     }
 #undef DISPATCH16
 #undef T_OPS_R
 #undef T_OPS_RW
 #undef FOR_T
 #undef TD
-    STAMP(6);
 
     // ---- read back: lambda_k, then x = W~ lambda - h -------------------------------------------------------------
     // (everything below derives its lane coordinates and kernel arguments afresh: nothing of that stays in registers across
@@ -852,7 +893,7 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 
         if (re_) re_[b] = rs;
         if (pe_) pe_[b] = pivots;
     }
-    STAMP(7);
+    STAMP(0);   // (diagnostic builds: read-back + post-check are added to the load slot)
 #ifdef QPN_STAMPS
     if (tid == 0 && a.stamps) {
         for (int k = 0; k < 8; ++k) a.stamps[(size_t)b * 8 + k] = stamp_acc[k];

@@ -21,9 +21,9 @@ from qpn_amd.engine import colmajor
 _lib.LIB_PATH = out
 _lib._lib = None
 eng = qpn_amd.Engine(0)
-names = ["load", "stage A: gather/publish + barrier", "stage A: LU + U'", "stage A: tile updates",
-         "W~ hand-over, S, transposition", "Lemke: column + barrier", "Lemke: ratio test, exchange, bookkeeping",
-         "read-back + post-check"]
+names = ["load + read-back + post-check", "stage A: gather/publish + barrier", "stage A: LU + U'", "stage A: tile updates",
+         "W~ hand-over, S, tile hand-over", "Lemke: column + barrier A", "Lemke: leader's turn + barrier B",
+         "Lemke: exchange"]
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
 for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
     m = n
@@ -41,4 +41,4 @@ for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
         print(f"n = m = {n}, {cnt} nodes: mean {tot:.0f} clocks (s_memtime) per workgroup; {n // 4 + (n % 4 > 0)} block pivots, {lp:.1f} Lemke pivots")
         for i, nm in enumerate(names):
             print(f"  {nm:42s} {s[:, i].mean():10.1f}  {100*s[:, i].mean()/tot:5.1f} %")
-        print(f"  per block pivot {(s[:, 1:4].sum(axis=1).mean()) / (n // 4 + (n % 4 > 0)):8.0f}   per Lemke pivot {(s[:, 5:7].sum(axis=1).mean()) / max(lp, 1):8.0f}", flush=True)
+        print(f"  per block pivot {(s[:, 1:4].sum(axis=1).mean()) / (n // 4 + (n % 4 > 0)):8.0f}   per Lemke pivot {(s[:, 5:8].sum(axis=1).mean()) / max(lp, 1):8.0f}", flush=True)
