@@ -146,7 +146,7 @@ __host__ __device__ constexpr int wg_lds_doubles(int n, int m, int n_pad, int m_
 // rows / columns elsewhere); the workgroup has NW = max(NT, MT) wavefronts.  Everything that depends on the tile counts is
 // resolved at compile time: the tile code is straight-line.
 template <int NT, int MT>
-__global__ __launch_bounds__(64 * (NT > MT ? NT : MT), (NT > 3 || MT > 3) ? 3 : 4) void schur_wg_nodes(AviBatchArgs a)
+__global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(AviBatchArgs a)
 {
     constexpr int NW = NT > MT ? NT : MT;
 
