@@ -33,6 +33,10 @@ def colmajor(M):
     return np.ascontiguousarray(np.swapaxes(np.asarray(M, dtype=np.float64), -1, -2))
 
 
+def _torch_dt(dt):
+    return {np.dtype(np.int32): torch.int32, np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8}[np.dtype(dt)]
+
+
 def _is_dev(x):
     return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
 
@@ -82,11 +86,14 @@ class Engine:
         if dev and self.use_torch_stream:
             s = torch.cuda.current_stream(self.device).cuda_stream
             if s != self._bound:                 # (the binding call is skipped while the stream stays what it was)
-                self.lib.qpn_ctx_set_stream(self.ctx, C.c_void_p(s))
+                # the binding is cached only once the library has accepted it (the call synchronises the old stream and can fail)
+                self._bound = None
+                self._chk(self.lib.qpn_ctx_set_stream(self.ctx, C.c_void_p(s)), "qpn_ctx_set_stream")
                 self._bound = s
         elif not dev:
             if self._bound != "own":
-                self.lib.qpn_ctx_use_own_stream(self.ctx)
+                self._bound = None
+                self._chk(self.lib.qpn_ctx_use_own_stream(self.ctx), "qpn_ctx_use_own_stream")
                 self._bound = "own"
 
     def synchronize(self):
@@ -591,10 +598,18 @@ class Nodes:
         fast = self._fast
         if fast is not None and out is fast[0] and x_out is fast[1] and opts is None and _is_dev(w) and w.dtype is torch.float64 \
                 and w.stride(-1) == 1:
-            eng._bind_stream(True)
-            rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, w.data_ptr(), 0 if w.ndim == 1 else w.stride(0), *fast[2])
-            eng._chk(rc, "qpn_solve_nodes_h")
-            return out
+            # the cached argument tail holds raw device addresses: it is valid only while every tensor it was built from is
+            # the same object at the same address (a swapped or deleted dict entry, or a resized tensor, rebuilds it below),
+            # and only for a w of the handle's own shape on the handle's device
+            same = all((out.get(k) is t) and (t is None or t.data_ptr() == a) for k, t, a in fast[4]) and \
+                (x_out is None or x_out.data_ptr() == fast[5])
+            w_ok = w.shape[-1] == self.p and w.device == fast[6] and (w.ndim == 1 or (w.ndim == 2 and w.shape[0] == self.batch))
+            if same and w_ok:
+                eng._bind_stream(True)
+                rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, w.data_ptr(), 0 if w.ndim == 1 else w.stride(0), *fast[2])
+                eng._chk(rc, "qpn_solve_nodes_h")
+                return out
+            self._fast = None
         dev = eng._mode(w, x_out)
         eng._bind_stream(dev)
         if not dev:
@@ -602,9 +617,31 @@ class Nodes:
         elif w.dtype != torch.float64 or w.stride(-1) != 1:
             raise QpnError("w must be a float64 tensor with unit inner stride")
         N = self.n + self.m
+        if w.shape[-1] != self.p or w.ndim > 2 or (w.ndim == 2 and w.shape[0] != self.batch):
+            raise QpnError(f"w must have shape ({self.p},) or ({self.batch}, {self.p})")
+        if dev and w.device.index != eng.device:
+            raise QpnError("w lives on another device than the engine")
         sw = 0 if w.ndim == 1 else int(w.stride(0) if dev else w.strides[0] // 8)
         o = opts if opts is not None else eng.default_opts()
         o.flags |= _lib.AVI_FLAG_COLD_START
+        if out is not None:
+            # a caller-supplied set of output buffers is checked once, when it is first seen
+            spec = dict(status=((self.batch,), np.int32), z=((self.batch, N), np.float64), resid=((self.batch,), np.float64),
+                        pivots=((self.batch,), np.int32), active=((self.batch, N), np.uint8))
+            for k, (shape, dt) in spec.items():
+                t = out.get(k)
+                if t is None:
+                    if k == "status":
+                        raise QpnError("out['status'] is required")
+                    continue
+                if _is_dev(t) != dev:
+                    raise QpnError(f"out['{k}'] and w must both be host arrays or both device tensors")
+                ok = tuple(t.shape) == shape and (t.is_contiguous() and t.dtype == _torch_dt(dt) and t.device.index == eng.device
+                                                  if dev else t.flags["C_CONTIGUOUS"] and t.dtype == dt)
+                if not ok:
+                    raise QpnError(f"out['{k}'] must be a contiguous {np.dtype(dt).name} buffer of shape {shape} on the engine's device")
+            for k in ("z", "resid", "pivots", "active"):
+                out.setdefault(k, None)
         if out is None:
             out = dict(status=eng._alloc(dev, (self.batch,), np.int32),
                        z=eng._alloc(dev, (self.batch, N), np.float64) if "z" in want else None,
@@ -617,7 +654,11 @@ class Nodes:
         rc = eng.lib.qpn_solve_nodes_h(eng.ctx, self.h, _ptr(w), sw, *tail)
         eng._chk(rc, "qpn_solve_nodes_h")
         if dev and opts is None:
-            self._fast = (out, x_out, tail, o)   # (o is kept alive: tail holds a reference to it)
+            # (o is kept alive: tail holds a reference to it; the tensors the addresses in `tail` came from are recorded with
+            #  those addresses, so that the fast path above can tell when they are no longer what they were)
+            snap = tuple((k, out.get(k), None if out.get(k) is None else out[k].data_ptr())
+                         for k in ("z", "status", "resid", "pivots", "active"))
+            self._fast = (out, x_out, tail, o, snap, None if x_out is None else x_out.data_ptr(), w.device)
         return out
 
     def verify(self, xd, w, tol=1e-4):

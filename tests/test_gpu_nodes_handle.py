@@ -170,3 +170,44 @@ def test_handle_abi_errors(engine):
     st = (C.c_int32 * 4)()
     assert lib.qpn_solve_nodes_h(engine.ctx, None, None, 0, None, st, None, None, None, None, 0, None, 0) == -1
     assert lib.qpn_nodes_free(engine.ctx, None) == 0
+
+
+def test_handle_fast_path_notices_swapped_or_dropped_output_buffers(engine, oracle):
+    """The sweep loop's cached argument tail holds raw device addresses: a dict whose tensors were swapped or deleted, a w
+    of another length, a mis-shaped caller buffer -- each must rebuild or raise, never write to a stale address."""
+    import torch
+    from qpn_amd.engine import QpnError
+    n, m, p, cnt = 32, 32, 8, 300
+    rec, abi = _records(11, cnt, n, m)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    dev = [t(a) for a in abi]
+    w = t(P.shared_params(p))
+    nodes = engine.upload_nodes(*dev)
+    out = nodes.solve(w)
+    out = nodes.solve(w, out=out)                   # second call: the fast path is armed with these buffers
+    torch.cuda.synchronize()
+    z_ref = out["z"].clone(); st_ref = out["status"].clone()
+    # (1) a tensor of the dict is replaced: the next sweep must write into the NEW tensor and leave the old one alone
+    old_z = out["z"]
+    old_z.fill_(7.0)
+    out["z"] = torch.zeros_like(old_z)
+    nodes.solve(w, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out["z"], z_ref) and bool((old_z == 7.0).all())
+    # (2) an optional output is dropped from the dict: nothing is written for it any more
+    old_act = out.pop("active")
+    old_act.fill_(9)
+    nodes.solve(w, out=out)
+    torch.cuda.synchronize()
+    assert bool((old_act == 9).all()) and torch.equal(out["status"], st_ref)
+    # (3) parameters of the wrong length or on the host while the buffers are on the device
+    with pytest.raises(QpnError):
+        nodes.solve(w[: p - 1], out=out)
+    # (4) a caller-supplied buffer of the wrong shape / dtype is refused when first seen
+    bad = dict(status=torch.zeros(cnt, dtype=torch.int32, device="cuda:0"), z=torch.zeros((cnt, n), dtype=torch.float64, device="cuda:0"))
+    with pytest.raises(QpnError):
+        nodes.solve(w, out=bad)
+    bad = dict(status=torch.zeros(cnt, dtype=torch.int64, device="cuda:0"))
+    with pytest.raises(QpnError):
+        nodes.solve(w, out=bad)
+    nodes.close()
