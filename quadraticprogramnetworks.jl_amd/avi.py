@@ -244,13 +244,27 @@ def solve_qep(qp_net, player_pool, x, S: Optional[Dict[int, object]] = None, eng
     param_inds = [i for i in range(x_dim) if i not in set(dec_inds)]
     labeled = {i: create_labeled_gavi_from_qp(qp_net, i, S) for i in player_pool}
     disjoint = sum(len(labeled[i]["dvars"]) for i in player_pool) == len(dec_inds)
-    if reference_form or not disjoint:
-        gavi = combine_gavis(x_dim, dec_inds, param_inds, labeled)
-    else:
-        gavi = combine_gavis_reduced(x_dim, dec_inds, param_inds, labeled)
     w = x[param_inds]
-    z0 = np.concatenate([x[dec_inds], np.zeros(gavi.M.shape[1] - len(dec_inds))])   # duals cold, :404
-    z, status, info = solve_gavi(gavi, z0, w, engine=engine, reference_form=reference_form)
+    nd = len(dec_inds)
+    # combine_gavis (:399-400) ON THE DEVICE: one qpn_assemble_pools call stacks the players' blocks into the pool's AVI --
+    # the reference form (xi blocks, the sum-of-xi rows :356-367, convert :113-128) when asked for or when players share
+    # decision variables, else the reduced form (N = nd + sum m_i) -- and the batched solve takes it as it stands.  (The host
+    # mirrors combine_gavis / combine_gavis_reduced above remain as the checkers of that kernel, tests/test_gpu_pools.py.)
+    form = "reference" if (reference_form or not disjoint) else "reduced"
+    blocks = pool_blocks(x_dim, dec_inds, param_inds, labeled)
+    Mc, q, lo, hi, kind = assemble_pool_batch(blocks, w, engine=engine, form=form)
+    Nn = np.asarray(q).shape[-1]
+    z0 = np.zeros(Nn)
+    z0[:nd] = x[dec_inds]                                                            # duals cold, :404
+    if form == "reference":
+        # z0s = [z0; A z0 + B w] (:107-108): the slack block, the last sum m_i entries of the converted AVI
+        sm = len(blocks["l"])
+        if sm:
+            z0[Nn - sm:] = blocks["Ad"] @ x[dec_inds] + blocks["Bp"] @ w
+    res = _eng(engine).solve_avi_batch(np.asarray(Mc), np.asarray(q).reshape(1, Nn), np.asarray(lo).reshape(1, Nn),
+                                       np.asarray(hi).reshape(1, Nn), z0=z0[None], kind=np.asarray(kind).reshape(Nn))
+    z = np.asarray(res["z"][0]); status = StatusCode(int(res["status"][0]))
+    info = dict(resid=float(res["resid"][0]), pivots=int(res["pivots"][0]), active=np.asarray(res["active"][0]))
     if status != StatusCode.SUCCESS:
         raise AVISolveError(f"AVI solve error. This might be because one of the qps {list(player_pool)} "
                             f"is unbounded or ill-conditioned. {info}")

@@ -1,5 +1,5 @@
 """Host-side mirror of the array part of src/avi_solutions.jl: comp_indices (the "active set")
-and -- scope row F1, first slice -- the local pieces of a strictly convex node's solution map.
+and -- scope row F1 -- the local pieces of a node's solution map, made by the device kernels (solution_graph_pieces).
 
 comp_indices masks: bit (c-1) set for code c.  Codes (src/avi_solutions.jl:390-399, :568-586):
   1  r >= 0, z = l      2  r = 0, l <= z <= u      3  r <= 0, z = u      4  l = z = u
@@ -72,82 +72,84 @@ def all_Ks(mask, engine=None, limit=4096):
     return eng.recipes_from_masks(np.asarray(mask, dtype=np.uint8), 0, min(total, limit))
 
 
-def local_pieces_strict(Q, q, A, l, u, dec_inds, x, lam, tol=1e-2, max_pieces=64):
-    """Local pieces of a node's solution map around (x, lam), in global x coordinates, for a
-    node whose Q[dec,dec] is positive definite and whose active rows are linearly independent.
-
-    Restates, for that regular case only, process_solution_graph (src/avi.jl:447-477) ->
-    comp_indices -> all_Ks (src/avi_solutions.jl:200-215) -> local_piece (:400-496) -> project:
-    for every recipe K (each weakly active row taken as active OR inactive) the piece is
-        { x :  Q_dd x_d + Q_dp x_p + q_d = A_act,d' lam_act            (stationarity)
-               A_act x = bound_act,  sign(lam_act) ok,  l <= A_inact x <= u }
-    and lam_act is eliminated by substitution (no polyhedral projection / CDD needed).
-    Returns a list of Poly over all variables."""
-    n = len(x)
-    dec = list(dec_inds)
-    par = [i for i in range(n) if i not in set(dec)]
-    Qdd = Q[np.ix_(dec, dec)]
-    ax = A @ x
-    m = A.shape[0]
-    options = []
-    for i in range(m):
-        at_l = np.isfinite(l[i]) and abs(ax[i] - l[i]) <= tol
-        at_u = np.isfinite(u[i]) and abs(ax[i] - u[i]) <= tol
-        lam_zero = abs(lam[i]) <= tol
-        opts = []
-        if l[i] == u[i]:
-            opts = ["eq"]
-        else:
-            if at_l and lam[i] >= -tol:
-                opts.append("lo")
-            if at_u and lam[i] <= tol:
-                opts.append("up")
-            if lam_zero:
-                opts.append("in")
-        if not opts:
-            opts = ["in"]
-        options.append(opts)
-    pieces = []
-    for rec in itertools.islice(itertools.product(*options), max_pieces):
-        act = [i for i in range(m) if rec[i] != "in"]
-        rows_A, rows_l, rows_u = [], [], []
-        Ad = A[np.ix_(act, dec)] if act else np.zeros((0, len(dec)))
-        # stationarity with lam eliminated: lam_act = (Ad Qdd^-1 Ad')^-1 (Ad Qdd^-1 g(x) + ...)
-        # g(x) = Q_d,: x + q_d  (gradient rows);  Ad' lam = g  =>  project g on range(Ad'):
-        Grow = Q[dec, :]                      # gradient is affine in the full x
-        if act:
-            try:
-                W = np.linalg.solve(Qdd, Ad.T)            # Qdd^-1 Ad'
-                S = Ad @ W
-                Sinv = np.linalg.inv(S)
-            except np.linalg.LinAlgError:
+def eliminate_multipliers(P: Poly, n: int, m: int, tol=1e-9, max_rows=4096) -> Poly:
+    """A local piece over [x_d (n); lambda (m); x_p] brought down to [x_d; x_p]: the multipliers are eliminated through
+    the piece's OWN equality rows (stationarity rows of free x_d, lambda_j = 0 of inactive rows, constraint rows of active
+    ones) -- the substitution x2 = Ae_elim^+ (rhs - Ae_keep x1) of eliminate_variables, src/sets.jl:731-800, one column at a
+    time with partial pivoting -- and, for a multiplier no equality pins (degenerate active sets), by one Fourier-Motzkin
+    step.  The path's counterpart of project_and_permute (src/avi_solutions.jl:79-91), which the reference does by vertex
+    enumeration (CDD: out of scope)."""
+    A, l, u = (np.array(a, dtype=np.float64) for a in P.vectorize())
+    alive = np.ones(A.shape[0], bool)
+    left = []
+    for j in range(n, n + m):
+        col = np.where(alive & (l == u) & np.isfinite(l), np.abs(A[:, j]), 0.0)
+        i = int(np.argmax(col)) if col.size else -1
+        if i < 0 or col[i] <= tol:
+            if np.any(alive & (np.abs(A[:, j]) > tol)):
+                left.append(j)
+            continue
+        piv = A[i, j]
+        for k in np.nonzero(alive & (np.abs(A[:, j]) > 0.0))[0]:
+            if k == i:
                 continue
-            # x_d is pinned by: A_act x = b_act and Qdd-stationarity in the null space of Ad.
-            # lam(x) = Sinv (W' (Grow x + q_d))  evaluated with x_d free  -> affine in x
-            Lx = Sinv @ (W.T @ Grow); Lc = Sinv @ (W.T @ q[dec])
-            # stationarity residual: Grow x + q_d - Ad' lam(x) = 0   (len(dec) equalities)
-            E = Grow - Ad.T @ Lx; ec = q[dec] - Ad.T @ Lc
-        else:
-            Lx = np.zeros((0, n)); Lc = np.zeros(0)
-            E = Grow; ec = q[dec].copy()
-        for k in range(E.shape[0]):
-            if np.max(np.abs(E[k])) > 1e-12:
-                rows_A.append(E[k]); rows_l.append(-ec[k]); rows_u.append(-ec[k])
-        for j, i in enumerate(act):
-            b = l[i] if rec[i] in ("lo", "eq") else u[i]
-            rows_A.append(A[i]); rows_l.append(b); rows_u.append(b)
-            if rec[i] == "lo":
-                rows_A.append(Lx[j]); rows_l.append(-Lc[j]); rows_u.append(INF)
-            elif rec[i] == "up":
-                rows_A.append(Lx[j]); rows_l.append(-INF); rows_u.append(-Lc[j])
-        for i in range(m):
-            if rec[i] == "in":
-                rows_A.append(A[i]); rows_l.append(l[i]); rows_u.append(u[i])
-        P = Poly(np.array(rows_A).reshape(-1, n), np.array(rows_l), np.array(rows_u))
-        P = _dedupe(P)
-        if P.contains(x, tol=10 * tol):
-            pieces.append(P)
-    return pieces
+            f = A[k, j] / piv
+            A[k] -= f * A[i]; A[k, j] = 0.0
+            l[k] -= f * l[i]; u[k] -= f * u[i]          # (row i is an equality: both bounds move by f b)
+        alive[i] = False
+    A, l, u = A[alive], l[alive], u[alive]
+    for j in left:
+        # Fourier-Motzkin on column j: rows as one-sided inequalities a.y <= b
+        zero = np.abs(A[:, j]) <= tol
+        Az, lz, uz = A[zero], l[zero], u[zero]
+        ub, lb = [], []                                # a_j > 0 rows bound lambda_j from above, a_j < 0 from below
+        for k in np.nonzero(~zero)[0]:
+            for a_, b_ in ((A[k], u[k]), (-A[k], -l[k])):
+                if not np.isfinite(b_):
+                    continue
+                (ub if a_[j] > 0 else lb).append((a_ / abs(a_[j]), b_ / abs(a_[j])))
+        if len(ub) * len(lb) + Az.shape[0] > max_rows:
+            raise RuntimeError("eliminate_multipliers: the piece needs a polyhedral projection (too many rows)")
+        rows = [(au + al, bu + bl) for au, bu in ub for al, bl in lb]
+        A = np.vstack([Az] + [r[0][None] for r in rows]) if rows else Az
+        l = np.concatenate([lz, np.full(len(rows), -INF)]); u = np.concatenate([uz, np.array([r[1] for r in rows])])
+        A[:, j] = 0.0
+    keep_cols = [c for c in range(A.shape[1]) if c < n or c >= n + m]
+    return Poly(A[:, keep_cols], l, u)
+
+
+def solution_graph_pieces(Q, q, A, l, u, dec_inds, x, lam, engine=None, tol=1e-2, max_pieces=64):
+    """The pieces of a node's solution map around (x, lam), in global x coordinates, from the DEVICE kernels:
+    process_solution_graph (src/avi.jl:447-477: the node's own GAVI at z = [x_d; lam], w = x_p) -> comp_indices (the masks,
+    qpn_comp_indices) -> all_Ks (src/avi_solutions.jl:200-215, qpn_recipes_from_masks) -> local_piece (:400-496,
+    qpn_local_pieces) for every recipe in one launch -> the multipliers eliminated per piece (eliminate_multipliers) and the
+    columns permuted back (permute!, src/avi_solutions.jl:86-87).  Covers what the first generation of LocalGAVISolutions
+    (:118-130) yields; vertex exploration and remove_subsets are out of scope.  Unlike the host-only
+    restatement for strictly convex leaves that preceded it (now a test-side checker, tests/strict_pieces.py) it needs
+    neither Q_dd > 0 nor independent active rows."""
+    x = np.asarray(x, dtype=np.float64)
+    rec = node_records(np.asarray(Q, float), np.asarray(q, float), np.asarray(A, float), l, u, dec_inds)
+    dec, par = rec["dec"], rec["par"]
+    n, m = len(dec), len(rec["l"])
+    z = np.concatenate([x[dec], np.asarray(lam, dtype=np.float64)])
+    w = x[par]
+    g = GAVI(np.hstack([rec["Qd"], -rec["Ad"].T]), rec["R"], rec["qd"], np.full(n, -INF), np.full(n, INF),
+             np.hstack([rec["Ad"], np.zeros((m, m))]), rec["B"], rec["l"], rec["u"])
+    mask = comp_indices(g, z, w, tol=tol, engine=engine)
+    if np.any(np.asarray(mask) == 0):
+        return []                                       # (x, lam) is not a solution of the node's GAVI at this tolerance
+    K, total = all_Ks(mask, engine=engine, limit=max_pieces)
+    lifted = local_pieces(rec, K, engine=engine, simplify=False)
+    out = []
+    for P in lifted:
+        Pl = eliminate_multipliers(P, n, m)
+        Al, ll, ul = Pl.vectorize()
+        Ag = np.zeros((Al.shape[0], len(x)))
+        Ag[:, dec] = Al[:, :n]; Ag[:, par] = Al[:, n:]
+        Pg = _dedupe(Poly(Ag, ll, ul))
+        if Pg.contains(x, tol=10 * tol):
+            out.append(Pg)
+    return out
 
 
 def _dedupe(P: Poly, digits=6):

@@ -9,7 +9,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from .avi import StatusCode, _eng
-from .avi_solutions import local_pieces_strict
+from .avi_solutions import solution_graph_pieces
 from .engine import colmajor
 from .programs import Poly
 
@@ -102,10 +102,12 @@ def solve_qp(Q, q, A, l, u, solver="PATH", engine=None):
 
 
 def process_qp(qpn, pid: int, x, S: Dict[int, list], engine=None, exploration_vertices=0):
-    """src/qp_processing.jl:151-241.  S maps child id -> list of Poly pieces.  For every combination
-    of the children's pieces (:162-169) the node is verified (:187); solution-graph generation
-    (:193-198, :231) is done for strictly convex nodes by local_pieces_strict and is otherwise
-    out of scope (polyhedral)."""
+    """src/qp_processing.jl:151-241.  S maps child id -> list of Poly pieces.  For every combination of the children's
+    pieces (:162-169) the node is verified (:187, one batched call).  Solution-graph generation (:193-198, :231): the pieces
+    come from the device kernels (avi_solutions.solution_graph_pieces: masks -> qpn_recipes_from_masks -> qpn_local_pieces)
+    for leaves and for every sub-piece combination of an inner node; an inner node returns each combination's pieces
+    intersected with the child pieces they were derived under -- the first generation of what combine(...) (:219,
+    IntersectionRoot, polyhedral: out of scope) would enumerate, without its exploration."""
     qp = qpn.qps[pid]
     base = [qpn.constraints[c].poly for c in qp.constraint_indices]
     dec_inds = qpn.decision_inds(pid)
@@ -124,14 +126,32 @@ def process_qp(qpn, pid: int, x, S: Dict[int, list], engine=None, exploration_ve
             if not ret["solution"]:
                 return dict(solution=False, e=ret["e"], failed=False,
                             subpiece_assignments={j: ji for j, ji in zip(children, combo)})
-        return dict(solution=True, S=None, failed=False)     # combine(): polyhedral, out of scope
+        S_out = None
+        if gen:
+            # :193-198 per combination: the node's GAVI under this combination's child pieces -> device pieces
+            S_out = []
+            for combo, ret in zip(combos, rets):
+                cons = base + [S[j][ji] for j, ji in zip(children, combo)]
+                rec = node_record(qp, cons, dec_inds, x)
+                pieces = solution_graph_pieces(qp.f.Q, qp.f.q, rec["A"], rec["l"], rec["u"], dec_inds, np.asarray(x), ret["lam"],
+                                               engine=engine)
+                child = [S[j][ji] for j, ji in zip(children, combo)]
+                for P in pieces:
+                    Ap, lp, up = P.vectorize()
+                    rows = [c.vectorize() for c in child]
+                    S_out.append(Poly(np.vstack([Ap] + [r[0] for r in rows]), np.concatenate([lp] + [r[1] for r in rows]),
+                                      np.concatenate([up] + [r[2] for r in rows])))
+            if len(S_out) == 0:
+                raise RuntimeError("This shouldn't happen. Solution graph is empty.")
+        return dict(solution=True, S=S_out, failed=False)
     ret = verify_solution(qp, pid, base, dec_inds, x, engine=engine)
     if not ret["solution"]:
         return dict(solution=False, e=ret["e"], failed=False, subpiece_assignments={})
     S_out = None
     if gen:
         rec = node_record(qp, base, dec_inds, x)
-        S_out = local_pieces_strict(qp.f.Q, qp.f.q, rec["A"], rec["l"], rec["u"], dec_inds, np.asarray(x), ret["lam"])
+        S_out = solution_graph_pieces(qp.f.Q, qp.f.q, rec["A"], rec["l"], rec["u"], dec_inds, np.asarray(x), ret["lam"],
+                                      engine=engine)
         if len(S_out) == 0:
             raise RuntimeError("This shouldn't happen. Solution graph is empty.")
     return dict(solution=True, S=S_out, failed=False)

@@ -49,3 +49,72 @@ class OracleEngine:
             s, lm, p = ob.verify_solution(Qc[b].T, Rc[b].T, qd[b], Ac[b].T, Bc[b].T, l[b], u[b], xd[b], wb, tol=tol)
             sol[b] = s; path[b] = p; lam[b, :m] = lm
         return sol, lam[:, :m], path
+
+    # ---- the pieces of the solution graph and the pool assembly (rows F1 / A6), served by the oracle / by plain numpy ----
+    def recipes_from_masks(self, mask, first=0, count=None):
+        """all_Ks (src/avi_solutions.jl:200-215): recipes first .. first+count-1 of the Cartesian product of the rows' code
+        sets, row 0 fastest (the device kernel's mixed-radix order)."""
+        mask = np.asarray(mask, dtype=np.uint8)
+        sets = [[c + 1 for c in range(8) if (int(mk) >> c) & 1] for mk in mask]
+        total = int(np.prod([len(s) for s in sets])) if all(sets) else 0
+        if count is None:
+            count = total - first
+        if first < 0 or first + count > total:
+            raise ValueError("recipes_from_masks: range outside the product")
+        K = np.zeros((count, len(sets)), np.uint8)
+        for t in range(count):
+            idx = first + t
+            for i, s in enumerate(sets):
+                K[t, i] = s[idx % len(s)]; idx //= len(s)
+        return K, total
+
+    def local_pieces(self, Qc, Rc, qd, Ac, Bc, l, u, K, node_of=None):
+        K = np.atleast_2d(np.asarray(K, dtype=np.uint8))
+        pieces = K.shape[0]
+        n = np.shape(qd)[1]; m = np.shape(l)[1]; p = np.shape(Rc)[1]; N = n + m
+        node_of = np.arange(pieces) if node_of is None else np.asarray(node_of)
+        Ap = np.zeros((pieces, N + p, 2 * N)); lp = np.zeros((pieces, 2 * N)); up = np.zeros((pieces, 2 * N))
+        keep = np.zeros((pieces, 2 * N), np.uint8)
+        for t in range(pieces):
+            b = int(node_of[t])
+            A_, lp[t], up[t], keep[t] = ob.local_piece(np.asarray(Qc[b]).T, np.asarray(Rc[b]).T.reshape(n, p), qd[b],
+                                                       np.asarray(Ac[b]).T.reshape(m, n), np.asarray(Bc[b]).T.reshape(m, p),
+                                                       l[b], u[b], K[t])
+            Ap[t] = A_.T                      # column-major per piece, as the ABI returns it
+        return Ap, lp, up, keep
+
+    def assemble_pools(self, n_i, m_i, dpos, nd, Qd, Qp, qd, Ad, Bp, l, u, w, form="reduced", share_M=None):
+        """combine_gavis / its reduced form for ONE pool instance, restated with plain numpy on the stacked blocks
+        (ABI layout in: column-major blocks; out: Mc column-major)."""
+        n_i = [int(v) for v in n_i]; m_i = [int(v) for v in m_i]; dpos = [int(v) for v in dpos]
+        sn, sm = sum(n_i), sum(m_i)
+        Qd = np.asarray(Qd, float).T.reshape(sn, nd); Ad = np.asarray(Ad, float).T.reshape(sm, nd)
+        p = int(np.shape(w)[-1])
+        Qp = np.asarray(Qp, float).T.reshape(sn, p); Bp = np.asarray(Bp, float).T.reshape(sm, p)
+        qd = np.ravel(qd).astype(float); l = np.ravel(l).astype(float); u = np.ravel(u).astype(float); w = np.ravel(w).astype(float)
+        owner_n = np.repeat(np.arange(len(n_i)), n_i); owner_m = np.repeat(np.arange(len(m_i)), m_i)
+        # -A_i[:, dvars_i]' of player i: rows = the player's own variables, columns = its own constraint rows
+        C = np.zeros((sn, sm))
+        for r in range(sn):
+            for c in range(sm):
+                if owner_n[r] == owner_m[c]:
+                    C[r, c] = -Ad[c, dpos[r]]
+        inf = np.inf
+        if form == "reduced":
+            M = np.block([[Qd, C], [Ad, np.zeros((sm, sm))]])
+            q = np.concatenate([qd + Qp @ w, Bp @ w])
+            lo = np.concatenate([np.full(sn, -inf), l]); hi = np.concatenate([np.full(sn, inf), u])
+            kind = np.concatenate([np.zeros(sn, np.uint8), np.ones(sm, np.uint8)])
+        else:
+            # z = [dvars (nd); xi (sn); lambda (sm); slack (sm)]: sum-of-xi rows, players' rows, A z - s = 0, s in [l, u]
+            top = np.zeros((nd, nd + sn + 2 * sm))
+            for r in range(sn):
+                top[dpos[r], nd + r] = 1.0
+            mid = np.hstack([Qd, np.zeros((sn, sn)), C, np.zeros((sn, sm))])
+            con = np.hstack([Ad, np.zeros((sm, sn + sm)), -np.eye(sm)])
+            bot = np.hstack([np.zeros((sm, nd + sn)), np.eye(sm), np.zeros((sm, sm))])
+            M = np.vstack([top, mid, con, bot])
+            q = np.concatenate([np.zeros(nd), qd + Qp @ w, Bp @ w, np.zeros(sm)])
+            lo = np.concatenate([np.full(nd + sn + sm, -inf), l]); hi = np.concatenate([np.full(nd + sn + sm, inf), u])
+            kind = np.zeros(nd + sn + 2 * sm, np.uint8)
+        return np.ascontiguousarray(M.T), q[None], lo[None], hi[None], kind[None]

@@ -94,3 +94,38 @@ def test_batched_subpiece_verification_on_gpu(engine):
             assert rb["solution"] == r1["solution"] == rr["solution"] and rb["path"] == r1["path"] == rr["path"]
             if rr["lam"] is not None:
                 assert np.allclose(rb["lam"], r1["lam"], atol=1e-9) and np.allclose(rb["lam"], rr["lam"], atol=1e-7)
+
+
+def test_robust_avoid_level3_through_process_qp_with_device_made_pieces(engine):
+    """BASELINE config 2, level 3 (the separating-hyperplane players: LP-like, Q = 0 -- outside what the strictly convex
+    host restatement of rounds 1-2 could do): solve_qep forms the level's pool on the device (qpn_assemble_pools) and solves
+    it; process_qp then verifies each node at the equilibrium and returns its solution-graph pieces, made by the device
+    kernels (masks -> qpn_recipes_from_masks -> qpn_local_pieces) and brought down to x-coordinates.  Every piece contains
+    the equilibrium, lives in the 18 variables of the net, and constrains only what the node's own KKT system touches."""
+    from qpn_amd import avi, examples
+    from qpn_amd.qp_processing import process_qp, verify_solution
+    net = examples.setup("robust_avoid_simple")
+    x = np.array(net.default_initialization, float)
+    level3 = sorted(net.network_depth_map[3])
+    x = avi.solve_qep(net, level3, x, {}, engine=engine)               # pool {s1, s2}: N_ref = 52, assembled on the device
+    x_ref = avi.solve_qep(net, level3, np.array(net.default_initialization, float), {}, engine=engine, reference_form=True)
+    assert np.max(np.abs(x - x_ref)) <= 1e-8
+    for pid in level3:
+        ret = process_qp(net, pid, x, {}, engine=engine)
+        assert ret["solution"] and ret["S"] is not None and len(ret["S"]) >= 1, (pid, ret)
+        dec = set(net.decision_inds(pid))
+        base = [net.constraints[c].poly for c in net.qps[pid].constraint_indices]
+        touched = set(np.nonzero(np.any(np.vstack([b.vectorize()[0] for b in base]) != 0, axis=0))[0]) | dec
+        for P in ret["S"]:
+            A, l, u = P.vectorize()
+            assert A.shape[1] == net.num_vars and P.contains(x, tol=1e-6)
+            assert set(np.nonzero(np.any(np.abs(A) > 1e-12, axis=0))[0]) <= touched
+        # moving along a piece keeps the node optimal: a point of the piece close to x still verifies
+        P = ret["S"][0]
+        A, l, u = P.vectorize()
+        eq = np.isfinite(l) & (l == u)
+        Z = np.linalg.svd(A[eq])[2][int(np.linalg.matrix_rank(A[eq])):].T if eq.any() else np.eye(net.num_vars)
+        if Z.shape[1]:
+            y = x + 1e-3 * Z @ np.random.default_rng(pid).standard_normal(Z.shape[1])
+            if P.contains(y, tol=1e-9):
+                assert verify_solution(net.qps[pid], pid, base, net.decision_inds(pid), y, engine=engine)["solution"]

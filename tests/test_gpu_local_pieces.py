@@ -5,7 +5,7 @@ per-node GAVI of process_solution_graph, src/avi.jl:447-477) and qpn_recipes_fro
   (copies, negations, the recipe's bounds), so Ap, lp, up and keep must be identical;
 * recipe enumeration == itertools.product over the rows' code sets;
 * on strictly convex leaves, from the masks of a HIP solve: the device pieces describe the same sets as the host-only
-  restatement avi_solutions.local_pieces_strict (lambda eliminated by substitution there, kept as a coordinate here):
+  restatement tests/strict_pieces.py::local_pieces_strict (lambda eliminated by substitution there, kept as a coordinate here):
   membership agrees on points of the recipe's equality manifold, inside and outside the inequalities."""
 import itertools
 
@@ -127,7 +127,8 @@ def test_device_pieces_describe_the_sets_of_the_strict_restatement(engine, seed)
     x = x0.copy(); x[dec] = z[:n]; lam = z[n:]
     K_all, total = AS.all_Ks(mask, engine=engine)
     assert total == K_all.shape[0] >= 1 and np.all(K_all[:, :n] == 2)              # free x_d rows: code 2 only
-    strict = AS.local_pieces_strict(Q, q, A, l, u, dec, x, lam)
+    from strict_pieces import local_pieces_strict
+    strict = local_pieces_strict(Q, q, A, l, u, dec, x, lam)
     assert len(strict) >= 1
     dev = AS.local_pieces(rec, K_all, engine=engine)
     zw = np.concatenate([z, w])
@@ -170,3 +171,38 @@ def test_device_pieces_describe_the_sets_of_the_strict_restatement(engine, seed)
                 if Ps.contains(xp, tol=1e-7) and scale == 0.0:
                     assert any(Pq.contains(np.concatenate([xd, lam_p, wp]), tol=1e-6) for Pq in dev)
     assert checked >= 4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_solution_graph_pieces_equal_the_strict_restatement_as_sets(engine, seed):
+    """The live loop's piece generator (masks -> qpn_recipes_from_masks -> qpn_local_pieces -> multipliers eliminated through
+    the piece's own equalities) against the host-only restatement on strictly convex leaves: the same NUMBER of pieces, and
+    the same SETS -- membership agrees on the solution, on points moved inside each piece and on points pushed across its
+    faces."""
+    from qpn_amd import avi_solutions as AS
+    from qpn_amd.engine import colmajor
+    from strict_pieces import local_pieces_strict
+    rng = np.random.default_rng(100 + seed)
+    nv, n, m = 8, 5, 6
+    dec = sorted(int(v) for v in rng.choice(nv, size=n, replace=False))
+    par = [i for i in range(nv) if i not in dec]
+    G = rng.standard_normal((nv, nv)); Q = G @ G.T / nv + 0.5 * np.eye(nv)
+    q = rng.standard_normal(nv)
+    A = rng.standard_normal((m, nv)) / 2
+    x0 = rng.standard_normal(nv) * 0.5
+    l = A @ x0 - 0.05 - 0.3 * rng.random(m); u = A @ x0 + 0.05 + 0.3 * rng.random(m)      # x0 is feasible: the node has a solution
+    rec = AS.node_records(Q, q, A, l, u, dec)
+    res = engine.solve_nodes(colmajor(rec["Qd"][None]), colmajor(rec["R"][None]), rec["qd"][None], colmajor(rec["Ad"][None]),
+                             colmajor(rec["B"][None]), l[None], u[None], x0[par])
+    assert res["status"][0] == 1
+    x = x0.copy(); x[dec] = res["z"][0][:n]; lam = res["z"][0][n:]
+    dev = AS.solution_graph_pieces(Q, q, A, l, u, dec, x, lam, engine=engine)
+    strict = local_pieces_strict(Q, q, A, l, u, dec, x, lam)
+    assert len(dev) == len(strict) >= 1
+    assert all(P.contains(x, tol=1e-6) for P in dev)
+    pts = [x] + [x + s * rng.standard_normal(nv) for s in (1e-3, 1e-2, 0.1, 0.5) for _ in range(6)]
+    for y in pts:
+        in_dev = any(P.contains(y, tol=1e-7) for P in dev)
+        in_str = any(P.contains(y, tol=1e-7) for P in strict)
+        near = any(P.contains(y, tol=1e-5) for P in dev) != any(P.contains(y, tol=1e-9) for P in dev)   # on a face: skip
+        assert in_dev == in_str or near, y

@@ -7,11 +7,13 @@ mean cycles per phase per solve."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-csrc = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc")
-out = "/tmp/libqpn_hip_stamps.so"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQPN_STAMPS", "-ffp-contract=off",
-                       "-o", out] + [os.path.join(csrc, f) for f in
-                       ("qpn_capi.hip", "qpn_avi_solve.hip", "qpn_avi_reg.hip", "qpn_avi_big.hip", "qpn_avi_schur.hip", "qpn_avi_schur_big.hip", "qpn_avi_schur_mid.hip", "qpn_kkt.hip", "qpn_verify.hip")])
+# (built in-tree beforehand where there is no GPU -- `QPN_OUT=.../libqpn_hip_stamps.so QPN_OBJ=/tmp/qpn_obj_stamps build.sh
+#  -DQPN_STAMPS`: git-ignored, travels with gpurun -- else built here)
+out = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "libqpn_hip_stamps.so")
+if not os.path.exists(out):
+    out = "/tmp/libqpn_hip_stamps.so"
+    subprocess.check_call(["bash", os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc", "build.sh"), "-DQPN_STAMPS"],
+                          env=dict(os.environ, QPN_OUT=out, QPN_OBJ="/tmp/qpn_obj_stamps"), stdout=subprocess.DEVNULL)
 import numpy as np, torch
 import qpn_amd
 from qpn_amd import _lib, synthetic
