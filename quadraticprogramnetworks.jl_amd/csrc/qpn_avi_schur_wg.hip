@@ -534,32 +534,34 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
                 [t6] "v"(TD(6)), [t7] "v"(TD(7)), [t8] "v"(TD(8)), [t9] "v"(TD(9)), [t10] "v"(TD(10)), [t11] "v"(TD(11)),         \
                 [t12] "v"(TD(12)), [t13] "v"(TD(13)), [t14] "v"(TD(14)), [t15] "v"(TD(15))
 #define DISPATCH16(P, L0, L1, L2, L3, L4, L5, L6, L7, L8, L9, L10, L11, L12, L13, L14, L15)                                        \
-    "s_cmp_gt_u32 %[cs], 7\n\ts_cbranch_scc1 ." P "_hi%=\n\t"                                                                      \
-    "s_cmp_gt_u32 %[cs], 3\n\ts_cbranch_scc1 ." P "_4%=\n\t"                                                                       \
-    "s_cmp_gt_u32 %[cs], 1\n\ts_cbranch_scc1 ." P "_2%=\n\t"                                                                       \
-    "s_cmp_eq_u32 %[cs], 0\n\ts_cbranch_scc0 ." P "_1%=\n\t"                                                                       \
-    L0 "\n\ts_branch ." P "_end%=\n"                                                                                               \
-    "." P "_1%=:\n\t" L1 "\n\ts_branch ." P "_end%=\n"                                                                             \
-    "." P "_2%=:\n\ts_cmp_eq_u32 %[cs], 2\n\ts_cbranch_scc0 ." P "_3%=\n\t" L2 "\n\ts_branch ." P "_end%=\n"                        \
-    "." P "_3%=:\n\t" L3 "\n\ts_branch ." P "_end%=\n"                                                                             \
-    "." P "_4%=:\n\ts_cmp_gt_u32 %[cs], 5\n\ts_cbranch_scc1 ." P "_6%=\n\t"                                                        \
-    "s_cmp_eq_u32 %[cs], 4\n\ts_cbranch_scc0 ." P "_5%=\n\t" L4 "\n\ts_branch ." P "_end%=\n"                                      \
-    "." P "_5%=:\n\t" L5 "\n\ts_branch ." P "_end%=\n"                                                                             \
-    "." P "_6%=:\n\ts_cmp_eq_u32 %[cs], 6\n\ts_cbranch_scc0 ." P "_7%=\n\t" L6 "\n\ts_branch ." P "_end%=\n"                        \
-    "." P "_7%=:\n\t" L7 "\n\ts_branch ." P "_end%=\n"                                                                             \
-    "." P "_hi%=:\n\ts_cmp_gt_u32 %[cs], 15\n\ts_cbranch_scc1 ." P "_end%=\n\t"                                                    \
-    "s_cmp_gt_u32 %[cs], 11\n\ts_cbranch_scc1 ." P "_12%=\n\t"                                                                     \
-    "s_cmp_gt_u32 %[cs], 9\n\ts_cbranch_scc1 ." P "_10%=\n\t"                                                                      \
-    "s_cmp_eq_u32 %[cs], 8\n\ts_cbranch_scc0 ." P "_9%=\n\t" L8 "\n\ts_branch ." P "_end%=\n"                                      \
-    "." P "_9%=:\n\t" L9 "\n\ts_branch ." P "_end%=\n"                                                                             \
-    "." P "_10%=:\n\ts_cmp_eq_u32 %[cs], 10\n\ts_cbranch_scc0 ." P "_11%=\n\t" L10 "\n\ts_branch ." P "_end%=\n"                    \
-    "." P "_11%=:\n\t" L11 "\n\ts_branch ." P "_end%=\n"                                                                           \
-    "." P "_12%=:\n\ts_cmp_gt_u32 %[cs], 13\n\ts_cbranch_scc1 ." P "_14%=\n\t"                                                     \
-    "s_cmp_eq_u32 %[cs], 12\n\ts_cbranch_scc0 ." P "_13%=\n\t" L12 "\n\ts_branch ." P "_end%=\n"                                   \
-    "." P "_13%=:\n\t" L13 "\n\ts_branch ." P "_end%=\n"                                                                           \
-    "." P "_14%=:\n\ts_cmp_eq_u32 %[cs], 14\n\ts_cbranch_scc0 ." P "_15%=\n\t" L14 "\n\ts_branch ." P "_end%=\n"                    \
-    "." P "_15%=:\n\t" L15 "\n"                                                                                                    \
-    "." P "_end%=:\n\t"
+    /* (numeric local labels, all referenced forwards: the compiler may duplicate an asm statement -- loop peeling --, and named  \
+        labels would then be defined twice; P only documents the call site) */                                                     \
+    "s_cmp_gt_u32 %[cs], 7\n\ts_cbranch_scc1 20f\n\t"                                                                             \
+    "s_cmp_gt_u32 %[cs], 3\n\ts_cbranch_scc1 4f\n\t"                                                                              \
+    "s_cmp_gt_u32 %[cs], 1\n\ts_cbranch_scc1 2f\n\t"                                                                              \
+    "s_cmp_eq_u32 %[cs], 0\n\ts_cbranch_scc0 1f\n\t"                                                                              \
+    L0 "\n\ts_branch 30f\n"                                                                                                        \
+    "1:\n\t" L1 "\n\ts_branch 30f\n"                                                                                              \
+    "2:\n\ts_cmp_eq_u32 %[cs], 2\n\ts_cbranch_scc0 3f\n\t" L2 "\n\ts_branch 30f\n"                                              \
+    "3:\n\t" L3 "\n\ts_branch 30f\n"                                                                                              \
+    "4:\n\ts_cmp_gt_u32 %[cs], 5\n\ts_cbranch_scc1 6f\n\t"                                                                       \
+    "s_cmp_eq_u32 %[cs], 4\n\ts_cbranch_scc0 5f\n\t" L4 "\n\ts_branch 30f\n"                                                    \
+    "5:\n\t" L5 "\n\ts_branch 30f\n"                                                                                              \
+    "6:\n\ts_cmp_eq_u32 %[cs], 6\n\ts_cbranch_scc0 7f\n\t" L6 "\n\ts_branch 30f\n"                                              \
+    "7:\n\t" L7 "\n\ts_branch 30f\n"                                                                                              \
+    "20:\n\ts_cmp_gt_u32 %[cs], 15\n\ts_cbranch_scc1 30f\n\t"                                                                    \
+    "s_cmp_gt_u32 %[cs], 11\n\ts_cbranch_scc1 12f\n\t"                                                                            \
+    "s_cmp_gt_u32 %[cs], 9\n\ts_cbranch_scc1 10f\n\t"                                                                             \
+    "s_cmp_eq_u32 %[cs], 8\n\ts_cbranch_scc0 9f\n\t" L8 "\n\ts_branch 30f\n"                                                    \
+    "9:\n\t" L9 "\n\ts_branch 30f\n"                                                                                              \
+    "10:\n\ts_cmp_eq_u32 %[cs], 10\n\ts_cbranch_scc0 11f\n\t" L10 "\n\ts_branch 30f\n"                                         \
+    "11:\n\t" L11 "\n\ts_branch 30f\n"                                                                                            \
+    "12:\n\ts_cmp_gt_u32 %[cs], 13\n\ts_cbranch_scc1 14f\n\t"                                                                    \
+    "s_cmp_eq_u32 %[cs], 12\n\ts_cbranch_scc0 13f\n\t" L12 "\n\ts_branch 30f\n"                                                 \
+    "13:\n\t" L13 "\n\ts_branch 30f\n"                                                                                            \
+    "14:\n\ts_cmp_eq_u32 %[cs], 14\n\ts_cbranch_scc0 15f\n\t" L14 "\n\ts_branch 30f\n"                                         \
+    "15:\n\t" L15 "\n"                                                                                                            \
+    "30:\n\t"
     while (code != CODE_STOP) {
         c = uni(c);
         // ---- the entering column, published by the lanes that hold it: row i goes to [i & 3][i >> 2]
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
         STAMP(5);   // entering column through LDS + barrier A
         if (lead) {
             // ================= the leader's turn: ratio test, bookkeeping, decision =================
-            const double cm = colP[par * 64 + (l & 3) * 16 + (l >> 2)];
+            const double cm = actb ? colP[par * 64 + (l & 3) * 16 + (l >> 2)] : 0.0;      // (rows beyond m: whatever LDS holds there)
             // ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
             const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
             const double rc = rcp64(gdir);
@@ -739,12 +741,12 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
                          "v_fma_f64 %[a4], -%[u4], %[pv], %[a4]\n\tv_fma_f64 %[a5], -%[u5], %[pv], %[a5]\n\t"                      \
                          "v_fma_f64 %[a6], -%[u6], %[pv], %[a6]\n\tv_fma_f64 %[a7], -%[u7], %[pv], %[a7]\n\t"                      \
                          /* column c: T[i][c] = u_i * inv on the 4 lanes that own it */                                            \
-                         "s_mov_b64 exec, %[mc]\n\ts_cbranch_execz .Lwgx_e%=\n\t"                                                  \
+                         "s_mov_b64 exec, %[mc]\n\ts_cbranch_execz 31f\n\t"                                                  \
                          "v_mul_f64 %[a0], %[u0], %[iv]\n\tv_mul_f64 %[a1], %[u1], %[iv]\n\t"                                      \
                          "v_mul_f64 %[a2], %[u2], %[iv]\n\tv_mul_f64 %[a3], %[u3], %[iv]\n\t"                                      \
                          "v_mul_f64 %[a4], %[u4], %[iv]\n\tv_mul_f64 %[a5], %[u5], %[iv]\n\t"                                      \
                          "v_mul_f64 %[a6], %[u6], %[iv]\n\tv_mul_f64 %[a7], %[u7], %[iv]\n"                                        \
-                         ".Lwgx_e%=:\n\ts_mov_b64 exec, -1"                                                                        \
+                         "31:\n\ts_mov_b64 exec, -1"                                                                        \
                          : [a0] "+v"(TD(A0)), [a1] "+v"(TD(A1)), [a2] "+v"(TD(A2)), [a3] "+v"(TD(A3)),                             \
                            [a4] "+v"(TD(A4)), [a5] "+v"(TD(A5)), [a6] "+v"(TD(A6)), [a7] "+v"(TD(A7))                              \
                          : [u0] "v"(UA[0]), [u1] "v"(UA[1]), [u2] "v"(UA[2]), [u3] "v"(UA[3]), [u4] "v"(UB[0]), [u5] "v"(UB[1]),  \

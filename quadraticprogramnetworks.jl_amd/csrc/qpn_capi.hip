@@ -809,7 +809,8 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                     for (int k = 0; k < ctx->mirror_count; ++k) a.mirror[k] = ctx->mirror_peer[k] + x_off;
                 }
             }
-            HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
+            if (qpn_schur_wg2_shape(n, m)) HIPCHK(ctx, qpn_launch_schur_wg2_nodes(a, s));
+            else HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
             a.x = nullptr; a.n_mirror = 0;
         } else HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
         if (need_general) {
@@ -866,7 +867,8 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
     nodes_poll_declines(h);
     // mid-size nodes: the fused workgroup kernel (no workspace) or, for A/B runs, the routes it replaced (ctx->mid_route)
     const bool mid_ok = qpn_schur_mid_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
-    const bool wg_shape = ctx->mid_route == 1 && mid_ok;
+    const bool wg2_ok = qpn_schur_wg2_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
+    const bool wg_shape = ctx->mid_route == 1 && (mid_ok || wg2_ok);
     const bool mid_shape = ctx->mid_route == 2 && mid_ok;
     const bool need_ws = !(h && (mfma_shape || mid_shape || wg_shape) && h->decl_state == 2);
 

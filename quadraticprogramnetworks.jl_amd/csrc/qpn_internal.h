@@ -118,6 +118,10 @@ hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream
 bool qpn_schur_wg_shape(int n, int m);
 hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream);              // a.nd set; declined nodes keep status -1
 
+// qpn_avi_schur_wg2.hip: the fused workgroup kernel for n, m <= 128 (one of them > 64): two wavefronts per row tile
+bool qpn_schur_wg2_shape(int n, int m);
+hipError_t qpn_launch_schur_wg2_nodes(const AviBatchArgs &a, hipStream_t stream);             // a.nd set; declined nodes keep status -1
+
 // qpn_avi_schur.hip: MFMA Schur-complement variant for items of shape [free STD x n | GAVI x m]
 hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, double *dbgc, double *dbgW,
                                       double *dbgh, hipStream_t stream);

@@ -13,11 +13,12 @@ from qpn_amd.engine import colmajor
 from qpn_amd._lib import OPT_MID_ROUTE
 sizes = [int(x) for x in sys.argv[1:]] or [33, 40, 48, 56, 64]
 routes = [int(x) for x in os.environ.get("ROUTES", "1,2").split(",")]
-cnt = int(os.environ.get("CNT", "4000")); reps = int(os.environ.get("REPS", "20"))
+cnt0 = int(os.environ.get("CNT", "4000")); reps = int(os.environ.get("REPS", "20"))
 eng = qpn_amd.Engine(0)
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
 for n in sizes:
     m = n
+    cnt = cnt0 if n <= 64 else min(cnt0, 1024)
     Q, R_, qd, A, B, l, u = P.synth_nodes(5000 + n, cnt, n, m)
     args = [t(colmajor(Q)), t(colmajor(R_)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(P.shared_params())]
     for route in routes:
