@@ -98,6 +98,18 @@ __device__ __forceinline__ double xsum_rows(double v)
     return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
 }
 
+#ifdef QPN_STAMPS
+#define STAMP(slot)                                                     \
+    do {                                                                \
+        unsigned long long now__ = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        stamp_acc[slot] += now__ - stamp_last;                          \
+        stamp_last = now__;                                             \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 // LDS map (doubles; ~151 KB at n = m = 128: one workgroup per CU).  The big area is, in turn: two Qd panels [2][16][n_pad + 2], the published pivot rows [2][4][VLD], W~
 // for the S product [n_pad][m_pad], the S tiles changing hands [NR][NR][4][64], Ad for the post-check [n][m | 1].
 constexpr int OFF_Q = 0;                // q = [g ; b] in item order                              [256]
@@ -107,11 +119,12 @@ constexpr int OFF_U = 256;              // Stage A: per row tile its 16 x 4 pane
 constexpr int OFF_PR = 1280;            // Stage A: raw pivot block + x_piv, two buffers          [2][24]
 constexpr int OFF_RED = 1328;           // block reduction                                        [16]
 constexpr int OFF_H = 1344;             // h (the eliminated extra column)                        [128]
-constexpr int OFF_COL = 1472;           // Stage B: entering column, two buffers, row i at [i & 3][i >> 2], 34 per i & 3   [2][136]
-constexpr int OFF_B = 1744;             // Stage B, leader's tables: fixed pair bounds sLo, sHi [128 each], the rows' current
+constexpr int OFF_COL = 1472;           // Stage B: the pivot column for the exchange, two buffers, and the next column as it
+                                        //   stands; row i at [i & 3][i >> 2], 34 doubles per i & 3                    [3][136]
+constexpr int OFF_B = 1880;             // Stage B, leader's tables: fixed pair bounds sLo, sHi [128 each], the rows' current
                                         //   intervals sRowLo, sRowHi [128 each], nonbasic values by column [136], bound flags
                                         //   by pair (int) [128], the waves' pieces of the pivot row [8][16], the decision [8]
-constexpr int OFF_BIG = 2768;
+constexpr int OFF_BIG = 2904;
 constexpr int CLD = 34;                 // doubles per (i & 3) run of the column buffer (32 + 2: the four runs on different banks)
 __host__ __device__ constexpr int wg2_lds_doubles(int n, int m, int pad)
 {
@@ -170,7 +183,8 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
     extern __shared__ __attribute__((aligned(32))) double sm[];
     double *const sQ = sm + OFF_Q, *const sU0 = sm + OFF_U + 64 * I, *const sPr = sm + OFF_PR;
     double *const sRed = sm + OFF_RED, *const sH = sm + OFF_H, *const sV = sm + OFF_BIG, *const sW = sm + OFF_BIG;
-    double *const colP = sm + OFF_COL;
+    double *const colU = sm + OFF_COL, *const colN = sm + OFF_COL + 8 * CLD;      // (see the LDS map)
+    double *const sCv = sm + OFF_U;                     // c = b - Ad h on its way to the leader (over Stage-A scratch)   [128]
 
     const double *Q_ = a.nd.Qd + (size_t)b * n * n;
     const double *A_ = a.nd.Ad + (size_t)b * m * n;
@@ -184,6 +198,10 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         }
     };
 
+#ifdef QPN_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     // ---- load ---------------------------------------------------------------------------------------------------------
     // H(r, c) = Qd[c * n + r] (padded rows: identity), C~(r, k) = Ad[r * m + k] (Ad is m x n column-major)
     const d4 z4 = {0.0, 0.0, 0.0, 0.0};
@@ -407,8 +425,10 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         double kx = (l < 16 && 16 * I + l < n) ? sQ[16 * I + l] : 0.0;       // lane l <-> row 16 I + l of the extra column
         __syncthreads();                    // the staged Qd has been read: the published pivot rows reuse its area
         if (declined) fail = true;          // (the steps below, and everything behind them, are skipped)
+        STAMP(0);   // load
         M_STEP4(H, 0, th0) M_STEP4(H, 4, th1) M_STEP4(H, 8, th2) M_STEP4(H, 12, th3)
         M_STEP4(H, 16, th4) M_STEP4(H, 20, th5) M_STEP4(H, 24, th6) M_STEP4(H, 28, th7)
+        STAMP(1);   // stage A
         if (!fail) {
         l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
         __syncthreads();                               // X1: the last step's pivot rows have been read (sW reuses them)
@@ -447,7 +467,6 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         }
         __syncthreads();                               // X3: W~ in LDS has been read: S goes through the same area
         // ---- S from row tiles to COLUMN tiles: H wave I hands tile (I, J) to H wave J; c goes to the leader
-        double *const sCv = colP + 4 * CLD;            // c, lane <-> row: in the second column buffer (the first pivot publishes into buffer 0)
         {
 #define M_SOUT(J, T)                                                                                \
     if constexpr ((J) < NR) {                                                                       \
@@ -468,79 +487,21 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
 #define M_TLOAD(j) double TD(j) = ((j) < 4 * NR) ? sX[((((j) >> 2) * NR + I) * 4 + ((j) & 3)) * 64 + l] : 0.0;
         FOR_T(M_TLOAD)
 #undef M_TLOAD
-        const bool lead = v == 0;
-        const bool act0 = l < m, act1 = 64 + l < m;
-        double xb0 = (lead && act0) ? sCv[l] : 0.0, xb1 = (lead && act1) ? sCv[64 + l] : 0.0;
         __syncthreads();                               // X5: S has been read: Ad for the post-check goes into the same area
         l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
         M_STAGE_AD
         // ================= Stage B: Lemke on the Schur dictionary =================
         // pair k (k < m) <-> item row n + k.  ids: p_k -> k, d_k -> 128 + k, artificial -> 256; column index 128 = the extra
-        // (covering) column.  Wave 0 is the LEADER (see qpn_avi_schur_wg.hip); its row vectors carry rows l and 64 + l, its
-        // column vectors columns l and 64 + l.
-        double *const sLo = sm + OFF_B, *const sHi = sm + OFF_B + 128;     // fixed pair bounds (looked up by a uniform index)
-        double *const sRowLo = sm + OFF_B + 256, *const sRowHi = sm + OFF_B + 384;     // interval of each row's basic variable
-        double *const sNb = sm + OFF_B + 512;                              // value of each column's nonbasic variable (128: extra)
-        int *const sSat = reinterpret_cast<int *>(sm + OFF_B + 648);       // pair k: 1 = bounded variable rests at its upper bound
+        // (covering) column.  The LEADER is C wave 0 (wave NR): it keeps the bookkeeping and runs the ratio test; the H waves
+        // hold the dictionary.  Per pivot t:
+        //   barrier B(t): the leader's decision {what, row r, 1 / pivot, column c, next column} is posted; the owner of the NEXT
+        //   column publishes it AS IT STANDS (before the exchange) -- barrier A'(t) -- the H waves run the exchange of pivot t
+        //   while the leader derives the next column from the old one (T'[i][j] = T[i][j] - u_i pv_j, row r: -pv_j: the
+        //   same two operations on the same bits as the tiles' own update) and takes its next turn -- barrier B(t+1).
+        // So the exchange (4 NR v_fma_f64 + fix-ups + two register dispatches) and the leader's turn overlap.
         double *const rowbuf = sm + OFF_B + 776 + 16 * I;                  // this H wave's piece of the pivot row            [16]
-        // (the leader keeps in REGISTERS only what every lane updates every pivot -- basic values, the extra column -- and the two
-        //  id vectors it searches; bounds, nonbasic values and flags, touched at one index per pivot, live in the tables above:
-        //  the wave also carries 4 NR dictionary entries per lane)
-        if (lead) {
-            double lo_0 = -QINF, hi_0 = QINF, lo_1 = -QINF, hi_1 = QINF;
-            if (act0) { lo_0 = a.nd.l[(size_t)b * m + l]; hi_0 = a.nd.u[(size_t)b * m + l]; }
-            if (act1) { lo_1 = a.nd.l[(size_t)b * m + 64 + l]; hi_1 = a.nd.u[(size_t)b * m + 64 + l]; }
-            sLo[l] = lo_0; sHi[l] = hi_0; sLo[64 + l] = lo_1; sHi[64 + l] = hi_1;
-            sRowLo[l] = lo_0; sRowHi[l] = hi_0; sRowLo[64 + l] = lo_1; sRowHi[64 + l] = hi_1;
-            sNb[l] = 0.0; sNb[64 + l] = 0.0; if (l < 8) sNb[128 + l] = 0.0;
-            sSat[l] = 0; sSat[64 + l] = 0;
-        }
-        int rowvar0 = act0 ? l : -1, rowvar1 = act1 ? 64 + l : -1;
-        int colvar0 = act0 ? NBP + l : -1, colvar1 = act1 ? NBP + 64 + l : -1;
-        int cvx = VTH;
-        double tcol0 = 0.0, tcol1 = 0.0;
-        const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
-        int c = XC, par = 0;
-        bool sneg = true;
-        double self_lim = 0.0, elo = 0.0, ehi = QINF;
-        const double slack = 1e-10, ptol = a.piv_tol;
-        auto col_of = [&](int var) -> int {
-            int cc = wave_first(colvar0 == var);
-            if (cc >= 0) return cc;
-            cc = wave_first(colvar1 == var);
-            return cc >= 0 ? 64 + cc : (cvx == var ? XC : -1);
-        };
-        if (lead) {
-            const double lo_0 = sRowLo[l], hi_0 = sRowHi[l], lo_1 = sRowLo[64 + l], hi_1 = sRowHi[64 + l];
-            double viol = 0.0, viol1 = 0.0;
-            if (act0) viol = xb0 < lo_0 ? lo_0 - xb0 : (xb0 > hi_0 ? xb0 - hi_0 : 0.0);
-            if (act1) viol1 = xb1 < lo_1 ? lo_1 - xb1 : (xb1 > hi_1 ? xb1 - hi_1 : 0.0);
-            const double theta0 = wave_max_f64(fmax(viol, viol1));
-            if (ubool(theta0 <= a.feas_tol)) status = QPN_SUCCESS;
-            else {
-                auto cover = [&](bool act, double &xb, double lo, double hi) -> double {
-                    double cov = 0.0;
-                    if (!act) return 0.0;
-                    if (xb < lo) {
-                        double tgt = lo + (theta0 - (lo - xb));
-                        if (hi < QINF) { double mid = 0.5 * (lo + hi); if (tgt > mid) tgt = mid; }
-                        cov = (tgt - xb) / theta0; xb = tgt;
-                    } else if (xb > hi) {
-                        double tgt = hi - (theta0 - (xb - hi));
-                        if (lo > -QINF) { double mid = 0.5 * (lo + hi); if (tgt < mid) tgt = mid; }
-                        cov = (tgt - xb) / theta0; xb = tgt;
-                    }
-                    return cov;
-                };
-                tcol0 = cover(act0, xb0, lo_0, hi_0);
-                tcol1 = cover(act1, xb1, lo_1, hi_1);
-                if (l == 0) sNb[XC] = theta0;
-                self_lim = theta0;
-                status = QPN_MAX_ITERS;
-            }
-            if (l == 0) sDecI[0] = status == QPN_MAX_ITERS ? CODE_PIVOT : CODE_STOP;
-        }
-        __syncthreads();                               // X6: the leader's first decision is posted
+        __syncthreads();                               // X6 = B(0): the leader's first decision is posted
+        STAMP(4);   // W~ hand-over, S product, tile hand-over, Ad staging
         int code = uni(sDecI[0]);
 #define T_OPS_RW_A [t0] "+v"(TD(0)), [t1] "+v"(TD(1)), [t2] "+v"(TD(2)), [t3] "+v"(TD(3)), [t4] "+v"(TD(4)), [t5] "+v"(TD(5)),     \
                        [t6] "+v"(TD(6)), [t7] "+v"(TD(7)), [t8] "+v"(TD(8)), [t9] "+v"(TD(9)), [t10] "+v"(TD(10)), [t11] "+v"(TD(11)), \
@@ -557,153 +518,22 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
 #define LEAVES16(OP) OP "%[t0]", OP "%[t1]", OP "%[t2]", OP "%[t3]", OP "%[t4]", OP "%[t5]", OP "%[t6]", OP "%[t7]",                \
                          OP "%[t8]", OP "%[t9]", OP "%[t10]", OP "%[t11]", OP "%[t12]", OP "%[t13]", OP "%[t14]", OP "%[t15]"
         while (code != CODE_STOP) {
-            c = uni(c);
-            // ---- the entering column, published by the lanes that hold it: row i goes to [i & 3][i >> 2]
-            {
-                double *const cp = colP + par * 4 * CLD;
-                if (c == XC) { if (lead) { cp[(l & 3) * CLD + (l >> 2)] = tcol0; cp[(l & 3) * CLD + 16 + (l >> 2)] = tcol1; } }
-                else if (I == (c >> 4) && lc == (c & 15)) {
-                    d4 *const dst = reinterpret_cast<d4 *>(cp + lq * CLD);
-                    dst[0] = d4{TD(0), TD(1), TD(2), TD(3)};
-                    dst[1] = d4{TD(4), TD(5), TD(6), TD(7)};
-                    dst[2] = d4{TD(8), TD(9), TD(10), TD(11)};
-                    dst[3] = d4{TD(12), TD(13), TD(14), TD(15)};
-                    dst[4] = d4{TD(16), TD(17), TD(18), TD(19)};
-                    if constexpr (NR > 5) dst[5] = d4{TD(20), TD(21), TD(22), TD(23)};
-                    if constexpr (NR > 6) dst[6] = d4{TD(24), TD(25), TD(26), TD(27)};
-                    if constexpr (NR > 7) dst[7] = d4{TD(28), TD(29), TD(30), TD(31)};
-                }
-            }
-            __syncthreads();                                // barrier A
-            if (lead) {
-                // ================= the leader's turn: ratio test, bookkeeping, decision =================
-                const double *const cp = colP + par * 4 * CLD + (l & 3) * CLD + (l >> 2);
-                const double cm0 = act0 ? cp[0] : 0.0, cm1 = act1 ? cp[16] : 0.0;       // (rows beyond m: whatever LDS holds there)
-                // ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first), two rows per lane
-                const int sbit = sneg ? (int)0x80000000 : 0;
-                const double g0 = __hiloint2double(__double2hiint(cm0) ^ sbit, __double2loint(cm0));
-                const double g1 = __hiloint2double(__double2hiint(cm1) ^ sbit, __double2loint(cm1));
-                const double rc0 = rcp64(g0), rc1 = rcp64(g1);
-                // the bound the row's basic variable moves towards: from the rows' interval tables (one read per row)
-                const double tb0 = (__double2hiint(g0) < 0 ? sRowLo : sRowHi)[l], tb1 = (__double2hiint(g1) < 0 ? sRowLo : sRowHi)[64 + l];
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
-                const bool cnd0 = (act0 & (fabs(g0) > ptol)) & (fabs(tb0) < QINF);
-                const bool cnd1 = (act1 & (fabs(g1) > ptol)) & (fabs(tb1) < QINF);
-#pragma clang diagnostic pop
-                const double dd0 = cnd0 ? (tb0 - xb0) * rc0 : QINF, dd1 = cnd1 ? (tb1 - xb1) * rc1 : QINF;
-                const double d10 = fma(slack, fabs(rc0), dd0), d11 = fma(slack, fabs(rc1), dd1);
-                const double dmax = wave_min64_with_limit_f64(min_f64_nc(d10, d11), self_lim);
-                int dcode = CODE_PIVOT, r = 0, cnext = XC;
-                double inv = 0.0;
-                if (pivots >= max_piv) dcode = CODE_STOP;          // status stays MAX_ITERS
-                else if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; dcode = CODE_STOP; }
-                else {
-                    const unsigned long long bal0 = qpn_ballot(dd0 <= dmax), bal1 = qpn_ballot(dd1 <= dmax);
-                    const bool newx = c == XC;
-                    const int ch = c >> 6, cl = c & 63;
-                    const int ve = newx ? cvx : (ch ? readlane_i32(colvar1, cl) : readlane_i32(colvar0, cl));     // the entering variable
-                    (void)cl;
-                    const double eloW = elo, ehiW = ehi;                            // ... and the interval it lives in once basic
-                    double delta, vx = 0.0, tcz0 = tcol0, tcz1 = tcol1, enter_val = 0.0, nbW = 0.0;
-                    int rW = -1, kW = -1, auW = 0, vlW = ve;
-                    if ((bal0 | bal1) == 0ull) {
-                        // the entering variable reaches its own opposite bound first: no basis change
-                        dcode = CODE_FLIP;
-                        delta = sneg ? -self_lim : self_lim;
-                        if (ve == VTH) { nbW = 0.0; status = QPN_SUCCESS; dcode = CODE_STOP; }
-                        else {
-                            const int k = ve;
-                            const int au = sneg ? 0 : 1;
-                            nbW = udbl(au ? sHi[k] : sLo[k]);
-                            kW = k; auW = au;
-                            pivots++;
-                            sneg = au != 0;
-                            self_lim = QINF;
-                            if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
-                            cnext = col_of(NBP + k);
-                            if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
-                        }
-                    } else {
-                        if (__popcll(bal0) + __popcll(bal1) == 1) r = bal0 ? __ffsll((long long)bal0) - 1 : 64 + __ffsll((long long)bal1) - 1;
-                        else {
-                            const bool ca0 = dd0 <= dmax, ca1 = dd1 <= dmax;
-                            double ag0 = ca0 ? fabs(g0) : -1.0, ag1 = ca1 ? fabs(g1) : -1.0;
-                            if (ca0 && rowvar0 == VTH) ag0 = QINF;
-                            if (ca1 && rowvar1 == VTH) ag1 = QINF;
-                            const double bestg = wave_max_f64(fmax(ag0, ag1));
-                            const int r0 = wave_first(ca0 && ag0 == bestg);
-                            r = r0 >= 0 ? r0 : 64 + wave_first(ca1 && ag1 == bestg);
-                        }
-                        r = uni(r);
-                        const int rh = r >> 6, rl = r & 63;
-                        double step = rh ? readlane_f64(dd1, rl) : readlane_f64(dd0, rl);
-                        if (step < 0.0) step = 0.0;
-                        const double leave_val = rh ? readlane_f64(tb1, rl) : readlane_f64(tb0, rl);
-                        const double rcr = rh ? readlane_f64(rc1, rl) : readlane_f64(rc0, rl);
-                        inv = sneg ? -rcr : rcr;                    // 1 / T[r][c]
-                        delta = sneg ? -step : step;
-                        const int vl = rh ? readlane_i32(rowvar1, rl) : readlane_i32(rowvar0, rl);
-                        enter_val = udbl(sNb[c]) + delta;
-                        if (newx) { vx = -inv; tcz0 = 0.0; tcz1 = 0.0; }
-                        else vx = (rh ? readlane_f64(tcol1, rl) : readlane_f64(tcol0, rl)) * inv;
-                        rW = r; vlW = vl; nbW = leave_val;
-                        pivots++;
-                        if (vl == VTH) { status = QPN_SUCCESS; dcode = CODE_STOP; }
-                        else {
-                            int vn;
-                            const int k = vl < NBP ? vl : vl - NBP;
-                            const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
-                            const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
-                            if (vl < NBP) {
-                                // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters
-                                const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
-                                kW = k; auW = au;
-                                vn = NBP + k;
-                                sneg = au != 0;
-                                self_lim = QINF;
-                                if (cls == 2) { elo = 0.0; ehi = 0.0; }
-                                else if (au) { elo = -QINF; ehi = 0.0; }
-                                else { elo = 0.0; ehi = QINF; }
-                            } else {
-                                // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
-                                const int au = uni(sSat[k]);
-                                vn = k;
-                                sneg = au != 0;
-                                self_lim = udbl(hk0 - lk0);         // +inf for a free pair
-                                if (cls == 2) sneg = false;
-                                elo = lk0; ehi = hk0;
-                            }
-                            cnext = (vn == ve) ? -1 : col_of(vn);
-                            if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
-                        }
-                    }
-                    // values, the extra column, bookkeeping write-backs (one definition of every vector per iteration)
-                    const bool isr0 = l == rW, isr1 = 64 + l == rW;
-                    xb0 = isr0 ? enter_val : fma(delta, cm0, xb0);
-                    xb1 = isr1 ? enter_val : fma(delta, cm1, xb1);
-                    tcol0 = isr0 ? -vx : fma(-cm0, vx, tcz0);
-                    tcol1 = isr1 ? -vx : fma(-cm1, vx, tcz1);
-                    if (isr0) rowvar0 = ve;
-                    if (isr1) rowvar1 = ve;
-                    if (!newx && l == c) colvar0 = vlW;
-                    if (!newx && 64 + l == c) colvar1 = vlW;
-                    if (newx) cvx = vlW;
-                    if (l == 0) {
-                        // the tables: row r now holds the entering variable (its interval was chosen when it was picked), column c
-                        // the leaving one at the value it left at, pair k its new bound flag
-                        if (rW >= 0) { sRowLo[rW] = eloW; sRowHi[rW] = ehiW; }
-                        sNb[c] = nbW;
-                        if (kW >= 0) sSat[kW] = auW;
-                    }
-                }
-                if (l == 0) { sDecI[0] = dcode; sDecI[1] = r; sDecI[2] = cnext; sDecD[0] = inv; }
-            }
-            __syncthreads();                                // barrier B
-            code = uni(sDecI[0]);
-            const int r = uni(sDecI[1]), cnext = uni(sDecI[2]);
+            const int r = uni(sDecI[1]), c = uni(sDecI[2]), cnext = uni(sDecI[3]), par = uni(sDecI[4]);
             const double inv = udbl(sDecD[0]);
-            if (code == CODE_STOP) break;
+            // ---- the NEXT entering column as it stands, published by the 4 lanes that hold it: row i goes to [i & 3][i >> 2]
+            if (cnext != XC && I == (cnext >> 4) && lc == (cnext & 15)) {
+                d4 *const dst = reinterpret_cast<d4 *>(colN + lq * CLD);
+                dst[0] = d4{TD(0), TD(1), TD(2), TD(3)};
+                dst[1] = d4{TD(4), TD(5), TD(6), TD(7)};
+                dst[2] = d4{TD(8), TD(9), TD(10), TD(11)};
+                dst[3] = d4{TD(12), TD(13), TD(14), TD(15)};
+                dst[4] = d4{TD(16), TD(17), TD(18), TD(19)};
+                if constexpr (NR > 5) dst[5] = d4{TD(20), TD(21), TD(22), TD(23)};
+                if constexpr (NR > 6) dst[6] = d4{TD(24), TD(25), TD(26), TD(27)};
+                if constexpr (NR > 7) dst[7] = d4{TD(28), TD(29), TD(30), TD(31)};
+            }
+            __syncthreads();                                // barrier A'
+            STAMP(5);   // decision read + next column + barrier A'
             // ---- the exchange (a flip runs it with empty lane masks and a zero row: a no-op, so the tile registers have one
             // definition per iteration)
             {
@@ -730,7 +560,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                 wave_sync();
                 const double pv = piv ? rowbuf[lc] * inv : 0.0;
                 // this lane's column entries: rows lq + 4 k, k = 4 R + g
-                const d4 *const up = reinterpret_cast<const d4 *>(colP + par * 4 * CLD + lq * CLD);
+                const d4 *const up = reinterpret_cast<const d4 *>(colU + par * 4 * CLD + lq * CLD);
                 const double inv_s = udbl(inv);
 #define M_XCHG4(A0, A1, A2, A3, U)                                                                                                 \
                 asm volatile("v_fma_f64 %[a0], -%[u0], %[pv], %[a0]\n\tv_fma_f64 %[a1], -%[u1], %[pv], %[a1]\n\t"                      \
@@ -770,18 +600,13 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                              "s_mov_b64 exec, -1"
                              : T_OPS_RW_B : [cs] "s"(csB), [mr] "s"(mrow), [pv] "v"(pv) : "scc");
             }
-            c = cnext;
-            par ^= 1;
+            STAMP(7);   // the exchange
+            __syncthreads();                                // barrier B
+            STAMP(6);   // waiting for the leader's decision
+            code = uni(sDecI[0]);
         }
-            __syncthreads();                                // every wave is out of the loop
-            if (v == 0) {
-                // the leader posts the values by variable id (the padded columns of W~ get a finite 0: 0 x 0)
-                if (l < m) { sval[rowvar0] = xb0; sval[colvar0] = sNb[l]; } else sval[NBP + l] = 0.0;
-                if (64 + l < m) { sval[rowvar1] = xb1; sval[colvar1] = sNb[64 + l]; } else sval[NBP + 64 + l] = 0.0;
-                if (l == 0) sval[cvx] = sNb[XC];
-            }
-            __syncthreads();
-
+        __syncthreads();                                // every wave is out of the loop
+        __syncthreads();                                // the leader has posted the values by variable id
         }
 #undef LEAVES16
 #undef T_OPS_R_B
@@ -842,16 +667,243 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         __syncthreads();                               // X5 (... and take them)
         l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
         M_STAGE_AD
-        __syncthreads();                               // X6
-        int code = uni(sDecI[0]);
-        // ---- the C wave sits the pivot loop out, barrier for barrier (A, B per pivot), its W~ tiles untouched ...
-        while (code != CODE_STOP) {
-            __syncthreads();                            // barrier A
-            __syncthreads();                            // barrier B
+
+        int code;
+        if (v == NR) {
+            // ================================ the LEADER (C wave 0): ratio test, bookkeeping, decisions ================================
+            const bool lead = true;
+            const bool act0 = l < m, act1 = 64 + l < m;
+            double xb0 = act0 ? sCv[l] : 0.0, xb1 = act1 ? sCv[64 + l] : 0.0;
+            double *const sLo = sm + OFF_B, *const sHi = sm + OFF_B + 128;     // fixed pair bounds (looked up by a uniform index)
+            double *const sRowLo = sm + OFF_B + 256, *const sRowHi = sm + OFF_B + 384;     // interval of each row's basic variable
+            double *const sNb = sm + OFF_B + 512;                              // value of each column's nonbasic variable (128: extra)
+            int *const sSat = reinterpret_cast<int *>(sm + OFF_B + 648);       // pair k: 1 = bounded variable rests at its upper bound
+            // (the leader keeps in REGISTERS only what every lane updates every pivot -- basic values, the extra column -- and the two
+            //  id vectors it searches; bounds, nonbasic values and flags, touched at one index per pivot, live in the tables above:
+            //  the wave also carries 4 NR dictionary entries per lane)
+            if (lead) {
+                double lo_0 = -QINF, hi_0 = QINF, lo_1 = -QINF, hi_1 = QINF;
+                if (act0) { lo_0 = a.nd.l[(size_t)b * m + l]; hi_0 = a.nd.u[(size_t)b * m + l]; }
+                if (act1) { lo_1 = a.nd.l[(size_t)b * m + 64 + l]; hi_1 = a.nd.u[(size_t)b * m + 64 + l]; }
+                sLo[l] = lo_0; sHi[l] = hi_0; sLo[64 + l] = lo_1; sHi[64 + l] = hi_1;
+                sRowLo[l] = lo_0; sRowHi[l] = hi_0; sRowLo[64 + l] = lo_1; sRowHi[64 + l] = hi_1;
+                sNb[l] = 0.0; sNb[64 + l] = 0.0; if (l < 8) sNb[128 + l] = 0.0;
+                sSat[l] = 0; sSat[64 + l] = 0;
+            }
+            int rowvar0 = act0 ? l : -1, rowvar1 = act1 ? 64 + l : -1;
+            int colvar0 = act0 ? NBP + l : -1, colvar1 = act1 ? NBP + 64 + l : -1;
+            int cvx = VTH;
+            double tcol0 = 0.0, tcol1 = 0.0;
+            const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
+            int c = XC, par = 0;
+            bool sneg = true;
+            double self_lim = 0.0, elo = 0.0, ehi = QINF;
+            const double slack = 1e-10, ptol = a.piv_tol;
+            auto col_of = [&](int var) -> int {
+                int cc = wave_first(colvar0 == var);
+                if (cc >= 0) return cc;
+                cc = wave_first(colvar1 == var);
+                return cc >= 0 ? 64 + cc : (cvx == var ? XC : -1);
+            };
+            if (lead) {
+                const double lo_0 = sRowLo[l], hi_0 = sRowHi[l], lo_1 = sRowLo[64 + l], hi_1 = sRowHi[64 + l];
+                double viol = 0.0, viol1 = 0.0;
+                if (act0) viol = xb0 < lo_0 ? lo_0 - xb0 : (xb0 > hi_0 ? xb0 - hi_0 : 0.0);
+                if (act1) viol1 = xb1 < lo_1 ? lo_1 - xb1 : (xb1 > hi_1 ? xb1 - hi_1 : 0.0);
+                const double theta0 = wave_max_f64(fmax(viol, viol1));
+                if (ubool(theta0 <= a.feas_tol)) status = QPN_SUCCESS;
+                else {
+                    auto cover = [&](bool act, double &xb, double lo, double hi) -> double {
+                        double cov = 0.0;
+                        if (!act) return 0.0;
+                        if (xb < lo) {
+                            double tgt = lo + (theta0 - (lo - xb));
+                            if (hi < QINF) { double mid = 0.5 * (lo + hi); if (tgt > mid) tgt = mid; }
+                            cov = (tgt - xb) / theta0; xb = tgt;
+                        } else if (xb > hi) {
+                            double tgt = hi - (theta0 - (xb - hi));
+                            if (lo > -QINF) { double mid = 0.5 * (lo + hi); if (tgt < mid) tgt = mid; }
+                            cov = (tgt - xb) / theta0; xb = tgt;
+                        }
+                        return cov;
+                    };
+                    tcol0 = cover(act0, xb0, lo_0, hi_0);
+                    tcol1 = cover(act1, xb1, lo_1, hi_1);
+                    if (l == 0) sNb[XC] = theta0;
+                    self_lim = theta0;
+                    status = QPN_MAX_ITERS;
+                }
+            }
+            // the first entering column is the extra one: the leader's own
+            double cm0 = tcol0, cm1 = tcol1;
+            code = status == QPN_MAX_ITERS ? CODE_PIVOT : CODE_STOP;
+            for (;;) {
+                int dcode = code, r = 0, cnext = XC;
+                double inv = 0.0;
+                if (code != CODE_STOP) {
+                    // this pivot's column, for the exchange of the H waves: row i goes to [i & 3][i >> 2]
+                    {
+                        double *const cu = colU + par * 4 * CLD + (l & 3) * CLD + (l >> 2);
+                        cu[0] = cm0; cu[16] = cm1;
+                    }
+                    // ================= the leader's turn =================
+                    // ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first), two rows per lane
+                    const int sbit = sneg ? (int)0x80000000 : 0;
+                    const double g0 = __hiloint2double(__double2hiint(cm0) ^ sbit, __double2loint(cm0));
+                    const double g1 = __hiloint2double(__double2hiint(cm1) ^ sbit, __double2loint(cm1));
+                    const double rc0 = rcp64(g0), rc1 = rcp64(g1);
+                    // the bound the row's basic variable moves towards: from the rows' interval tables (one read per row)
+                    const double tb0 = (__double2hiint(g0) < 0 ? sRowLo : sRowHi)[l], tb1 = (__double2hiint(g1) < 0 ? sRowLo : sRowHi)[64 + l];
+    #pragma clang diagnostic push
+    #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
+                    const bool cnd0 = (act0 & (fabs(g0) > ptol)) & (fabs(tb0) < QINF);
+                    const bool cnd1 = (act1 & (fabs(g1) > ptol)) & (fabs(tb1) < QINF);
+    #pragma clang diagnostic pop
+                    const double dd0 = cnd0 ? (tb0 - xb0) * rc0 : QINF, dd1 = cnd1 ? (tb1 - xb1) * rc1 : QINF;
+                    const double d10 = fma(slack, fabs(rc0), dd0), d11 = fma(slack, fabs(rc1), dd1);
+                    const double dmax = wave_min64_with_limit_f64(min_f64_nc(d10, d11), self_lim);
+                    dcode = CODE_PIVOT;
+                    if (pivots >= max_piv) dcode = CODE_STOP;          // status stays MAX_ITERS
+                    else if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; dcode = CODE_STOP; }
+                    else {
+                        const unsigned long long bal0 = qpn_ballot(dd0 <= dmax), bal1 = qpn_ballot(dd1 <= dmax);
+                        const bool newx = c == XC;
+                        const int ch = c >> 6, cl = c & 63;
+                        const int ve = newx ? cvx : (ch ? readlane_i32(colvar1, cl) : readlane_i32(colvar0, cl));     // the entering variable
+                        (void)cl;
+                        const double eloW = elo, ehiW = ehi;                            // ... and the interval it lives in once basic
+                        double delta, vx = 0.0, tcz0 = tcol0, tcz1 = tcol1, enter_val = 0.0, nbW = 0.0;
+                        int rW = -1, kW = -1, auW = 0, vlW = ve;
+                        if ((bal0 | bal1) == 0ull) {
+                            // the entering variable reaches its own opposite bound first: no basis change
+                            dcode = CODE_FLIP;
+                            delta = sneg ? -self_lim : self_lim;
+                            if (ve == VTH) { nbW = 0.0; status = QPN_SUCCESS; dcode = CODE_STOP; }
+                            else {
+                                const int k = ve;
+                                const int au = sneg ? 0 : 1;
+                                nbW = udbl(au ? sHi[k] : sLo[k]);
+                                kW = k; auW = au;
+                                pivots++;
+                                sneg = au != 0;
+                                self_lim = QINF;
+                                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+                                cnext = col_of(NBP + k);
+                                if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
+                            }
+                        } else {
+                            if (__popcll(bal0) + __popcll(bal1) == 1) r = bal0 ? __ffsll((long long)bal0) - 1 : 64 + __ffsll((long long)bal1) - 1;
+                            else {
+                                const bool ca0 = dd0 <= dmax, ca1 = dd1 <= dmax;
+                                double ag0 = ca0 ? fabs(g0) : -1.0, ag1 = ca1 ? fabs(g1) : -1.0;
+                                if (ca0 && rowvar0 == VTH) ag0 = QINF;
+                                if (ca1 && rowvar1 == VTH) ag1 = QINF;
+                                const double bestg = wave_max_f64(fmax(ag0, ag1));
+                                const int r0 = wave_first(ca0 && ag0 == bestg);
+                                r = r0 >= 0 ? r0 : 64 + wave_first(ca1 && ag1 == bestg);
+                            }
+                            r = uni(r);
+                            const int rh = r >> 6, rl = r & 63;
+                            double step = rh ? readlane_f64(dd1, rl) : readlane_f64(dd0, rl);
+                            if (step < 0.0) step = 0.0;
+                            const double leave_val = rh ? readlane_f64(tb1, rl) : readlane_f64(tb0, rl);
+                            const double rcr = rh ? readlane_f64(rc1, rl) : readlane_f64(rc0, rl);
+                            inv = sneg ? -rcr : rcr;                    // 1 / T[r][c]
+                            delta = sneg ? -step : step;
+                            const int vl = rh ? readlane_i32(rowvar1, rl) : readlane_i32(rowvar0, rl);
+                            enter_val = udbl(sNb[c]) + delta;
+                            if (newx) { vx = -inv; tcz0 = 0.0; tcz1 = 0.0; }
+                            else vx = (rh ? readlane_f64(tcol1, rl) : readlane_f64(tcol0, rl)) * inv;
+                            rW = r; vlW = vl; nbW = leave_val;
+                            pivots++;
+                            if (vl == VTH) { status = QPN_SUCCESS; dcode = CODE_STOP; }
+                            else {
+                                int vn;
+                                const int k = vl < NBP ? vl : vl - NBP;
+                                const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
+                                const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
+                                if (vl < NBP) {
+                                    // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters
+                                    const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
+                                    kW = k; auW = au;
+                                    vn = NBP + k;
+                                    sneg = au != 0;
+                                    self_lim = QINF;
+                                    if (cls == 2) { elo = 0.0; ehi = 0.0; }
+                                    else if (au) { elo = -QINF; ehi = 0.0; }
+                                    else { elo = 0.0; ehi = QINF; }
+                                } else {
+                                    // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                                    const int au = uni(sSat[k]);
+                                    vn = k;
+                                    sneg = au != 0;
+                                    self_lim = udbl(hk0 - lk0);         // +inf for a free pair
+                                    if (cls == 2) sneg = false;
+                                    elo = lk0; ehi = hk0;
+                                }
+                                cnext = (vn == ve) ? -1 : col_of(vn);
+                                if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
+                            }
+                        }
+                        // values, the extra column, bookkeeping write-backs (one definition of every vector per iteration)
+                        const bool isr0 = l == rW, isr1 = 64 + l == rW;
+                        xb0 = isr0 ? enter_val : fma(delta, cm0, xb0);
+                        xb1 = isr1 ? enter_val : fma(delta, cm1, xb1);
+                        tcol0 = isr0 ? -vx : fma(-cm0, vx, tcz0);
+                        tcol1 = isr1 ? -vx : fma(-cm1, vx, tcz1);
+                        if (isr0) rowvar0 = ve;
+                        if (isr1) rowvar1 = ve;
+                        if (!newx && l == c) colvar0 = vlW;
+                        if (!newx && 64 + l == c) colvar1 = vlW;
+                        if (newx) cvx = vlW;
+                        if (l == 0) {
+                            // the tables: row r now holds the entering variable (its interval was chosen when it was picked), column c
+                            // the leaving one at the value it left at, pair k its new bound flag
+                            if (rW >= 0) { sRowLo[rW] = eloW; sRowHi[rW] = ehiW; }
+                            sNb[c] = nbW;
+                            if (kW >= 0) sSat[kW] = auW;
+                        }
+                    }
+                }
+                if (l == 0) { sDecI[0] = dcode; sDecI[1] = r; sDecI[2] = c; sDecI[3] = cnext; sDecI[4] = par; sDecD[0] = inv; }
+                __syncthreads();                            // barrier B(t): decision t is posted   (t = 0: X6)
+                code = dcode;
+                if (code == CODE_STOP) break;
+                __syncthreads();                            // barrier A'(t): the next column, as it stands, is in colN
+                // the next column after the exchange of pivot t, derived here: T'[i][j] = T[i][j] - u_i pv_j, row r: -pv_j (a flip:
+                // pv = 0; the extra column: the leader's own, already updated above)
+                if (cnext == XC) { cm0 = tcol0; cm1 = tcol1; }
+                else {
+                    const double *const cn = colN + (l & 3) * CLD + (l >> 2);
+                    const double o0 = act0 ? cn[0] : 0.0, o1 = act1 ? cn[16] : 0.0;
+                    double pvn = 0.0;
+                    if (code == CODE_PIVOT) pvn = udbl(((r >> 6) ? readlane_f64(o1, r & 63) : readlane_f64(o0, r & 63)) * inv);
+                    const double n0 = fma(-cm0, pvn, o0), n1 = fma(-cm1, pvn, o1);
+                    const bool pr = code == CODE_PIVOT;
+                    cm0 = (pr && l == r) ? -pvn : n0;
+                    cm1 = (pr && 64 + l == r) ? -pvn : n1;
+                }
+                c = cnext;
+                par ^= 1;
+            }
+            __syncthreads();                                // every wave is out of the loop
+            // the leader posts the values by variable id (the padded columns of W~ get a finite 0: 0 x 0)
+            if (l < m) { sval[rowvar0] = xb0; sval[colvar0] = sNb[l]; } else sval[NBP + l] = 0.0;
+            if (64 + l < m) { sval[rowvar1] = xb1; sval[colvar1] = sNb[64 + l]; } else sval[NBP + 64 + l] = 0.0;
+            if (l == 0) sval[cvx] = sNb[XC];
+            __syncthreads();
+        } else {
+            // ---- the other C waves sit the pivot loop out, barrier for barrier (B, A' per pivot), their W~ tiles untouched
+            __syncthreads();                                // B(0)
             code = uni(sDecI[0]);
+            while (code != CODE_STOP) {
+                __syncthreads();                            // A'
+                __syncthreads();                            // B
+                code = uni(sDecI[0]);
+            }
+            __syncthreads();                                // every wave is out of the loop
+            __syncthreads();                                // the leader has posted the values by variable id
         }
-        __syncthreads();                                // every wave is out of the loop
-        __syncthreads();                                // the leader has posted the values by variable id
         // ... and then forms its rows of x = W~ lambda - h: (W~ lambda)_row for the 4 rows (g) a lane holds, folded butterfly
         // over the 16 lanes of a DPP row (see the 64-class)
         l = lane_id_fresh(); lc = l & 15; lq = l >> 4;
@@ -966,8 +1018,12 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(nres, off, 64); nres = o > nres ? o : nres; }
     if (l == 0) sRed[v] = nres;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 64 * NR) {                               // the leader's lane 0: it holds the status and the pivot count
         if (badt > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
+#ifdef QPN_STAMPS
+        STAMP(0);   // (diagnostic builds: read-back + post-check are added to the load slot)
+        if (kp->stamps) for (int k = 0; k < 8; ++k) kp->stamps[(size_t)b * 8 + k] = stamp_acc[k];
+#endif
         kp->status[b] = status;
         double rs = sRed[0];
 #pragma unroll

@@ -27,7 +27,7 @@ names = ["load + read-back + post-check", "stage A: gather/publish + barrier", "
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
 for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
     m = n
-    for cnt in [int(x) for x in os.environ.get("CNT", "4000").split(",")]:
+    for cnt in [min(int(x), 4000 if n <= 64 else 1024) for x in os.environ.get("CNT", "4000").split(",")]:
         Q, R, qd, A, B, l, u = P.synth_nodes(5000 + n, cnt, n, m)
         args = [t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(P.shared_params())]
         st = torch.zeros((cnt, 8), dtype=torch.int64, device="cuda:0")
