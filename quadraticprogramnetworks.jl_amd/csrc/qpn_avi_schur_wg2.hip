@@ -255,7 +255,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
     };
 #define M_PANEL(J, CUR, NXT, READ)                                                                  \
     if constexpr ((J) < NR) {                                                                       \
-        if constexpr ((J) + 1 < NR) issue((J) + 1, NXT);                                            \
+        if constexpr ((J) + 3 < NR) issue((J) + 3, NXT);                                            \
         park((J), CUR);                                                                             \
         __syncthreads();                                                                            \
         { const double *const pb = sQd + ((J) & 1) * 16 * LDQ; (void)pb; READ }                     \
@@ -414,11 +414,12 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         // =============================================== the H-wave program ===============================================
         d4 th0 = z4, th1 = z4, th2 = z4, th3 = z4, th4 = z4, th5 = z4, th6 = z4, th7 = z4;      // row tile I of H
         {
-            double pa[4], pb_[4];
-            issue(0, pa);
-            M_PANEL(0, pa, pb_, M_TILE_OF(th0)) M_PANEL(1, pb_, pa, M_TILE_OF(th1)) M_PANEL(2, pa, pb_, M_TILE_OF(th2))
-            M_PANEL(3, pb_, pa, M_TILE_OF(th3)) M_PANEL(4, pa, pb_, M_TILE_OF(th4)) M_PANEL(5, pb_, pa, M_TILE_OF(th5))
-            M_PANEL(6, pa, pb_, M_TILE_OF(th6)) M_PANEL(7, pb_, pa, M_TILE_OF(th7))
+            // (four register sets: panels J + 1 .. J + 3 are in flight while panel J is parked and read)
+            double pa[4], pb_[4], pc[4], pd[4];
+            issue(0, pa); issue(1, pb_); issue(2, pc);
+            M_PANEL(0, pa, pd, M_TILE_OF(th0)) M_PANEL(1, pb_, pa, M_TILE_OF(th1)) M_PANEL(2, pc, pb_, M_TILE_OF(th2))
+            M_PANEL(3, pd, pc, M_TILE_OF(th3)) M_PANEL(4, pa, pd, M_TILE_OF(th4)) M_PANEL(5, pb_, pa, M_TILE_OF(th5))
+            M_PANEL(6, pc, pb_, M_TILE_OF(th6)) M_PANEL(7, pd, pc, M_TILE_OF(th7))
         }
         M_SCALE
         any_decline = declined;
@@ -446,23 +447,42 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
             const int arow = 16 * I + lc;
             auto jr = [&](int Jc) { int j = Jc + rot; return j >= NR ? j - NR : j; };
             const int j0 = jr(0), j1 = jr(1), j2 = jr(2), j3 = jr(3), j4 = jr(4), j5 = jr(5), j6 = jr(6), j7 = jr(7);
-#pragma unroll
-            for (int kk = 0; kk < 4 * NR; ++kk) {
+            // A operands (16 x 4 blocks of Ad, element (i = lc, k = lq)) in batches of 8 k-blocks, the next batch requested
+            // before the MFMAs of the current one: the round trips to L2 hide behind 8 x (NR + 1) MFMAs
+            auto aload = [&](int kk) -> double {
                 const int r = 4 * kk + lq;                              // k index: column of Ad, row of W~
-                const bool valid = r < n && arow < m;
+                const bool valid = kk < 4 * NR && r < n && arow < m;
                 const double t_ = A_[valid ? (size_t)r * m + arow : 0];
-                const double a_ = valid ? t_ : 0.0;
-                const double *wr = sW + r * pad + lc;
-                s0 = MFMA(a_, wr[16 * j0], s0);
-                s1 = MFMA(a_, wr[16 * j1], s1);
-                s2 = MFMA(a_, wr[16 * j2], s2);
-                s3 = MFMA(a_, wr[16 * j3], s3);
-                s4 = MFMA(a_, wr[16 * j4], s4);
-                if constexpr (NR > 5) s5 = MFMA(a_, wr[16 * j5], s5);
-                if constexpr (NR > 6) s6 = MFMA(a_, wr[16 * j6], s6);
-                if constexpr (NR > 7) s7 = MFMA(a_, wr[16 * j7], s7);
-                const double hb = lc == 0 ? sH[r] : 0.0;
-                sx = MFMA_NEGA(a_, hb, sx);
+                return valid ? t_ : 0.0;
+            };
+            double ab[8], an[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ab[q] = aload(q);
+#pragma unroll
+            for (int k0 = 0; k0 < 4 * NR; k0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) an[q] = aload(k0 + 8 + q);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int kk = k0 + q;
+                    if (kk < 4 * NR) {
+                        const int r = 4 * kk + lq;
+                        const double a_ = ab[q];
+                        const double *wr = sW + r * pad + lc;
+                        s0 = MFMA(a_, wr[16 * j0], s0);
+                        s1 = MFMA(a_, wr[16 * j1], s1);
+                        s2 = MFMA(a_, wr[16 * j2], s2);
+                        s3 = MFMA(a_, wr[16 * j3], s3);
+                        s4 = MFMA(a_, wr[16 * j4], s4);
+                        if constexpr (NR > 5) s5 = MFMA(a_, wr[16 * j5], s5);
+                        if constexpr (NR > 6) s6 = MFMA(a_, wr[16 * j6], s6);
+                        if constexpr (NR > 7) s7 = MFMA(a_, wr[16 * j7], s7);
+                        const double hb = lc == 0 ? sH[r] : 0.0;
+                        sx = MFMA_NEGA(a_, hb, sx);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ab[q] = an[q];
             }
         }
         __syncthreads();                               // X3: W~ in LDS has been read: S goes through the same area
@@ -631,10 +651,10 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         M_LOADC(0, tc0) M_LOADC(1, tc1) M_LOADC(2, tc2) M_LOADC(3, tc3) M_LOADC(4, tc4) M_LOADC(5, tc5) M_LOADC(6, tc6) M_LOADC(7, tc7)
 #undef M_LOADC
         {
-            double pa[4], pb_[4];
-            issue(0, pa);
-            M_PANEL(0, pa, pb_, ) M_PANEL(1, pb_, pa, ) M_PANEL(2, pa, pb_, ) M_PANEL(3, pb_, pa, )
-            M_PANEL(4, pa, pb_, ) M_PANEL(5, pb_, pa, ) M_PANEL(6, pa, pb_, ) M_PANEL(7, pb_, pa, )
+            double pa[4], pb_[4], pc[4], pd[4];
+            issue(0, pa); issue(1, pb_); issue(2, pc);
+            M_PANEL(0, pa, pd, ) M_PANEL(1, pb_, pa, ) M_PANEL(2, pc, pb_, ) M_PANEL(3, pd, pc, )
+            M_PANEL(4, pa, pd, ) M_PANEL(5, pb_, pa, ) M_PANEL(6, pc, pb_, ) M_PANEL(7, pd, pc, )
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -667,7 +687,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         __syncthreads();                               // X5 (... and take them)
         l = lane_id_fresh(); lc = l & 15; lq = l >> 4; tid = 64 * v + l;
         M_STAGE_AD
-
+        STAMP(4);   // (C waves) stage A is in slot 0 for them; W~ hand-over and the waits for the S product
         int code;
         if (v == NR) {
             // ================================ the LEADER (C wave 0): ratio test, bookkeeping, decisions ================================
@@ -746,6 +766,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                         double *const cu = colU + par * 4 * CLD + (l & 3) * CLD + (l >> 2);
                         cu[0] = cm0; cu[16] = cm1;
                     }
+                    STAMP(5);   // (leader) barriers + the next column derived
                     // ================= the leader's turn =================
                     // ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first), two rows per lane
                     const int sbit = sneg ? (int)0x80000000 : 0;
@@ -866,6 +887,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                     }
                 }
                 if (l == 0) { sDecI[0] = dcode; sDecI[1] = r; sDecI[2] = c; sDecI[3] = cnext; sDecI[4] = par; sDecD[0] = inv; }
+                STAMP(6);   // (leader) its turn
                 __syncthreads();                            // barrier B(t): decision t is posted   (t = 0: X6)
                 code = dcode;
                 if (code == CODE_STOP) break;

@@ -39,6 +39,9 @@ for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
         tot = s.sum(axis=1).mean()
         lp = float(res["pivots"].double().mean()) - n
         print(f"n = m = {n}, {cnt} nodes: mean {tot:.0f} clocks (s_memtime) per workgroup; {n // 4 + (n % 4 > 0)} block pivots, {lp:.1f} Lemke pivots")
+        if n > 64:      # csrc/qpn_avi_schur_wg2.hip: the stamps are the LEADER's (C wave 0)
+            names = ["load + stage A + read-back + post-check (leader = a C wave)", "-", "-", "-", "W~ hand-over, waits for S, Ad staging",
+                     "Lemke: barriers + next column derived", "Lemke: the leader's turn", "-"]
         for i, nm in enumerate(names):
             print(f"  {nm:42s} {s[:, i].mean():10.1f}  {100*s[:, i].mean()/tot:5.1f} %")
         print(f"  per block pivot {(s[:, 1:4].sum(axis=1).mean()) / (n // 4 + (n % 4 > 0)):8.0f}   per Lemke pivot {(s[:, 5:8].sum(axis=1).mean()) / max(lp, 1):8.0f}", flush=True)
