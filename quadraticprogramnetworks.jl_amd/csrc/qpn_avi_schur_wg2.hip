@@ -760,6 +760,10 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
             for (;;) {
                 int dcode = code, r = 0, cnext = XC;
                 double inv = 0.0;
+                // what the second half of the turn needs from the first
+                bool flip = false, pivot = false;
+                int ve = 0, vl = 0, kf = 0;
+                double rcr = 0.0, step = 0.0, leave_val = 0.0;
                 if (code != CODE_STOP) {
                     // this pivot's column, for the exchange of the H waves: row i goes to [i & 3][i >> 2]
                     {
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                         cu[0] = cm0; cu[16] = cm1;
                     }
                     STAMP(5);   // (leader) barriers + the next column derived
-                    // ================= the leader's turn =================
+                    // ================= the leader's turn, first half: WHAT the H waves wait for =================
                     // ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first), two rows per lane
                     const int sbit = sneg ? (int)0x80000000 : 0;
                     const double g0 = __hiloint2double(__double2hiint(cm0) ^ sbit, __double2loint(cm0));
@@ -775,11 +779,11 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                     const double rc0 = rcp64(g0), rc1 = rcp64(g1);
                     // the bound the row's basic variable moves towards: from the rows' interval tables (one read per row)
                     const double tb0 = (__double2hiint(g0) < 0 ? sRowLo : sRowHi)[l], tb1 = (__double2hiint(g1) < 0 ? sRowLo : sRowHi)[64 + l];
-    #pragma clang diagnostic push
-    #pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
                     const bool cnd0 = (act0 & (fabs(g0) > ptol)) & (fabs(tb0) < QINF);
                     const bool cnd1 = (act1 & (fabs(g1) > ptol)) & (fabs(tb1) < QINF);
-    #pragma clang diagnostic pop
+#pragma clang diagnostic pop
                     const double dd0 = cnd0 ? (tb0 - xb0) * rc0 : QINF, dd1 = cnd1 ? (tb1 - xb1) * rc1 : QINF;
                     const double d10 = fma(slack, fabs(rc0), dd0), d11 = fma(slack, fabs(rc1), dd1);
                     const double dmax = wave_min64_with_limit_f64(min_f64_nc(d10, d11), self_lim);
@@ -788,31 +792,21 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                     else if (uni(__double2hiint(dmax)) == 0x7ff00000) { status = QPN_RAY_TERM; dcode = CODE_STOP; }
                     else {
                         const unsigned long long bal0 = qpn_ballot(dd0 <= dmax), bal1 = qpn_ballot(dd1 <= dmax);
-                        const bool newx = c == XC;
                         const int ch = c >> 6, cl = c & 63;
-                        const int ve = newx ? cvx : (ch ? readlane_i32(colvar1, cl) : readlane_i32(colvar0, cl));     // the entering variable
-                        (void)cl;
-                        const double eloW = elo, ehiW = ehi;                            // ... and the interval it lives in once basic
-                        double delta, vx = 0.0, tcz0 = tcol0, tcz1 = tcol1, enter_val = 0.0, nbW = 0.0;
-                        int rW = -1, kW = -1, auW = 0, vlW = ve;
+                        ve = (c == XC) ? cvx : (ch ? readlane_i32(colvar1, cl) : readlane_i32(colvar0, cl));     // the entering variable
                         if ((bal0 | bal1) == 0ull) {
                             // the entering variable reaches its own opposite bound first: no basis change
+                            flip = true;
                             dcode = CODE_FLIP;
-                            delta = sneg ? -self_lim : self_lim;
-                            if (ve == VTH) { nbW = 0.0; status = QPN_SUCCESS; dcode = CODE_STOP; }
+                            if (ve == VTH) { status = QPN_SUCCESS; dcode = CODE_STOP; }
                             else {
-                                const int k = ve;
-                                const int au = sneg ? 0 : 1;
-                                nbW = udbl(au ? sHi[k] : sLo[k]);
-                                kW = k; auW = au;
+                                kf = ve;
                                 pivots++;
-                                sneg = au != 0;
-                                self_lim = QINF;
-                                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
-                                cnext = col_of(NBP + k);
+                                cnext = col_of(NBP + kf);               // (the id vectors do not change in a flip)
                                 if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
                             }
                         } else {
+                            pivot = true;
                             if (__popcll(bal0) + __popcll(bal1) == 1) r = bal0 ? __ffsll((long long)bal0) - 1 : 64 + __ffsll((long long)bal1) - 1;
                             else {
                                 const bool ca0 = dd0 <= dmax, ca1 = dd1 <= dmax;
@@ -825,70 +819,95 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
                             }
                             r = uni(r);
                             const int rh = r >> 6, rl = r & 63;
-                            double step = rh ? readlane_f64(dd1, rl) : readlane_f64(dd0, rl);
-                            if (step < 0.0) step = 0.0;
-                            const double leave_val = rh ? readlane_f64(tb1, rl) : readlane_f64(tb0, rl);
-                            const double rcr = rh ? readlane_f64(rc1, rl) : readlane_f64(rc0, rl);
+                            rcr = rh ? readlane_f64(rc1, rl) : readlane_f64(rc0, rl);
                             inv = sneg ? -rcr : rcr;                    // 1 / T[r][c]
-                            delta = sneg ? -step : step;
-                            const int vl = rh ? readlane_i32(rowvar1, rl) : readlane_i32(rowvar0, rl);
-                            enter_val = udbl(sNb[c]) + delta;
-                            if (newx) { vx = -inv; tcz0 = 0.0; tcz1 = 0.0; }
-                            else vx = (rh ? readlane_f64(tcol1, rl) : readlane_f64(tcol0, rl)) * inv;
-                            rW = r; vlW = vl; nbW = leave_val;
+                            vl = rh ? readlane_i32(rowvar1, rl) : readlane_i32(rowvar0, rl);
+                            step = rh ? readlane_f64(dd1, rl) : readlane_f64(dd0, rl);
+                            leave_val = rh ? readlane_f64(tb1, rl) : readlane_f64(tb0, rl);
                             pivots++;
                             if (vl == VTH) { status = QPN_SUCCESS; dcode = CODE_STOP; }
                             else {
-                                int vn;
-                                const int k = vl < NBP ? vl : vl - NBP;
-                                const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
-                                const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
-                                if (vl < NBP) {
-                                    // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters
-                                    const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
-                                    kW = k; auW = au;
-                                    vn = NBP + k;
-                                    sneg = au != 0;
-                                    self_lim = QINF;
-                                    if (cls == 2) { elo = 0.0; ehi = 0.0; }
-                                    else if (au) { elo = -QINF; ehi = 0.0; }
-                                    else { elo = 0.0; ehi = QINF; }
-                                } else {
-                                    // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
-                                    const int au = uni(sSat[k]);
-                                    vn = k;
-                                    sneg = au != 0;
-                                    self_lim = udbl(hk0 - lk0);         // +inf for a free pair
-                                    if (cls == 2) sneg = false;
-                                    elo = lk0; ehi = hk0;
-                                }
+                                // the complement of the leaving variable enters next.  (colvar / cvx still hold the entering id at
+                                // column c -- the write-back is in the second half --, which is never vn's; the id that lands
+                                // there, vl, is never its own complement either)
+                                const int vn = vl < NBP ? NBP + vl : vl - NBP;
                                 cnext = (vn == ve) ? -1 : col_of(vn);
                                 if (cnext < 0) { status = QPN_FAILURE; dcode = CODE_STOP; }
                             }
                         }
-                        // values, the extra column, bookkeeping write-backs (one definition of every vector per iteration)
-                        const bool isr0 = l == rW, isr1 = 64 + l == rW;
-                        xb0 = isr0 ? enter_val : fma(delta, cm0, xb0);
-                        xb1 = isr1 ? enter_val : fma(delta, cm1, xb1);
-                        tcol0 = isr0 ? -vx : fma(-cm0, vx, tcz0);
-                        tcol1 = isr1 ? -vx : fma(-cm1, vx, tcz1);
-                        if (isr0) rowvar0 = ve;
-                        if (isr1) rowvar1 = ve;
-                        if (!newx && l == c) colvar0 = vlW;
-                        if (!newx && 64 + l == c) colvar1 = vlW;
-                        if (newx) cvx = vlW;
-                        if (l == 0) {
-                            // the tables: row r now holds the entering variable (its interval was chosen when it was picked), column c
-                            // the leaving one at the value it left at, pair k its new bound flag
-                            if (rW >= 0) { sRowLo[rW] = eloW; sRowHi[rW] = ehiW; }
-                            sNb[c] = nbW;
-                            if (kW >= 0) sSat[kW] = auW;
-                        }
                     }
                 }
                 if (l == 0) { sDecI[0] = dcode; sDecI[1] = r; sDecI[2] = c; sDecI[3] = cnext; sDecI[4] = par; sDecD[0] = inv; }
-                STAMP(6);   // (leader) its turn
+                STAMP(6);   // (leader) first half of its turn: the decision
                 __syncthreads();                            // barrier B(t): decision t is posted   (t = 0: X6)
+                // ================= second half: the bookkeeping, while the H waves read the decision and publish the next column ====
+                if (flip || pivot) {
+                    const bool newx = c == XC;
+                    const double eloW = elo, ehiW = ehi;            // the interval the entering variable lives in once basic
+                    double delta, vx = 0.0, tcz0 = tcol0, tcz1 = tcol1, enter_val = 0.0, nbW = 0.0;
+                    int rW = -1, kW = -1, auW = 0, vlW = ve;
+                    if (flip) {
+                        delta = sneg ? -self_lim : self_lim;
+                        if (ve != VTH) {
+                            const int au = sneg ? 0 : 1;
+                            nbW = udbl(au ? sHi[kf] : sLo[kf]);
+                            kW = kf; auW = au;
+                            sneg = au != 0;
+                            self_lim = QINF;
+                            if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+                        }
+                    } else {
+                        if (step < 0.0) step = 0.0;
+                        delta = sneg ? -step : step;
+                        enter_val = udbl(sNb[c]) + delta;
+                        const int rh = r >> 6, rl = r & 63;
+                        // the extra column (scalar statement: prow = T[r][.] * inv; T[i][.] = fma(-cm_i, prow, T[i][.]); row r: -prow;
+                        // the pivot column's own entries start from 0 and its slot in the row carries -inv)
+                        if (newx) { vx = -inv; tcz0 = 0.0; tcz1 = 0.0; }
+                        else vx = (rh ? readlane_f64(tcol1, rl) : readlane_f64(tcol0, rl)) * inv;
+                        rW = r; vlW = vl; nbW = leave_val;
+                        if (vl != VTH) {
+                            const int k = vl < NBP ? vl : vl - NBP;
+                            const double lk0 = udbl(sLo[k]), hk0 = udbl(sHi[k]);
+                            const int cls = (lk0 == -QINF && hk0 == QINF) ? 2 : 0;
+                            if (vl < NBP) {
+                                // the bounded variable p_k left at a bound -- the upper one iff row r was a `hi` ratio --: d_k enters
+                                const int au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0;
+                                kW = k; auW = au;
+                                sneg = au != 0;
+                                self_lim = QINF;
+                                if (cls == 2) { elo = 0.0; ehi = 0.0; }
+                                else if (au) { elo = -QINF; ehi = 0.0; }
+                                else { elo = 0.0; ehi = QINF; }
+                            } else {
+                                // the multiplier d_k left at 0: p_k enters, moving off the bound it rests at
+                                const int au = uni(sSat[k]);
+                                sneg = au != 0;
+                                self_lim = udbl(hk0 - lk0);         // +inf for a free pair
+                                if (cls == 2) sneg = false;
+                                elo = lk0; ehi = hk0;
+                            }
+                        }
+                    }
+                    // values, the extra column, write-backs (one definition of every vector per iteration)
+                    const bool isr0 = l == rW, isr1 = 64 + l == rW;
+                    xb0 = isr0 ? enter_val : fma(delta, cm0, xb0);
+                    xb1 = isr1 ? enter_val : fma(delta, cm1, xb1);
+                    tcol0 = isr0 ? -vx : fma(-cm0, vx, tcz0);
+                    tcol1 = isr1 ? -vx : fma(-cm1, vx, tcz1);
+                    if (isr0) rowvar0 = ve;
+                    if (isr1) rowvar1 = ve;
+                    if (!newx && l == c) colvar0 = vlW;
+                    if (!newx && 64 + l == c) colvar1 = vlW;
+                    if (newx) cvx = vlW;
+                    if (l == 0) {
+                        // the tables: row r now holds the entering variable (its interval was chosen when it was picked), column c
+                        // the leaving one at the value it left at, pair k its new bound flag
+                        if (rW >= 0) { sRowLo[rW] = eloW; sRowHi[rW] = ehiW; }
+                        sNb[c] = nbW;
+                        if (kW >= 0) sSat[kW] = auW;
+                    }
+                }
                 code = dcode;
                 if (code == CODE_STOP) break;
                 __syncthreads();                            // barrier A'(t): the next column, as it stands, is in colN
