@@ -85,6 +85,12 @@ __device__ __forceinline__ void wave_sync()
 // on the original blocks, and 1e-15 is far inside the 1e-9 parity bar.
 // max(a, |b|) in ONE instruction (fmax(a, fabs(b)) costs three: the compiler canonicalises both operands first; the
 // callers feed no NaNs that matter: a NaN entry fails the pivot test and the item goes to the general kernel)
+__device__ __forceinline__ double min_abs_nc(double a, double b)      // min(a, |b|)
+{
+    double r;
+    asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ double max_abs_nc(double a, double b)
 {
     double r;
@@ -107,7 +113,7 @@ constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resi
 // FULL32 (node path only): the launch's nodes are n = m = 32 -- the hot shape gets its own instantiation, without the
 // ragged-shape code, predicates and padding selects (sizes are compile-time constants there)
 template <bool NODES, int STAGGER = 0, bool FULL32 = false>
-__global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
+__global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
     if constexpr (NODES) {
         // The wavefronts resident from the start of a launch all begin at once: one burst of loads (HBM-bound: the first
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     // solve, both with column stride 34 (conflict-free tile reads); the two spare slots per column hold
     // q in item order (g and b of the header).  1536 + 8704 = 10240 B: 16 waves per CU.
     constexpr int SQS = 34, SAS = 34;
-    __shared__ double sA[NODES ? 32 * SQS : 1];
+    __shared__ double sA[32 * SQS];
 #define SQ(i) sA[((i) >> 1) * SQS + 32 + ((i) & 1)]
 
     const double *Mg = NODES ? nullptr : a.M + (size_t)b * (size_t)a.strideM;
@@ -225,23 +231,26 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     };
 
     // ---- structure test: leading free STD rows, then GAVI rows -------------------------------------
-    int n, m;
+    int n_s, m_s;
     if constexpr (NODES) {
         // a node record IS of that shape (n free rows, then m GAVI rows): nothing to read, so the block loads
         // below are the first memory round trip of the wave
-        n = nn; m = nm;
-        if (!(n + m == N && n <= 32 && m <= 32 && n >= 1)) { decline(); return; }
+        n_s = nn; m_s = nm;
+        if (!(n_s + m_s == N && n_s <= 32 && m_s <= 32 && n_s >= 1)) { decline(); return; }
     } else {
         double lk, uk; int gk;
         row_bounds(lk, uk, gk);
         const bool isfree = act && !gk && lk == -QINF && uk == QINF;
         const unsigned long long mfree = qpn_ballot(isfree), mg = qpn_ballot(act && gk);
-        n = __popcll(mfree); m = __popcll(mg);
-        const bool shape_ok = n + m == N && n <= 32 && m <= 32 && n >= 1 &&
-                              mfree == ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) &&
-                              mg == ((((m + n) >= 64) ? ~0ull : ((1ull << (m + n)) - 1ull)) & ~((1ull << n) - 1ull));
+        n_s = __popcll(mfree); m_s = __popcll(mg);
+        // (FULL32: the launch's items are N = 64, and n + m = 64 with n, m <= 32 leaves n = m = 32: constants from here on)
+        const bool shape_ok = n_s + m_s == N && n_s <= 32 && m_s <= 32 && n_s >= 1 && (!FULL32 || a.N == 64) &&
+                              mfree == ((n_s >= 64) ? ~0ull : ((1ull << n_s) - 1ull)) &&
+                              mg == ((((m_s + n_s) >= 64) ? ~0ull : ((1ull << (m_s + n_s)) - 1ull)) & ~((1ull << n_s) - 1ull));
         if (!shape_ok) { decline(); return; }
     }
+
+    const int n = FULL32 ? 32 : n_s, m = FULL32 ? 32 : m_s;     // (compile-time constants in the FULL32 instantiations)
 
     // ---- load: the top half [H | C] straight into the MFMA tile layout ----------------------------------
 #define M_DECL(I, J) d4 TL(I, J);
@@ -299,36 +308,66 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
 #undef M_LOADH
 #undef M_LOADC
     } else {
-        // internal index (0..63) -> item index or -1 (padding): x block 0..31, lambda block 32..63
-        auto item_of = [&](int r) -> int { return r < 32 ? (r < n ? r : -1) : (r - 32 < m ? n + (r - 32) : -1); };
-#define M_LOAD(I, J)                                                                                \
-    {                                                                                               \
-        const int cc = 16 * (J) + lc;                                                               \
-        const int ci = item_of(cc);                                                                 \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-            const int rr = 16 * (I) + 4 * g + lq;                                                   \
-            const bool valid = rr < n && ci >= 0;                                                   \
-            double v = Mg[valid ? (size_t)ci * N + rr : 0];                                         \
-            if (!valid) v = (rr == cc) ? 1.0 : 0.0;                 /* padded x rows: identity */     \
-            TL(I, J)[g] = v;                                                                        \
-            mabs = fmax(mabs, fabs(v));                                                             \
-        }                                                                                           \
-    }
-        FOR_IJ(M_LOAD)
-#undef M_LOAD
-        // the pivot threshold is relative to max |M| over the WHOLE item: sweep the bottom half too
-        // (rows n.., lane <-> row: coalesced; also warms L2 for the operand loads after the crash)
-        {
-            const bool lowr = l < m;
-            const double *base = Mg + n + (lowr ? l : 0);
-            for (int j = 0; j < N; j += 8) {
-                double mv[8];
+        // Explicit M (N x N column-major, item order = [x | lambda]): the four blocks H = M[0:n, 0:n], C = M[0:n, n:N],
+        // A = M[n:N, 0:n] go through the same LDS block buffer as the node path's Qd and Ad -- whole columns of 32 rows with
+        // coalesced loads (256 contiguous bytes per column, two columns per instruction), every byte read once; A stays in the
+        // buffer (the A operands of the S product and c = b - A h).  D = M[n:N, n:N] is read where it is used (straight into
+        // the S accumulators): its share of max |M| is settled there, see `minpiv`.
+        const int r5 = l & 31, ch = l >> 5;
+        double vh[16], vc[16];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = (lowr && j + q8 < N) ? base[(size_t)(j + q8 < N ? j + q8 : 0) * N] : 0.0;
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mabs = fmax(mabs, fabs(mv[q8]));
-            }
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            vh[t] = Mg[(cj < n && r5 < n) ? (size_t)cj * N + r5 : 0];
+            vc[t] = Mg[(cj < m && r5 < n) ? (size_t)(n + cj) * N + r5 : 0];
         }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            const double h_ = (cj < n && r5 < n) ? vh[t] : 0.0;
+            sA[cj * SQS + r5] = h_;
+            mabs = max_abs_nc(mabs, h_);
+        }
+        wave_sync();
+#define M_LOADH(I, J)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * (I) + 4 * g + lq, cc = 16 * (J) + lc;                                   \
+        double v = sA[cc * SQS + rr];                                                               \
+        if (rr == cc && rr >= n) v = 1.0;                           /* padded x rows: identity */     \
+        TL(I, J)[g] = v;                                                                            \
+    }
+        M_LOADH(0, 0) M_LOADH(0, 1) M_LOADH(1, 0) M_LOADH(1, 1)
+#undef M_LOADH
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {          // A: requested now (into H's registers), staged after C
+            const int cj = 2 * t + ch;
+            vh[t] = Mg[(cj < n && r5 < m) ? (size_t)cj * N + n + r5 : 0];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            const double c_ = (cj < m && r5 < n) ? vc[t] : 0.0;
+            sA[cj * SQS + r5] = c_;
+            mabs = max_abs_nc(mabs, c_);
+        }
+        wave_sync();
+#define M_LOADC(I, J)                                                                               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const int rr = 16 * (I) + 4 * g + lq, ck = 16 * ((J) - 2) + lc;                             \
+        TL(I, J)[g] = sA[ck * SQS + rr];                            /* zeros outside n x m already */ \
+    }
+        M_LOADC(0, 2) M_LOADC(0, 3) M_LOADC(1, 2) M_LOADC(1, 3)
+#undef M_LOADC
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            const double a_ = (cj < n && r5 < m) ? vh[t] : 0.0;
+            sA[cj * SAS + r5] = a_;                                  // [column of x][constraint row]: the node path's Ad layout
+            mabs = max_abs_nc(mabs, a_);
+        }
+        // (the first reader of A is behind the wave_syncs of Stage A)
     }
     // extra column: g = q of the x rows, lane l <-> row l of the top half (lanes >= 32 idle)
     double kx;
@@ -342,6 +381,10 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     // Pivot rows carry P - I in sU so that the update T -= (U P^-1) V turns them into P^-1 V themselves:
     // no separate V' = P^-1 V product (an MFMA that would use 4 of its 16 output rows) is needed.
     bool fail = false;
+    // explicit M: the pivot threshold is relative to max |M| over the WHOLE item, and the D block is read only after the
+    // crash.  The smallest accepted pivot is kept; once max |D| is known, an item with a pivot below 1e-4 max |D| is declined
+    // after all -- the same items as a threshold known in advance would have declined (the pivots do not depend on it).
+    double minpiv = QINF;
 #define M_GATHER(I, JP, GP)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq;                                                       \
@@ -379,6 +422,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         double rd[4];                                   /* reciprocals of the pivots u_ss */        \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
             okp = okp && fabs(pm[s][s]) >= diag_thr;                                                \
+            if constexpr (!NODES) minpiv = min_abs_nc(minpiv, pm[s][s]);                            \
             rd[s] = rcp64(pm[s][s]);                                                                \
             _Pragma("unroll") for (int i = s + 1; i < 4; ++i) {                                     \
                 const double f = pm[i][s] * rd[s];      /* l_is, kept in place */                   \
@@ -438,17 +482,19 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     }
         M_LOADD(0, 0) M_LOADD(0, 1) M_LOADD(1, 0) M_LOADD(1, 1)
 #undef M_LOADD
+        double md = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            md = max_abs_nc(md, SB(0, 0)[g]); md = max_abs_nc(md, SB(0, 1)[g]);
+            md = max_abs_nc(md, SB(1, 0)[g]); md = max_abs_nc(md, SB(1, 1)[g]);
+        }
+        if (ubool(minpiv < 1e-4 * wave_max_f64(md))) { decline(); return; }
     }
     // A operand (16 x 4) of row tile Ib, k-block kk: element (i = lc, k = lq) = A[16 Ib + lc][4 kk + lq].
     // Node path: the tiles hold W~ = -W, so S = D - A W = D + A W~ (plain MFMA); M path: S = D - A W (NEG on A).
     auto aop = [&](int Ib, int kk) -> double {
         const int rk_ = 16 * Ib + lc, cj = 4 * kk + lq;
-        if constexpr (NODES) return sA[cj * SAS + rk_];            // zeros outside m x n already
-        else {
-            const bool valid = rk_ < m && cj < n;
-            const double v = Mg[valid ? (size_t)cj * N + n + rk_ : 0];
-            return valid ? v : 0.0;
-        }
+        return sA[cj * SAS + rk_];                                  // zeros outside m x n already
     };
 #define M_SACC(a_, b_, c_) (NODES ? MFMA(a_, b_, c_) : MFMA_NEGA(a_, b_, c_))
 #define M_SK(I, g, kk)                                                                              \
@@ -473,18 +519,8 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
         const int ls = lowr ? l : 0;
         double acc;
         if constexpr (NODES) acc = lowr ? SQ(n + ls) : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
-        if constexpr (NODES) {
 #pragma unroll 8
-            for (int j = 0; j < 32; ++j) acc = fma(-sA[j * SAS + ls], sz[j], acc);      // zero columns beyond n
-        } else {
-            for (int j = 0; j < n; j += 8) {
-                double mv[8];
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = (j + q8 < n) ? Mg[(size_t)(j + q8) * N + n + ls] : 0.0;
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) acc = fma(-mv[q8], sz[(j + q8) & 31], acc);
-            }
-        }
+        for (int j = 0; j < 32; ++j) acc = fma(-sA[j * SAS + ls], sz[j], acc);          // zero columns beyond n
         xb = lowr ? acc : 0.0;
     }
     STAMP(6);   // crash on the matrix cores
@@ -970,6 +1006,7 @@ __global__ __launch_bounds__(WAVE, NODES ? 4 : 3) void avi_solve_schur(AviBatchA
     } else {
         rk = act ? ae.q[vo + l] : 0.0;
         int j = 0;
+#pragma unroll 1
         for (; j + 8 <= N; j += 8) {
             double mv[8];
 #pragma unroll
@@ -1045,7 +1082,10 @@ hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, doubl
 {
     if (a.batch <= 0) return hipSuccess;
     SchurDebug d{dbgS, dbgc, dbgW, dbgh};
-    hipLaunchKernelGGL(avi_solve_schur<false>, dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+    if (a.N == 64 && !dbgS)
+        hipLaunchKernelGGL((avi_solve_schur<false, 0, true>), dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+    else
+        hipLaunchKernelGGL((avi_solve_schur<false, 0, false>), dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
     return hipGetLastError();
 }
 

@@ -1059,6 +1059,12 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(nres, off, 64); nres = o > nres ? o : nres; }
     if (l == 0) sRed[v] = nres;
     __syncthreads();
+#ifdef QPN_STAMPS
+    if (tid == 0 && kp->stamps) {                       // H wave 0's phases: the second half of a [2][batch][8] buffer
+        STAMP(0);
+        for (int k = 0; k < 8; ++k) kp->stamps[((size_t)kp->batch + b) * 8 + k] = stamp_acc[k];
+    }
+#endif
     if (tid == 64 * NR) {                               // the leader's lane 0: it holds the status and the pivot count
         if (badt > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
 #ifdef QPN_STAMPS

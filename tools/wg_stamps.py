@@ -30,18 +30,31 @@ for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
     for cnt in [min(int(x), 4000 if n <= 64 else 1024) for x in os.environ.get("CNT", "4000").split(",")]:
         Q, R, qd, A, B, l, u = P.synth_nodes(5000 + n, cnt, n, m)
         args = [t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(P.shared_params())]
-        st = torch.zeros((cnt, 8), dtype=torch.int64, device="cuda:0")
+        st = torch.zeros((2 * cnt if n > 64 else cnt, 8), dtype=torch.int64, device="cuda:0")
         eng.lib.qpn_debug_set_stamps(C.c_void_p(st.data_ptr()))
         for _ in range(2):
             res = eng.solve_nodes(*args)
         torch.cuda.synchronize()
-        s = st.cpu().numpy().astype(np.float64)
-        tot = s.sum(axis=1).mean()
+        sall = st.cpu().numpy().astype(np.float64)
         lp = float(res["pivots"].double().mean()) - n
-        print(f"n = m = {n}, {cnt} nodes: mean {tot:.0f} clocks (s_memtime) per workgroup; {n // 4 + (n % 4 > 0)} block pivots, {lp:.1f} Lemke pivots")
-        if n > 64:      # csrc/qpn_avi_schur_wg2.hip: the stamps are the LEADER's (C wave 0)
-            names = ["load + stage A + read-back + post-check (leader = a C wave)", "-", "-", "-", "W~ hand-over, waits for S, Ad staging",
-                     "Lemke: barriers + next column derived", "Lemke: the leader's turn", "-"]
+        steps = n // 4 + (n % 4 > 0)
+        if n > 64:      # csrc/qpn_avi_schur_wg2.hip: the LEADER's stamps (C wave 0), then H wave 0's
+            for who, s, nm_ in (("leader (C wave 0)", sall[:cnt],
+                                 ["load + stage A + read-back + post-check", "-", "-", "-", "W~ hand-over, waits for S, Ad staging",
+                                  "Lemke: bookkeeping + barriers + next column derived", "Lemke: decision half of the turn", "-"]),
+                                ("H wave 0", sall[cnt:],
+                                 ["load + read-back + post-check", "stage A", "-", "-", "W~ hand-over, S, tile hand-over",
+                                  "Lemke: decision read + publish + barrier A'", "Lemke: wait for the decision (barrier B)", "Lemke: exchange"])):
+                tot = s.sum(axis=1).mean()
+                print(f"n = m = {n}, {cnt} nodes, {who}: mean {tot:.0f} clocks (s_memtime) per workgroup; {steps} block pivots, {lp:.1f} Lemke pivots")
+                for i, nm in enumerate(nm_):
+                    if nm != "-":
+                        print(f"  {nm:52s} {s[:, i].mean():10.1f}  {100*s[:, i].mean()/tot:5.1f} %")
+                print(f"  per block pivot {s[:, 1].mean() / steps:8.0f}   per Lemke pivot {(s[:, 5:8].sum(axis=1).mean()) / max(lp, 1):8.0f}", flush=True)
+            continue
+        s = sall
+        tot = s.sum(axis=1).mean()
+        print(f"n = m = {n}, {cnt} nodes: mean {tot:.0f} clocks (s_memtime) per workgroup; {steps} block pivots, {lp:.1f} Lemke pivots")
         for i, nm in enumerate(names):
             print(f"  {nm:42s} {s[:, i].mean():10.1f}  {100*s[:, i].mean()/tot:5.1f} %")
-        print(f"  per block pivot {(s[:, 1:4].sum(axis=1).mean()) / (n // 4 + (n % 4 > 0)):8.0f}   per Lemke pivot {(s[:, 5:8].sum(axis=1).mean()) / max(lp, 1):8.0f}", flush=True)
+        print(f"  per block pivot {(s[:, 1:4].sum(axis=1).mean()) / steps:8.0f}   per Lemke pivot {(s[:, 5:8].sum(axis=1).mean()) / max(lp, 1):8.0f}", flush=True)
