@@ -110,11 +110,17 @@ __device__ __forceinline__ double rcp64(double x)
 #endif
 constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resident at once: 16 per CU, 256 CUs
 
-// FULL32 (node path only): the launch's nodes are n = m = 32 -- the hot shape gets its own instantiation, without the
+// SHAPE: 0 = sizes read at run time (any n, m <= 32); 32 / 16 = every item of the launch is n = m = SHAPE, a compile-time
+// constant: no ragged-shape code, bounds predicates or padding selects, and (16) no MFMAs on the padding tiles.
+// FULL32 = (SHAPE == 32): the launch's nodes are n = m = 32 -- the hot shape gets its own instantiation, without the
 // ragged-shape code, predicates and padding selects (sizes are compile-time constants there)
-template <bool NODES, int STAGGER = 0, bool FULL32 = false>
+template <bool NODES, int STAGGER = 0, int SHAPE = 0>
 __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
+    static_assert(SHAPE == 0 || SHAPE == 16 || SHAPE == 32, "compile-time shapes: 16 and 32");
+    static_assert(NODES || SHAPE != 16, "explicit M: N alone settles the split only at N = 64");
+    constexpr bool FULL32 = SHAPE == 32;
+    constexpr bool HALF16 = SHAPE == 16;
     if constexpr (NODES) {
         // The wavefronts resident from the start of a launch all begin at once: one burst of loads (HBM-bound: the first
         // round's load phase is 3x a later one's), then four waves per SIMD in lock-step through the same phases.
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
                          : "scc", "vcc");
         }
     }
-    const int N = FULL32 ? 64 : (NODES ? a.nd.n + a.nd.m : a.N);
+    const int N = SHAPE ? 2 * SHAPE : (NODES ? a.nd.n + a.nd.m : a.N);
     const int l = threadIdx.x;
     int b = blockIdx.x;
     if constexpr (NODES) {
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime() & 0xffffffffull;
 #endif
     // node records (fused path): M = [[Qd, -Ad'],[Ad, 0]], q = [qd + R w; B w], src/avi.jl:205-251 + :305-377
-    const int nn = FULL32 ? 32 : a.nd.n, nm = FULL32 ? 32 : a.nd.m, np_ = a.nd.p;
+    const int nn = SHAPE ? SHAPE : a.nd.n, nm = SHAPE ? SHAPE : a.nd.m, np_ = a.nd.p;
     const double *Q_ = NODES ? a.nd.Qd + (size_t)b * nn * nn : nullptr;
     const double *A_ = NODES ? a.nd.Ad + (size_t)b * nm * nn : nullptr;
     const double *R_ = NODES ? a.nd.R + (size_t)b * nn * np_ : nullptr;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         if (!shape_ok) { decline(); return; }
     }
 
-    const int n = FULL32 ? 32 : n_s, m = FULL32 ? 32 : m_s;     // (compile-time constants in the FULL32 instantiations)
+    const int n = SHAPE ? SHAPE : n_s, m = SHAPE ? SHAPE : m_s;     // (compile-time constants in the fixed-shape instantiations)
 
     // ---- load: the top half [H | C] straight into the MFMA tile layout ----------------------------------
 #define M_DECL(I, J) d4 TL(I, J);
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         // Qd and Ad with fully coalesced loads (two columns of 32 rows per instruction = 512 contiguous
         // bytes when n = m = 32), all 32 + the q loads in flight at once.  FULL (n = m = 32, the hot shape)
         // drops every bounds predicate, clamp and padding select.
-        const int r5 = l & 31, ch = l >> 5;
+        const int r50 = l & 31, ch0 = l >> 5;
 #define M_LOADH(I, J, FULL)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq, cc = 16 * (J) + lc;                                   \
@@ -279,12 +285,16 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     {                                                                                               \
         double vq[16], va[16];                                                                      \
         _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
-            const int cj = 2 * t + ch;                                                              \
-            const bool okq = (FULL) || (cj < nn && r5 < nn), oka = (FULL) || (cj < nn && r5 < nm);  \
-            vq[t] = Q_[okq ? (size_t)cj * ((FULL) ? 32 : nn) + r5 : 0];                             \
-            va[t] = A_[oka ? (size_t)cj * ((FULL) ? 32 : nm) + r5 : 0];                             \
+            const int cj = 2 * t + ch0;                                                             \
+            const bool okq = (FULL) || (cj < nn && r50 < nn), oka = (FULL) || (cj < nn && r50 < nm); \
+            vq[t] = Q_[okq ? (size_t)cj * ((FULL) ? 32 : nn) + r50 : 0];                            \
+            va[t] = A_[oka ? (size_t)cj * ((FULL) ? 32 : nm) + r50 : 0];                            \
         }                                                                                           \
         SQ(l) = act ? qelem(l) : 0.0;                                                               \
+        /* (ragged shapes: the bounds predicates are formed again from a fresh copy of the lane id where the values are    \
+           staged -- carried over from the loads they are 32 lane masks held across the round trip) */ \
+        int l2_ = l; asm volatile("" : "+v"(l2_));                                                  \
+        const int r5 = l2_ & 31, ch = l2_ >> 5;                                                     \
         _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
             const int cj = 2 * t + ch;                                                              \
             const double q_ = ((FULL) || (cj < nn && r5 < nn)) ? vq[t] : 0.0;                       \
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         wave_sync();                                                                                \
         M_LOADC(0, 2, FULL) M_LOADC(0, 3, FULL) M_LOADC(1, 2, FULL) M_LOADC(1, 3, FULL)             \
     }
-        if constexpr (FULL32) M_NODE_LOAD(true) else { if (nn == 32 && nm == 32) M_NODE_LOAD(true) else M_NODE_LOAD(false) }
+        if constexpr (FULL32) M_NODE_LOAD(true) else M_NODE_LOAD(false)      // (n = m = 32 launches take the FULL32 instantiation)
 #undef M_NODE_LOAD
 #undef M_LOADH
 #undef M_LOADC
@@ -313,20 +323,28 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         // coalesced loads (256 contiguous bytes per column, two columns per instruction), every byte read once; A stays in the
         // buffer (the A operands of the S product and c = b - A h).  D = M[n:N, n:N] is read where it is used (straight into
         // the S accumulators): its share of max |M| is settled there, see `minpiv`.
-        const int r5 = l & 31, ch = l >> 5;
+        // (ragged shapes: every batch of bounds predicates is formed from a fresh copy of the lane id -- carried over from the
+        // loads to the staging they are 48 lane masks held across the round trips)
+        auto lane_now = [&]() -> int { int t_ = l; asm volatile("" : "+v"(t_)); return t_; };
         double vh[16], vc[16];
+        {
+        const int l0_ = lane_now(), r5 = l0_ & 31, ch = l0_ >> 5;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int cj = 2 * t + ch;
             vh[t] = Mg[(cj < n && r5 < n) ? (size_t)cj * N + r5 : 0];
             vc[t] = Mg[(cj < m && r5 < n) ? (size_t)(n + cj) * N + r5 : 0];
         }
+        }
+        {
+        const int l0_ = lane_now(), r5 = l0_ & 31, ch = l0_ >> 5;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int cj = 2 * t + ch;
             const double h_ = (cj < n && r5 < n) ? vh[t] : 0.0;
             sA[cj * SQS + r5] = h_;
             mabs = max_abs_nc(mabs, h_);
+        }
         }
         wave_sync();
 #define M_LOADH(I, J)                                                                               \
@@ -339,17 +357,23 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         M_LOADH(0, 0) M_LOADH(0, 1) M_LOADH(1, 0) M_LOADH(1, 1)
 #undef M_LOADH
         wave_sync();
+        {
+        const int l0_ = lane_now(), r5 = l0_ & 31, ch = l0_ >> 5;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {          // A: requested now (into H's registers), staged after C
             const int cj = 2 * t + ch;
             vh[t] = Mg[(cj < n && r5 < m) ? (size_t)cj * N + n + r5 : 0];
         }
+        }
+        {
+        const int l0_ = lane_now(), r5 = l0_ & 31, ch = l0_ >> 5;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int cj = 2 * t + ch;
             const double c_ = (cj < m && r5 < n) ? vc[t] : 0.0;
             sA[cj * SQS + r5] = c_;
             mabs = max_abs_nc(mabs, c_);
+        }
         }
         wave_sync();
 #define M_LOADC(I, J)                                                                               \
@@ -360,12 +384,15 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         M_LOADC(0, 2) M_LOADC(0, 3) M_LOADC(1, 2) M_LOADC(1, 3)
 #undef M_LOADC
         wave_sync();
+        {
+        const int l0_ = lane_now(), r5 = l0_ & 31, ch = l0_ >> 5;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int cj = 2 * t + ch;
             const double a_ = (cj < n && r5 < m) ? vh[t] : 0.0;
             sA[cj * SAS + r5] = a_;                                  // [column of x][constraint row]: the node path's Ad layout
             mabs = max_abs_nc(mabs, a_);
+        }
         }
         // (the first reader of A is behind the wave_syncs of Stage A)
     }
@@ -384,7 +411,9 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     // explicit M: the pivot threshold is relative to max |M| over the WHOLE item, and the D block is read only after the
     // crash.  The smallest accepted pivot is kept; once max |D| is known, an item with a pivot below 1e-4 max |D| is declined
     // after all -- the same items as a threshold known in advance would have declined (the pivots do not depend on it).
-    double minpiv = QINF;
+    // (kept in an idle LDS slot, not in a register pair across the eight steps)
+    double *const sMinPiv = sbuf + 191;
+    if constexpr (!NODES) { if (l == 0) sMinPiv[0] = QINF; }
 #define M_GATHER(I, JP, GP)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq;                                                       \
@@ -401,7 +430,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         double vraw = TL(IP, J)[GP];                                                                \
         asm volatile("" : "+v"(vraw));      /* opaque: the copy itself is the compiler's (hazard-aware) */ \
         TL(0, J) = MFMA_NEGA(au0, vraw, TL(0, J));                                                  \
-        TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));                                                  \
+        if constexpr (!HALF16) TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));     /* (16: rows 16.. are padding, U' = 0 there) */ \
     }
 #define M_STEP(KB, JP, GP)                                                                          \
     if (!fail && 4 * (KB) < n) {       /* a block of padded rows is an identity pivot: nothing moves */ \
@@ -419,6 +448,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         const double x0 = readlane_f64(kx, p0), x1 = readlane_f64(kx, p0 + 1);                      \
         const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);                  \
         bool okp = true;                                                                            \
+        double minpiv = QINF;                                                                       \
         double rd[4];                                   /* reciprocals of the pivots u_ss */        \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
             okp = okp && fabs(pm[s][s]) >= diag_thr;                                                \
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         }                                                                                           \
         if (!ubool(okp)) { fail = true; }                                                           \
         else {                                                                                      \
+            if constexpr (!NODES) { if (l == 0) sMinPiv[0] = fmin(sMinPiv[0], minpiv); }            \
             /* U' = U P^-1, row l of the panel: solve x L U = u (pivot rows hold P - I, so theirs   \
                is I - P^-1), and the extra column kx_l -= U'[l] . x_piv */                          \
             if (l < 32) {                                                                           \
@@ -451,9 +482,9 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             wave_sync();                                                                            \
             const double au0 = sU[(0 + lc) * 4 + lq], au1 = sU[(16 + lc) * 4 + lq];    /* T -= U' V: NEG on A */ \
             if ((JP) <= 0) M_COLTILE(0, JP, GP)                                                     \
-            if ((JP) <= 1) M_COLTILE(1, JP, GP)                                                     \
+            if constexpr (!HALF16) { if ((JP) <= 1) M_COLTILE(1, JP, GP) }     /* (16: columns 16.. of H and of C are zero) */ \
             M_COLTILE(2, JP, GP)                                                                    \
-            M_COLTILE(3, JP, GP)                                                                    \
+            if constexpr (!HALF16) M_COLTILE(3, JP, GP)                                             \
             wave_sync();                                                                            \
         }                                                                                           \
     }
@@ -488,7 +519,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             md = max_abs_nc(md, SB(0, 0)[g]); md = max_abs_nc(md, SB(0, 1)[g]);
             md = max_abs_nc(md, SB(1, 0)[g]); md = max_abs_nc(md, SB(1, 1)[g]);
         }
-        if (ubool(minpiv < 1e-4 * wave_max_f64(md))) { decline(); return; }
+        if (ubool(sMinPiv[0] < 1e-4 * wave_max_f64(md))) { decline(); return; }
     }
     // A operand (16 x 4) of row tile Ib, k-block kk: element (i = lc, k = lq) = A[16 Ib + lc][4 kk + lq].
     // Node path: the tiles hold W~ = -W, so S = D - A W = D + A W~ (plain MFMA); M path: S = D - A W (NEG on A).
@@ -500,8 +531,11 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
 #define M_SK(I, g, kk)                                                                              \
     if (4 * (kk) < n) {                /* rows of W beyond n are zero */                             \
         const double a0_ = aop(0, kk), a1_ = aop(1, kk);                                            \
-        SB(0, 0) = M_SACC(a0_, TL(I, 2)[g], SB(0, 0)); SB(0, 1) = M_SACC(a0_, TL(I, 3)[g], SB(0, 1)); \
-        SB(1, 0) = M_SACC(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = M_SACC(a1_, TL(I, 3)[g], SB(1, 1)); \
+        SB(0, 0) = M_SACC(a0_, TL(I, 2)[g], SB(0, 0));                                              \
+        if constexpr (!HALF16) {           /* (16: the other three tiles of S are padding, zero) */    \
+            SB(0, 1) = M_SACC(a0_, TL(I, 3)[g], SB(0, 1));                                          \
+            SB(1, 0) = M_SACC(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = M_SACC(a1_, TL(I, 3)[g], SB(1, 1)); \
+        }                                                                                           \
     }
     // bounds of pair l for Stage B: requested here so that the round trip hides behind the 32 MFMAs
     double lo_pre = -QINF, hi_pre = QINF;
@@ -921,8 +955,8 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         // (the W tiles are dead from here on: their 32 registers take the 32 entries of Qd this lane needs for the
         // post-check, requested now so that the round trip hides behind the reduction and its LDS hops)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NODES) {
-            if (nn == 32) {
+        if constexpr (NODES && FULL32) {
+            {
                 const double *qc = Qe_ + (l < 32 ? l : 0);
 #pragma unroll
                 for (int j = 0; j < 32; ++j) mq32[j] = qc[(size_t)j * 32];
@@ -969,7 +1003,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         const int aoff = isx ? 0 : ls, roff = (isx ? ls : 0) * SAS;   // column of Ad (constraint rows) / row of Ad' (x rows)
         double rq = SQ(l), ra = rq;
         int j = 0;
-        if (nn == 32) {
+        if constexpr (FULL32) {
             // eight columns at a time, with both accumulators pinned in between: left alone the compiler sinks the `ra` chain
             // below the lambda loop (only the constraint lanes keep it) and carries its 32 LDS operands there through scratch
 #pragma unroll
@@ -1083,9 +1117,9 @@ hipError_t qpn_launch_avi_solve_schur(const AviBatchArgs &a, double *dbgS, doubl
     if (a.batch <= 0) return hipSuccess;
     SchurDebug d{dbgS, dbgc, dbgW, dbgh};
     if (a.N == 64 && !dbgS)
-        hipLaunchKernelGGL((avi_solve_schur<false, 0, true>), dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+        hipLaunchKernelGGL((avi_solve_schur<false, 0, 32>), dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
     else
-        hipLaunchKernelGGL((avi_solve_schur<false, 0, false>), dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
+        hipLaunchKernelGGL((avi_solve_schur<false, 0, 0>), dim3((unsigned)a.batch), dim3(WAVE), 0, stream, a, d);
     return hipGetLastError();
 }
 
@@ -1112,14 +1146,13 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
     static const bool no_stagger = [] { const char *e = getenv("QPN_NO_STAGGER"); return e && e[0] == '1'; }();   // A/B switch
     // a partial round has no burst to spread; other CU counts (partitioned modes) run without the stagger
     const bool stag = !no_stagger && resident[dev] == kResidentMI355X && a.batch > kResidentMI355X;
-    const bool full = a.nd.n == 32 && a.nd.m == 32;
-    if (stag && full)
-        hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, true>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
-    else if (stag)
-        hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, false>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
-    else if (full)
-        hipLaunchKernelGGL((avi_solve_schur<true, 0, true>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
-    else
-        hipLaunchKernelGGL((avi_solve_schur<true, 0, false>), dim3((unsigned)a.batch), dim3(WAVE), pad, stream, a, d);
+    const bool full = a.nd.n == 32 && a.nd.m == 32, half = a.nd.n == 16 && a.nd.m == 16;
+    const dim3 grid((unsigned)a.batch), block(WAVE);
+    if (stag && full) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 32>), grid, block, pad, stream, a, d);
+    else if (stag && half) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 16>), grid, block, pad, stream, a, d);
+    else if (stag) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 0>), grid, block, pad, stream, a, d);
+    else if (full) hipLaunchKernelGGL((avi_solve_schur<true, 0, 32>), grid, block, pad, stream, a, d);
+    else if (half) hipLaunchKernelGGL((avi_solve_schur<true, 0, 16>), grid, block, pad, stream, a, d);
+    else hipLaunchKernelGGL((avi_solve_schur<true, 0, 0>), grid, block, pad, stream, a, d);
     return hipGetLastError();
 }

@@ -148,7 +148,9 @@ def test_solve_nodes_fused_equals_assemble_then_solve(engine, oracle):
     against the two-call path, host and device buffers, matrix-core sizes and general sizes."""
     import torch
     from qpn_amd.engine import colmajor
-    for n, m, p, cnt in [(32, 32, 8, 300), (7, 19, 3, 40), (32, 5, 8, 20), (3, 32, 1, 20), (40, 50, 4, 3), (6, 0, 2, 4)]:
+    # ((16, 16): the compile-time n = m = 16 instantiation; 4 400 nodes: more than the resident set, the staggered launch)
+    for n, m, p, cnt in [(32, 32, 8, 300), (16, 16, 8, 300), (16, 16, 4, 4400), (7, 19, 3, 40), (32, 5, 8, 20), (3, 32, 1, 20), (40, 50, 4, 3),
+                         (6, 0, 2, 4)]:
         Q, R, qd, A, B, l, u = P.synth_nodes(4000 + n, cnt, n, m, p)
         B = 0.3 * np.random.default_rng(n).standard_normal((cnt, m, p))
         w = P.shared_params(p)
