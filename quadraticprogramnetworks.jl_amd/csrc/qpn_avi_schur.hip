@@ -843,6 +843,31 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             //  1 / pivot goes in as the scalar it is)
             const double inv_s = udbl(inv);
             cx = uni(cx); rsel = uni(rsel);
+            if constexpr (HALF16) {
+                // n = m = 16: pairs 16.. are padding -- the other three tiles stay zero (u = 0 in rows 16.., v = 0 in columns 16..)
+                asm volatile(
+                    "v_fma_f64 %[s000], -%[u0], %[v0], %[s000]\n\tv_fma_f64 %[s001], -%[u1], %[v0], %[s001]\n\t"
+                    "v_fma_f64 %[s002], -%[u2], %[v0], %[s002]\n\tv_fma_f64 %[s003], -%[u3], %[v0], %[s003]\n\t"
+                    "s_cmp_gt_i32 %[c], 31\n\ts_cbranch_scc1 1f\n\t"
+                    "s_mov_b64 exec, %[mcol]\n\t"
+                    "v_mul_f64 %[s000], %[u0], %[iv]\n\tv_mul_f64 %[s001], %[u1], %[iv]\n\t"
+                    "v_mul_f64 %[s002], %[u2], %[iv]\n\tv_mul_f64 %[s003], %[u3], %[iv]\n"
+                    "1:\n\t"
+                    "s_mov_b64 exec, %[mrow]\n\t"
+                    "s_cmp_gt_i32 %[rs], 1\n\ts_cbranch_scc1 3f\n\t"
+                    "s_cmp_eq_u32 %[rs], 0\n\ts_cbranch_scc0 2f\n\t"
+                    "v_mul_f64 %[s000], %[v0], -1.0\n\ts_branch 5f\n"
+                    "2:\n\tv_mul_f64 %[s001], %[v0], -1.0\n\ts_branch 5f\n"
+                    "3:\n\ts_cmp_eq_u32 %[rs], 2\n\ts_cbranch_scc0 4f\n\t"
+                    "v_mul_f64 %[s002], %[v0], -1.0\n\ts_branch 5f\n"
+                    "4:\n\tv_mul_f64 %[s003], %[v0], -1.0\n"
+                    "5:\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [s000] "+v"(SD(0, 0, 0)), [s001] "+v"(SD(0, 0, 1)), [s002] "+v"(SD(0, 0, 2)), [s003] "+v"(SD(0, 0, 3))
+                    : [u0] "v"(ua[0]), [u1] "v"(ua[1]), [u2] "v"(ua[2]), [u3] "v"(ua[3]), [v0] "v"(v0), [iv] "s"(inv_s),
+                      [mcol] "s"(mcol), [mrow] "s"(mrow), [c] "s"(cx), [rs] "s"(rsel)
+                    : "scc");
+            } else
             asm volatile(
                 "v_fma_f64 %[s000], -%[u0], %[v0], %[s000]\n\tv_fma_f64 %[s001], -%[u1], %[v0], %[s001]\n\t"
                 "v_fma_f64 %[s002], -%[u2], %[v0], %[s002]\n\tv_fma_f64 %[s003], -%[u3], %[v0], %[s003]\n\t"
