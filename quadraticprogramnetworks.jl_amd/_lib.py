@@ -30,6 +30,7 @@ IPC_HANDLE_BYTES = 64
 SHARED_FINE_GRAINED = 1
 SWEEP_BOX_BYTES = 512
 OPT_MID_ROUTE = 1
+OPT_BIG_ROUTE = 2
 
 
 class LibraryMissing(RuntimeError):

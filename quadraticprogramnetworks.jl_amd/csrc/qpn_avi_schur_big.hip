@@ -730,7 +730,9 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
     }
     if (tid == 0) { colvar[m] = VTH; cnb[m] = 0.0; }
     // T_base = [S | 0]: S is column-major, read coalesced over rows
-    if (w.s_rowmajor) {
+    if (w.s_rowmajor == 2) {
+        // (stage A wrote S straight into T_base)
+    } else if (w.s_rowmajor) {
         for (int idx = tid; idx < m * m; idx += TPB) { const int i = idx / m, j = idx - i * m; Tb[(size_t)i * ld + j] = Sg[idx]; }
     } else {
         for (int j = 0; j < m; ++j)

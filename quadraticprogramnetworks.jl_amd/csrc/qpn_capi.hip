@@ -38,6 +38,9 @@ struct qpn_ctx {
     // when the context is created, sets the default): 1 the fused workgroup kernel, 2 round 2's three kernels, 0 the route of
     // the large nodes
     int32_t mid_route = 1;
+    // route of large node records (QPN_OPT_BIG_ROUTE): 1 the blocked crash straight from the records (qpn_avi_schur_big2.hip),
+    // 0 round 2's route (M assembled, qpn_avi_schur_big.hip)
+    int32_t big_route = 1;
 };
 
 namespace {
@@ -147,6 +150,10 @@ int qpn_ctx_set_option(qpn_ctx *ctx, int32_t option, int32_t value)
     case QPN_OPT_MID_ROUTE:
         if (value < 0 || value > 2) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_MID_ROUTE takes 0, 1 or 2");
         ctx->mid_route = value;
+        return QPN_OK;
+    case QPN_OPT_BIG_ROUTE:
+        if (value < 0 || value > 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_BIG_ROUTE takes 0 or 1");
+        ctx->big_route = value;
         return QPN_OK;
     default:
         return fail_arg(ctx, "qpn_ctx_set_option: unknown option");
@@ -829,6 +836,22 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
             HIPCHK(ctx, hipEventRecord(h->decl_ev, s));
             h->decl_state = 1;
         }
+    } else if (ctx->big_route == 1 && qpn_schur_big2_shape(n, m) && wbig && (o.max_pivots <= 0 || o.max_pivots - n >= 1)) {
+        // large nodes (BASELINE config 5): the blocked crash straight from the records (qpn_avi_schur_big2.hip), the
+        // delayed-update Lemke kernel on the Schur problems, read-back and post-check on the records; no M is assembled unless a
+        // node declines -- those (status = -1) are assembled and solved by the general kernel in gated launches
+        SchurBigWs sw{};
+        double *dict = wbig;
+        void *sb = wbig + (size_t)batch * (size_t)N * (size_t)(N + 1);
+        HIPCHK(ctx, qpn_launch_schur_big2_stage_a(a, sb, dict, &sw, s));
+        HIPCHK(ctx, qpn_launch_schur_big_lemke(a, sw, dict, s));
+        HIPCHK(ctx, qpn_launch_schur_big2_finish(a, sw, s));
+        HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
+                                              wu, wk, s, d.st, -1));
+        AviBatchArgs g = a;
+        g.M = wM; g.strideM = (int64_t)N * N; g.q = wq; g.l = wl; g.u = wu; g.kind = wk; g.stride_kind = N;
+        g.only_if = d.st; g.only_if_value = -1;
+        HIPCHK(ctx, qpn_launch_avi_solve_big(g, wbig, s));
     } else {
         HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
                                               wu, wk, s));

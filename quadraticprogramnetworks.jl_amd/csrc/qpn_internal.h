@@ -94,13 +94,20 @@ struct SchurBigWs {
     double *Tt, *S, *c, *l2, *u2, *lam;
     int32_t *st2, *piv2, *nsplit, *nred;
     int64_t tt_stride, s_stride;
-    int32_t s_rowmajor;      // layout of S: row-major for the workgroup Lemke kernel (its dictionary is row-major: no
+    int32_t s_rowmajor;      // layout of S (2: already in the Lemke kernel's dictionary, row stride m + 1): row-major for the workgroup Lemke kernel (its dictionary is row-major: no
                              // transposition anywhere), column-major for the kernels that take S as an ABI-layout M
 };
 size_t qpn_schur_big_workspace_bytes(int batch, int N);
 hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, int s_rowmajor, hipStream_t stream);
 hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
 hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream);
+
+// qpn_avi_schur_big2.hip: the same stage A straight from node records (64 < n <= 256, m <= 256), rank-64 block pivots, one
+// workgroup of 16 wavefronts per node; its finish reads the records too.  Same workspace views: the Lemke kernel above runs
+// between the two.
+bool qpn_schur_big2_shape(int n, int m);
+hipError_t qpn_launch_schur_big2_stage_a(const AviBatchArgs &a, void *ws, double *dict, SchurBigWs *out, hipStream_t stream);   // a.nd set
+hipError_t qpn_launch_schur_big2_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
 
 // qpn_avi_schur_mid.hip: node records with n, m <= 64 (one of them > 32): four wavefronts per node, no assembled M
 struct SchurMidWs {
