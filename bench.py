@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", type=int, choices=(4, 5), default=4,
                     help="4: 10 000 nodes x 32 variables (BASELINE configs[3], the metric's config); 5: 512 nodes x 256 variables")
+    ap.add_argument("--big-route", type=int, choices=(0, 1), default=1,
+                    help="--config 5, A/B: 1 = blocked crash straight from the records (default), 0 = round 2's route over an assembled M")
     ap.add_argument("--nodes", type=int, default=None, help="nodes in the whole net (strong) / per GPU (weak)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: shard ONE net (strong, BASELINE configs[3]) or give every GPU its own (weak)")
@@ -562,12 +564,14 @@ def run_config5(env, args):
     if not args.fixed_w:
         ring_host = ring_host + 0.25 * np.random.Generator(np.random.Philox(key=[synthetic.SEED, 2 ** 41])).standard_normal((RING, p))
     ring = t(ring_host)
+    from qpn_amd import _lib as qlib
+    eng.set_option(qlib.OPT_BIG_ROUTE, args.big_route)
     handle = eng.upload_nodes(*drec)
     steps = min(args.steps, 50)
     warmup = min(args.warmup, 5)
     out = None
     x = torch.zeros((cnt, n), dtype=torch.float64, device=dev)
-    prewarm_steps = 0 if args.no_prewarm else 40          # ~0.2 s: the GPU's idle power state (see the module docstring)
+    prewarm_steps = 0 if args.no_prewarm else 200         # ~0.7 s: the GPU's idle power state (see the module docstring)
     for i in range(prewarm_steps + warmup):
         out = handle.solve(ring[i % RING], out=out, x_out=x)
     torch.cuda.synchronize()
@@ -594,11 +598,12 @@ def run_config5(env, args):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {total}-node x {n}-var QPNet (n=m={n}, N_red={N}, p={p}; BASELINE.json configs[4]); step = "
                                "KKT assembly + cold-start AVI solve + check + active sets + primal write-back over resident node "
-                               f"records (qpn_solve_nodes_h -> blocked MFMA crash + delayed-update Lemke); ring of {RING} parameter vectors",
+                               f"records (qpn_solve_nodes_h -> blocked MFMA crash straight from the records + delayed-update Lemke); ring of {RING} "
+                               "parameter vectors",
                    "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p, "mean_pivots": mean_piv, "mean_lemke_pivots": mean_piv - n,
                    "max_resid": float(out["resid"].max().item()), "solved": solved},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "schur_big_stage_a + schur_big_lemke + schur_big_finish (per step)", "kernel_ms": ms,
+                     "traffic": None, "kernel": "schur_big2_convert + schur_big2_eliminate + schur_big2_sprod + schur_big_lemke + schur_big2_finish (per step)", "kernel_ms": ms,
                      "flops_per_solve": flops, "solves_per_launch": cnt},
     }
     if world == 1 and not args.no_cpu_baseline and rank == 0:

@@ -31,6 +31,7 @@ constexpr int TPB = 256;
 constexpr int PW = 16;                  // panel width (block pivot size)
 constexpr int NMAXA = 512;              // rows of the top half held in LDS as U' (512 x 17 doubles = 68 KB)
 constexpr int LDU = PW + 1;
+__host__ __device__ constexpr int sb_pend_stride(int m) { return ((m + 1 + 15) & ~31) + 16; }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
@@ -46,9 +47,14 @@ struct SbShared {
     int flag;
 };
 
+struct SbRed {              // the reduction slots alone (the Lemke kernel: its LDS budget is two workgroups per CU)
+    double red[TPB / 64];
+    int redi[TPB / 64];
+};
+
 // Block reductions (TPB = 256: 4 waves): a shuffle reduction inside each wave, the 4 wave results through LDS --
 // two barriers per call (publish / reuse) instead of the ten of a tree over LDS.  NaN never wins a max.
-__device__ __forceinline__ double sb_block_max(double v, SbShared &S, int tid)
+template <class SH> __device__ __forceinline__ double sb_block_max(double v, SH &S, int tid)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
@@ -60,7 +66,7 @@ __device__ __forceinline__ double sb_block_max(double v, SbShared &S, int tid)
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ int sb_block_min_i(int v, SbShared &S, int tid)
+template <class SH> __device__ __forceinline__ int sb_block_min_i(int v, SH &S, int tid)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
@@ -72,7 +78,7 @@ __device__ __forceinline__ int sb_block_min_i(int v, SbShared &S, int tid)
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ int sb_block_sum_i(int v, SbShared &S, int tid)
+template <class SH> __device__ __forceinline__ int sb_block_sum_i(int v, SH &S, int tid)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -87,7 +93,7 @@ __device__ __forceinline__ int sb_block_sum_i(int v, SbShared &S, int tid)
 
 // Row choice of the ratio test in ONE reduction: the candidate with the largest key, ties -> the lowest row;
 // key < 0 = no candidate (returns -1).  Shuffle tournament inside each wave, the 4 wave winners through LDS.
-__device__ __forceinline__ int sb_block_argbest(double key, int row, SbShared &S, int tid)
+template <class SH> __device__ __forceinline__ int sb_block_argbest(double key, int row, SH &S, int tid)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -693,28 +699,48 @@ __global__ __launch_bounds__(TPB) void schur_big_finish(AviBatchArgs a, SchurBig
 // it (1 MB read + written at m = 256); every KP pivots the pending pairs are folded into T_base with a rank-KP
 // MFMA pass.  Entries of the exchanged row / column carry a relative error ~ eps |p| (cancellation in the
 // rank-1 form); the result is certified by the post-check on the original blocks like every other path.
+#ifdef QPN_STAMPS
+#define LSTAMP(slot)                                                    \
+    do {                                                                \
+        unsigned long long now__ = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+        stamp_acc[slot] += now__ - stamp_last;                          \
+        stamp_last = now__;                                             \
+    } while (0)
+#else
+#define LSTAMP(slot) do { } while (0)
+#endif
 template <int KP>
 __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigWs w, double *dict, int m_lo, int m_hi)
 {
     const int tid = threadIdx.x, b = blockIdx.x;
     if (a.status[b] != -2) return;
+#ifdef QPN_STAMPS
+    // (diagnostic builds: thread 0's clocks per phase, second half of a [2][batch][8] buffer -- tools/big2_stamps.py)
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
-    const int m = w.nred[b], XC = m, VTH = 2 * m, ld = m + 1;
+    // (row stride of T_base: a multiple of 16 doubles -- with m + 1 every 16-column run of a row straddles two cache lines and
+    // the fold's tile stores are partial-sector writes)
+    const int m = w.nred[b], XC = m, VTH = 2 * m, ld = (m + 1 + 15) & ~15;
     if (m < m_lo || m > m_hi) return;                // this launch's LDS is sized for m_hi
     const size_t vo = (size_t)b * (size_t)a.N;
-    __shared__ SbShared S;
+    __shared__ SbRed S;
     __shared__ double bcd[8];
     __shared__ int bci[8];
     extern __shared__ __attribute__((aligned(16))) double dynl[];
-    const int mA = m, mB = m + 1;
-    double *PA = dynl;                               // [KP][m]
-    double *PB = PA + (size_t)KP * mA;               // [KP][m + 1]
+    // row stride of the pending pairs: >= m + 1 and == 16 mod 32 doubles, so that the four k-rows an MFMA operand of the fold
+    // reads (kk = 4 s + lq) sit on different LDS banks (stride m or m + 1: a 4-way / 2-way conflict on every operand read)
+    const int mA = sb_pend_stride(m), mB = mA;
+    double *PA = dynl;                               // [KP][mA]: m used
+    double *PB = PA + (size_t)KP * mA;               // [KP][mB]: m + 1 used
     double *cnb = PB + (size_t)KP * mB;              // nonbasic values by column, [m + 1]
-    double *lo0 = cnb + mB + (mB & 1);               // pair bounds
+    double *lo0 = cnb + (m + 1) + ((m + 1) & 1);     // pair bounds
     double *hi0 = lo0 + m;
     int *colvar = reinterpret_cast<int *>(hi0 + m);  // [m + 1]
-    int *sat = colvar + mB + (mB & 1);               // [m]
-    double *Tb = dict + (size_t)b * (size_t)a.N * (size_t)(a.N + 1);     // T_base, row-major, ld = m + 1
+    int *sat = colvar + (m + 1) + ((m + 1) & 1);     // [m]
+    double *Tb = dict + (size_t)b * (size_t)a.N * (size_t)(a.N + 1);     // T_base, row-major, m rows of ld
     const double *Sg = w.S + (size_t)b * (size_t)w.s_stride;
 
     // rows owned by this thread
@@ -784,6 +810,7 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
         return r == 0x7fffffff ? -1 : r;
     };
 
+    LSTAMP(0);   // setup
     while (status == QPN_MAX_ITERS) {
         if (pivots >= max_piv) break;
         // ---- entering column of the CURRENT dictionary: T_base column minus the pending rank-1 terms
@@ -796,6 +823,7 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
             for (int k = 0; k < npend; ++k) v = fma(-PA[k * mA + i], PB[k * mB + c], v);
             cm[h] = v;
         }
+        LSTAMP(1);   // entering column (T_base + pending terms)
         // ---- ratio test
         double gdir[2], rc[2], dd[2], d1min = QINF;
         bool cndlo[2], cnd[2];
@@ -826,6 +854,7 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
             }
         }
         const int r = sb_block_argbest(ag, myr, S, tid);
+        LSTAMP(2);   // ratio test + the two reductions
         const int ncand = r < 0 ? 0 : 1;
         if (ncand == 0) {
             // the entering variable reaches its own opposite bound first: no basis change
@@ -880,6 +909,7 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
             else xb[h] = fma(delta, cm[h], xb[h]);
         }
         __syncthreads();
+        LSTAMP(3);   // pivot row (T_base + pending terms) -> pending pair
         if (tid == 0) { colvar[c] = vl; cnb[c] = leave_val; }
         npend++;
         pivots++;
@@ -906,6 +936,7 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
         }
         __syncthreads();
         c = col_of(vn);
+        LSTAMP(4);   // bookkeeping + the next column's index
         if (c < 0) { status = QPN_FAILURE; break; }
         // ---- fold the pending pairs into T_base: rank-KP MFMA pass over its tiles
         if (npend == KP) {
@@ -947,8 +978,13 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
             npend = 0;
             __threadfence_block();
             __syncthreads();
+            LSTAMP(5);   // fold of KP pending pairs
         }
     }
+    LSTAMP(6);
+#ifdef QPN_STAMPS
+    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[((size_t)a.batch + b) * 8 + k] = stamp_acc[k];
+#endif
 
     // ---- read-back: lambda_k = value of d_k (id m + k)
     __syncthreads();
@@ -1053,7 +1089,7 @@ hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w
     const int m_mid = (N + 1) / 2 < m_top ? (N + 1) / 2 : m_top;
     auto bytes_for = [](int KP, int mh) -> size_t {
         const size_t mB = (size_t)mh + 1;
-        const size_t dbl = (size_t)KP * (2 * mB + 1) + (mB + 2) + 2 * mB;
+        const size_t dbl = (size_t)KP * 2 * (size_t)sb_pend_stride(mh) + (mB + 2) + 2 * mB;
         return ((dbl * sizeof(double) + sizeof(int) * (2 * mB + 4)) + 15) & ~(size_t)15;
     };
     for (int part = 0; part < 2; ++part) {

@@ -42,8 +42,9 @@ constexpr int MC = 13;                              // column tiles per mega-chu
 constexpr int OFF_P = 0;                            // pivot block, inverted in place                      [64][LDP]
 constexpr int OFF_D = OFF_P + 64 * LDP;             // inverse of the current diagonal tile                [16][LDD] (+ pad)
 constexpr int OFF_V = OFF_D + 288;                  // raw pivot rows of a mega-chunk, as tiles            [MC][4][256]
-constexpr int OFF_RED = OFF_V + MC * 4 * 256;       // block reductions, flags                             [32]
-constexpr int LDS_DOUBLES = OFF_RED + 32;           // 18 752 doubles = 146.5 KB: one workgroup per CU
+constexpr int OFF_G = OFF_V + MC * 4 * 256;         // g = qd + R w (pass 0 from the records)              [256]
+constexpr int OFF_RED = OFF_G + 256;                // block reductions, flags                             [32]
+constexpr int LDS_DOUBLES = OFF_RED + 32;           // 19 008 doubles = 148.5 KB: one workgroup per CU
 constexpr int LDS_SPROD = 2 * 16 * 256 + 256;       // the S product: two blocks of W (4 block rows x JC tiles) + b
 
 #ifdef QPN_STAMPS
@@ -175,9 +176,16 @@ __global__ __launch_bounds__(256) void schur_big2_convert(AviBatchArgs a, SchurB
     if (tid == 0) w.c[(size_t)b * N] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));       // (until the S product writes c)
 }
 
-// ---- K1: the elimination, rank-64 block pivots on the tiles K0 has laid out --------------------------------------------
+// ---- K1: the elimination, rank-64 block pivots --------------------------------------------------------------------------
+// MODE 0: every pass on the tiles K0 has laid out.  n, m multiples of 16 need no conversion pass -- MODE 1: pass 0 ALONE, reading
+// Qd, Ad, qd, R, w straight from the records (the top half is first written by this pass's own update; max |M| falls out of it,
+// and the pivots it accepted under the threshold's lower bound 1e-4 are looked at again), status -4 behind it; MODE 2: the
+// remaining passes of those nodes.  (Two launches, not two code paths in one kernel: with both pass bodies inlined in one function
+// the register allocator spills a hundred registers.)
+template <int MODE>
 __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, SchurBigWs w)
 {
+    constexpr bool RECORDS = MODE == 1;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lc = lane & 15, lq = lane >> 4;
     const int n = a.nd.n, m = a.nd.m;
@@ -192,20 +200,44 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (MODE == 2) { if (a.status[b] != -4) return; }
     // equality rows are not taken here (their multiplier would have to be crashed in)
     int bad_row = 0;
-    if (tid < m && a.nd.l[(size_t)b * m + tid] == a.nd.u[(size_t)b * m + tid]) bad_row = 1;
+    if constexpr (MODE != 2) { if (tid < m && a.nd.l[(size_t)b * m + tid] == a.nd.u[(size_t)b * m + tid]) bad_row = 1; }
     if (tid == 0) sFlag[0] = 1;
     if (__syncthreads_count(bad_row) > 0) { if (tid == 0) a.status[b] = -1; return; }
 
-    double minpiv = QINF;
-    // the pivot threshold 1e-4 max(1, max |M|), max |M| from K0
-    const double ms = w.c[(size_t)b * (n + m)];
-    const double thr = 1e-4 * (ms > 1.0 ? ms : 1.0);
+    double minpiv = QINF, mabs = 0.0;
+    // the pivot threshold 1e-4 max(1, max |M|), max |M| from K0 (RECORDS: after pass 0)
+    double thr = 1e-4;
+    if constexpr (!RECORDS) { const double ms = w.c[(size_t)b * (n + m)]; thr = 1e-4 * (ms > 1.0 ? ms : 1.0); }
     const bool owner = wave < nrt;                      // this wavefront owns row tile `wave`
     const int I = wave;
+    double *const sG = sm + OFF_G;                      // (RECORDS) g = qd + R w
+    if constexpr (RECORDS) {
+        if (tid < n) {
+            const int np_ = a.nd.p;
+            const double *R_ = a.nd.R + (size_t)b * n * np_;
+            const double *w_ = a.nd.w + (size_t)b * (size_t)a.nd.stride_w;
+            double s_ = a.nd.qd[(size_t)b * n + tid];
+            for (int k = 0; k < np_; ++k) s_ = fma(R_[(size_t)k * n + tid], w_[k], s_);
+            sG[tid] = s_;
+        }
+        __syncthreads();
+    }
 
-    for (int kb = 0; 4 * kb < nrt; ++kb) {
+    auto pass = [&](auto first_c, int kb) -> bool {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const double *Q_ = a.nd.Qd + (size_t)b * n * n;          // (FIRST only)
+        const double *A_ = a.nd.Ad + (size_t)b * m * n;
+        // element (g, lane) of the initial tile (I_, J_): H = Qd, C = -Ad', the g tile
+        auto t0 = [&](int I_, int J_, int g) -> double {
+            const int r = 16 * I_ + 4 * g + lq;
+            if (J_ < nrt) return Q_[(16 * J_ + lc) * n + r];
+            if (J_ < nrt + mct) return -A_[r * m + 16 * (J_ - nrt) + lc];
+            const double q = sG[r];
+            return lc == 0 ? q : 0.0;
+        };
         const int bw = (nrt - 4 * kb) < 4 ? (nrt - 4 * kb) : 4;
         const int Jlo = 4 * kb + bw;                    // live column tiles: right of the block
         const int nlive = nct - Jlo;
@@ -217,7 +249,19 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int t = wave + 16 * q, jj = t / bw, br = t - jj * bw;
-                if (t < cnt * bw) v[q] = *reinterpret_cast<const d4 *>(tile(4 * kb + br, J0 + jj) + 4 * lane);
+                if (t < cnt * bw) {
+                    if constexpr (FIRST) {
+                        // entries 4 lane .. 4 lane + 3 of the tile: register g = lane >> 4, lanes 4 (lane & 15) ..: row 4 g + lq', columns cc ..
+                        const int J = J0 + jj, g = lane >> 4, l4 = 4 * (lane & 15), r = 16 * (4 * kb + br) + 4 * g + (l4 >> 4), cc = l4 & 15;
+                        if (J < nrt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[q][e] = Q_[(16 * J + cc + e) * n + r];
+                        } else if (J < nrt + mct) {
+                            const d4 t_ = *reinterpret_cast<const d4 *>(A_ + r * m + 16 * (J - nrt) + cc);
+                            v[q] = -t_;
+                        } else { const double g_ = sG[r]; v[q] = d4{cc == 0 ? g_ : 0.0, 0.0, 0.0, 0.0}; }
+                    } else v[q] = *reinterpret_cast<const d4 *>(tile(4 * kb + br, J0 + jj) + 4 * lane);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -229,8 +273,13 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + TPB2 * e;
-            const int tt = idx >> 8, ti = tt >> 2, tj = tt & 3, g = (idx >> 6) & 3, ln = idx & 63;
-            if (ti < bw && tj < bw) sP[(16 * ti + 4 * g + (ln >> 4)) * LDP + 16 * tj + (ln & 15)] = tile(4 * kb + ti, 4 * kb + tj)[g * 64 + ln];
+            if constexpr (FIRST) {
+                const int r = idx & 63, c = idx >> 6;       // (records: column-major, rows fastest)
+                if (r < 16 * bw && c < 16 * bw) sP[r * LDP + c] = Q_[c * n + r];
+            } else {
+                const int tt = idx >> 8, ti = tt >> 2, tj = tt & 3, g = (idx >> 6) & 3, ln = idx & 63;
+                if (ti < bw && tj < bw) sP[(16 * ti + 4 * g + (ln >> 4)) * LDP + 16 * tj + (ln & 15)] = tile(4 * kb + ti, 4 * kb + tj)[g * 64 + ln];
+            }
         }
         stage(Jlo, nlive < MC ? nlive : MC);
         __syncthreads();
@@ -244,7 +293,7 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
             }
             __syncthreads();
             STAMP(5);   // (diagnostic) the diagonal tile's inverse (wave 0) + barrier
-            if (sFlag[0] == 0) { if (tid == 0) a.status[b] = -1; return; }
+            if (sFlag[0] == 0) return false;
             if (wave < bw && wave != j) {               // row block j: tile (j, k = wave)
                 const int k = wave;
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -294,7 +343,14 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 u[t] = 0.0;
-                if (owner && t < 4 * bw) u[t] = tile(I, 4 * kb + (t >> 2))[(lc >> 2) * 64 + (lc & 3) * 16 + 4 * (t & 3) + lq];
+                if (owner && t < 4 * bw) {
+                    if constexpr (FIRST) u[t] = Q_[(4 * t + lq) * n + 16 * I + lc];
+                    else u[t] = tile(I, 4 * kb + (t >> 2))[(lc >> 2) * 64 + (lc & 3) * 16 + 4 * (t & 3) + lq];
+                }
+            }
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) mabs = max_abs(mabs, u[t]);
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) if (16 * I + lc == 64 * kb + 4 * t + lq) u[t] -= 1.0;      // pivot rows carry P - I
@@ -329,13 +385,17 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
             if (owner) {
                 d4 ct;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) ct[g] = tile(I, J0)[g * 64 + lane];
+                for (int g = 0; g < 4; ++g) ct[g] = FIRST ? t0(I, J0, g) : tile(I, J0)[g * 64 + lane];
 #pragma unroll 1
                 for (int jj = 0; jj < cnt; ++jj) {
                     d4 nx = {0.0, 0.0, 0.0, 0.0};
                     if (jj + 1 < cnt) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) nx[g] = tile(I, J0 + jj + 1)[g * 64 + lane];
+                        for (int g = 0; g < 4; ++g) nx[g] = FIRST ? t0(I, J0 + jj + 1, g) : tile(I, J0 + jj + 1)[g * 64 + lane];
+                    }
+                    if constexpr (FIRST) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) mabs = max_abs(mabs, ct[g]);
                     }
                     const double *const vb = sV + (jj << 10) + lane;
                     if (bw == 4) {
@@ -354,14 +414,37 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_eliminate(AviBatchArgs a, 
             }
             STAMP(6);   // (diagnostic) this wave's tiles of the mega-chunk
         }
+        return true;
+    };
+
+    const int kb_lo = MODE == 2 ? 1 : 0, kb_hi = MODE == 1 ? 1 : (nrt + 3) / 4;
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        const bool ok = pass(std::integral_constant<bool, RECORDS>{}, kb);
+        if (!ok) { if (tid == 0) a.status[b] = -1; return; }
+        if constexpr (RECORDS) {
+            // max |M| is known now: the threshold of the remaining passes (left in the workspace for them), and the pivots of this
+            // pass once more
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mabs, off, 64); mabs = o > mabs ? o : mabs; }
+            if (lane == 0) sRed[wave] = mabs;
+            if (tid == 0) sRed[16] = minpiv;            // (wave 0 ran the inversions)
+            __syncthreads();
+            double ms = sRed[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) ms = sRed[k] > ms ? sRed[k] : ms;
+            thr = 1e-4 * (ms > 1.0 ? ms : 1.0);
+            if (sRed[16] < thr) { if (tid == 0) a.status[b] = -1; return; }
+            if (tid == 0) w.c[(size_t)b * (n + m)] = ms;
+        }
         __threadfence_block();
         __syncthreads();
         STAMP(7);   // (diagnostic) end-of-pass barrier
     }
 #ifdef QPN_STAMPS
-    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[(size_t)b * 8 + k] = stamp_acc[k];
+    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[(size_t)b * 8 + k] += stamp_acc[k];
 #endif
-    if (tid == 0) a.status[b] = -3;                      // eliminated: the S product takes it from here
+    // eliminated (-3: the S product takes it from here) / pass 0 done (-4: the remaining passes are another launch)
+    if (tid == 0) a.status[b] = (MODE == 1 && kb_hi < (nrt + 3) / 4) ? -4 : -3;
 }
 
 // ---- K2: S = -Ad W and c = b - Ad h (b = B w): wave Is holds row tile Is of S, W | h crosses LDS in blocks of 64 rows x JC
@@ -449,7 +532,7 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_sprod(AviBatchArgs a, Schu
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int ri = 16 * Is + 4 * g + lq, cj = 16 * J + lc;
-                        if (J < mct) { if (ri < m && cj < m) Sg[(size_t)ri * (m + 1) + cj] = acc[jj][g]; }       // straight into the Lemke dictionary
+                        if (J < mct) { if (ri < m && cj < m) Sg[(size_t)ri * ((m + 1 + 15) & ~15) + cj] = acc[jj][g]; }       // straight into the Lemke dictionary
                         else if (J == mct && lc == 0 && ri < m) cg[ri] = acc[jj][g];
                     }
                 }
@@ -597,7 +680,7 @@ hipError_t qpn_launch_schur_big2_stage_a(const AviBatchArgs &a, void *ws, double
     SchurBigWs w{};
     w.tt_stride = (int64_t)((rows < 512 ? rows : 512) * (size_t)(((N + 15) & ~15) + 48));
     w.s_stride = (int64_t)N * N;
-    w.s_rowmajor = 2;                                   // S is written straight into the Lemke kernel's dictionary (row stride m + 1)
+    w.s_rowmajor = 2;                                   // S is written straight into the Lemke kernel's dictionary (its row stride)
     double *p = static_cast<double *>(ws);
     w.Tt = p; p += (size_t)batch * w.tt_stride;
     p += (size_t)batch * w.s_stride;                    // (the S area of the shared carving: unused here)
@@ -615,8 +698,14 @@ hipError_t qpn_launch_schur_big2_stage_a(const AviBatchArgs &a, void *ws, double
     static QpnPerDeviceOnce attr_once;
     const int attr_dev = attr_once.device();
     if (!attr_once.done[attr_dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big2_eliminate),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big2_eliminate<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * (int)sizeof(double));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big2_eliminate<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * (int)sizeof(double));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big2_eliminate<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DOUBLES * (int)sizeof(double));
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big2_sprod),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SPROD * (int)sizeof(double));
@@ -624,8 +713,14 @@ hipError_t qpn_launch_schur_big2_stage_a(const AviBatchArgs &a, void *ws, double
         attr_once.done[attr_dev] = true;
     }
     const dim3 grid((unsigned)batch);
-    hipLaunchKernelGGL(schur_big2_convert, grid, dim3(256), 0, stream, a, w);
-    hipLaunchKernelGGL(schur_big2_eliminate, grid, dim3(TPB2), LDS_DOUBLES * sizeof(double), stream, a, w);
+    static const bool force_convert = [] { const char *e = getenv("QPN_BIG2_CONVERT"); return e && e[0] == '1'; }();     // A/B switch
+    if (!force_convert && (a.nd.n & 15) == 0 && (a.nd.m & 15) == 0) {
+        hipLaunchKernelGGL(schur_big2_eliminate<1>, grid, dim3(TPB2), LDS_DOUBLES * sizeof(double), stream, a, w);
+        if (a.nd.n > 64) hipLaunchKernelGGL(schur_big2_eliminate<2>, grid, dim3(TPB2), LDS_DOUBLES * sizeof(double), stream, a, w);
+    } else {
+        hipLaunchKernelGGL(schur_big2_convert, grid, dim3(256), 0, stream, a, w);
+        hipLaunchKernelGGL(schur_big2_eliminate<0>, grid, dim3(TPB2), LDS_DOUBLES * sizeof(double), stream, a, w);
+    }
     hipLaunchKernelGGL(schur_big2_sprod, grid, dim3(TPB2), LDS_SPROD * sizeof(double), stream, a, w);
     return hipGetLastError();
 }

@@ -90,3 +90,52 @@ def test_config5_subset_against_oracle(oracle, full5):
     assert np.array_equal(res["active"][idx], rc["active"])          # bit-exact active sets
     zr = rc["z"]
     assert np.max(np.abs(res["z"][idx] - zr)) <= 1e-9 * max(1.0, np.max(np.abs(zr)))
+
+
+@pytest.mark.parametrize("n,m,cnt", [(256, 256, 3), (100, 130, 4), (70, 40, 5), (256, 100, 3), (200, 256, 3), (129, 1, 4), (250, 255, 3)])
+def test_large_nodes_from_records_vs_oracle_and_previous_route(engine, oracle, n, m, cnt):
+    """The blocked crash straight from the records (csrc/qpn_avi_schur_big2.hip: rank-64 block pivots on a tile-format
+    workspace, sizes that are not multiples of 16 padded in the conversion pass) against the oracle -- status, masks bit-exact,
+    primals within 1e-9 relative, pivot counts -- and against round 2's route over an assembled M (QPN_OPT_BIG_ROUTE = 0):
+    same masks and pivot counts, primals within 1e-9."""
+    from qpn_amd import _lib
+    from qpn_amd.engine import colmajor
+    Q, R, qd, A, B, l, u = P.synth_nodes(9000 + n + m, cnt, n, m, 4)
+    w = P.shared_params(4)
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+    rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+    args = (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+    rh = engine.solve_nodes(*args)
+    assert np.array_equal(rh["status"], rc["status"]) and np.all(rc["status"] == 1)
+    assert np.array_equal(rh["active"], rc["active"]) and np.array_equal(rh["pivots"], rc["pivots"])
+    scale = np.maximum(1.0, np.max(np.abs(rc["z"]), axis=1, keepdims=True))
+    assert np.max(np.abs(rh["z"] - rc["z"]) / scale) <= 1e-9 and np.max(rh["resid"]) <= 1e-8
+    engine.set_option(_lib.OPT_BIG_ROUTE, 0)
+    try:
+        r0 = engine.solve_nodes(*args)
+    finally:
+        engine.set_option(_lib.OPT_BIG_ROUTE, 1)
+    assert np.array_equal(r0["status"], rh["status"]) and np.array_equal(r0["active"], rh["active"])
+    assert np.array_equal(r0["pivots"], rh["pivots"]) and np.max(np.abs(r0["z"] - rh["z"]) / scale) <= 1e-9
+
+
+def test_large_nodes_declines_take_the_general_path(engine, oracle):
+    """A node whose Qd has a block pivot below the threshold (here: Q = 0 in the first 3 variables) and a node with an equality
+    row are declined by the blocked crash and solved by the general kernel behind it: same results as the checker."""
+    from qpn_amd.engine import colmajor
+    n, m, cnt = 80, 70, 4
+    Q, R, qd, A, B, l, u = P.synth_nodes(9500, cnt, n, m, 4)
+    w = P.shared_params(4)
+    Q[1, :3, :] = 0.0; Q[1, :, :3] = 0.0                  # a singular leading block: the crash declines node 1
+    A[1, :3, :] = 0.0; A[1, 0, 0] = 1.0; A[1, 1, 1] = 1.0; A[1, 2, 2] = 1.0      # ... which the bounds keep well-posed
+    l[1, :3] = -0.5; u[1, :3] = 0.5
+    u[2, 5] = l[2, 5]                                      # an equality row: node 2 is declined too
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+    rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+    rh = engine.solve_nodes(colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+    assert np.array_equal(rh["status"], rc["status"])
+    ok = rc["status"] == 1
+    assert ok[0] and ok[3]
+    scale = np.maximum(1.0, np.max(np.abs(rc["z"]), axis=1, keepdims=True))
+    assert np.max((np.abs(rh["z"] - rc["z"]) / scale)[ok]) <= 1e-9
+    assert np.array_equal(rh["active"][ok], rc["active"][ok])

@@ -19,13 +19,20 @@ names = ["setup", "pivot block + first pivot rows -> LDS", "inversion: the three
 for cnt in [int(x) for x in os.environ.get("CNT", "512,256").split(",")]:
     Q, R, qd, A, B, l, u = P.synth_nodes(7000 + n, cnt, n, m)
     args = [t(colmajor(Q)), t(colmajor(R)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(P.shared_params())]
-    st = torch.zeros((cnt, 8), dtype=torch.int64, device="cuda:0")
+    st = torch.zeros((2 * cnt, 8), dtype=torch.int64, device="cuda:0")
     eng.lib.qpn_debug_set_stamps(C.c_void_p(st.data_ptr()))
     for _ in range(3):
         res = eng.solve_nodes(*args)
     torch.cuda.synchronize()
-    s = st.cpu().numpy().astype(np.float64)
+    sall = st.cpu().numpy().astype(np.float64)
+    s = sall[:cnt]
     tot = s.sum(axis=1).mean()
     print(f"n = m = {n}, {cnt} nodes: mean {tot:.0f} clocks per workgroup, solved {(res['status'] == 1).float().mean().item() * 100:.0f} %")
     for i, nm in enumerate(names):
         print(f"  {nm:36s} {s[:, i].mean():12.0f}  {100 * s[:, i].mean() / tot:5.1f} %", flush=True)
+    s = sall[cnt:]
+    tot = s.sum(axis=1).mean()
+    lp = float(res["pivots"].double().mean()) - n
+    print(f"  Lemke kernel (thread 0): mean {tot:.0f} clocks per workgroup, {lp:.1f} pivots -> {tot / max(lp, 1):.0f} per pivot")
+    for i, nm in enumerate(["setup", "entering column", "ratio test + two reductions", "pivot row -> pending pair", "bookkeeping + next column index", "folds", "exit"]):
+        print(f"    {nm:36s} {s[:, i].mean():12.0f}  {100 * s[:, i].mean() / tot:5.1f} %", flush=True)
