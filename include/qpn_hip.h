@@ -298,7 +298,10 @@ int qpn_sweep_status(qpn_ctx *ctx, const int32_t *status, const double *resid, i
  *     entries <= 1e-8 dropped (:439),  keep[] = find_non_trivial (:384-388).
  * Output per piece: Ap [(2N) x (N+p)] column-major (N = n+m), lp, up [2N], keep [2N]; simplify / projection stay with the
  * caller (polyhedral algebra).  `pieces` items; item t uses the records of node node_of[t] (node_of == NULL: node t), so
- * the many recipes of one solution share its records (nodes = number of record sets behind the pointers).
+ * the many recipes of one solution share its records (nodes = number of record sets behind the pointers).  node_of entries
+ * outside 0 .. nodes-1: QPN_ERR_ARG for host arrays; for device arrays (not read by the host) the piece comes back EMPTY --
+ * keep = 0 on every row, bounds (-inf, +inf), zero coefficients -- and no record is read.  Codes outside a row's range
+ * (x_d rows: 1..3, constraint rows: 5..8) mean "no condition" like code 0 (what qpn_recipes_from_masks emits for an empty mask).
  * qpn_recipes_from_masks enumerates recipes from the active-set masks of a solve (`active` of qpn_solve_nodes, one uint8
  * per row: the code sets J of src/avi_solutions.jl:511-562): recipe number first + t of the Cartesian product of the rows'
  * code sets (all_Ks, :200-215; row 0 is the fastest digit) for t < count; *total (may be NULL) = number of recipes

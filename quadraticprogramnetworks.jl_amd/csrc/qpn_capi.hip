@@ -508,7 +508,7 @@ int qpn_local_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     if (mem == QPN_MEM_DEVICE) {
-        HIPCHK(ctx, qpn_launch_local_pieces(pieces, n, m, p, Qd, R, qd, Ad, B, l, u, node_of, K, Ap, lp, up, keep, s));
+        HIPCHK(ctx, qpn_launch_local_pieces(pieces, nodes, n, m, p, Qd, R, qd, Ad, B, l, u, node_of, K, Ap, lp, up, keep, s));
         return QPN_OK;
     }
     if (node_of)
@@ -535,7 +535,7 @@ int qpn_local_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int
     if (sz.lu) { HIPCHK(ctx, hipMemcpyAsync(dl, l, sz.lu, hipMemcpyHostToDevice, s)); HIPCHK(ctx, hipMemcpyAsync(du, u, sz.lu, hipMemcpyHostToDevice, s)); }
     if (node_of) HIPCHK(ctx, hipMemcpyAsync(dno, node_of, (size_t)pieces * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(dK, K, (size_t)pieces * N, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, qpn_launch_local_pieces(pieces, n, m, p, dQ, dR, dq, dA, dB, dl, du, dno, dK, dAp, dlp, dup, dkeep, s));
+    HIPCHK(ctx, qpn_launch_local_pieces(pieces, nodes, n, m, p, dQ, dR, dq, dA, dB, dl, du, dno, dK, dAp, dlp, dup, dkeep, s));
     HIPCHK(ctx, hipMemcpyAsync(Ap, dAp, (size_t)pieces * rows * cols * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(lp, dlp, (size_t)pieces * rows * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(up, dup, (size_t)pieces * rows * 8, hipMemcpyDeviceToHost, s));

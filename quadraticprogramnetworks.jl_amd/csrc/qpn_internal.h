@@ -147,7 +147,7 @@ hipError_t qpn_launch_sweep_status(const int32_t *status, const double *resid, i
                                    int32_t rank, int32_t world, const SweepBoxes &boxes, unsigned long long epoch,
                                    unsigned long long timeout_ticks, hipStream_t stream);
 // local pieces (local_piece) and recipe enumeration (all_Ks): all pointers device
-hipError_t qpn_launch_local_pieces(int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
+hipError_t qpn_launch_local_pieces(int32_t batch, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
                                    const double *qd, const double *Ad, const double *B, const double *l, const double *u,
                                    const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up, uint8_t *keep,
                                    hipStream_t stream);

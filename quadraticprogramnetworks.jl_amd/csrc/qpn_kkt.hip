@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void assemble_pools_kernel(PoolArgs a)
 // node node_of[t] (or t): many recipes of one node share its records.  Output BEFORE simplify (polyhedral, host side):
 // Ap [(2N) x (N+p)] column-major, lp / up [2N] with the noisy l > u fix (:437-438), entries <= 1e-8 dropped (:439),
 // keep [2N] = find_non_trivial (:384-388: a finite bound and a non-empty row).
-__global__ __launch_bounds__(256) void local_pieces_kernel(int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd,
+__global__ __launch_bounds__(256) void local_pieces_kernel(int32_t batch, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd,
                                                             const double *R, const double *qd, const double *Ad,
                                                             const double *B, const double *l, const double *u,
                                                             const int32_t *node_of, const uint8_t *K, double *Ap,
@@ -262,6 +262,14 @@ __global__ __launch_bounds__(256) void local_pieces_kernel(int32_t batch, int32_
     const int t = blockIdx.x, tid = threadIdx.x;
     const int b = node_of ? node_of[t] : t;
     const int N = n + m, rows = 2 * N, cols = N + p;
+    if ((unsigned)b >= (unsigned)nodes) {
+        // a record index outside 0 .. nodes - 1 (device callers are not checked on the host): the piece comes back EMPTY -- every
+        // row dropped (keep = 0), bounds (-inf, +inf), zero coefficients -- and no record is read
+        for (int r = tid; r < rows; r += 256) { keep[(size_t)t * rows + r] = 0; lp[(size_t)t * rows + r] = -QINF; up[(size_t)t * rows + r] = QINF; }
+        double *Az = Ap + (size_t)t * (size_t)rows * cols;
+        for (size_t e = tid; e < (size_t)rows * cols; e += 256) Az[e] = 0.0;
+        return;
+    }
     const double *Q_ = Qd + (size_t)b * n * n, *A_ = Ad + (size_t)b * m * n, *R_ = R + (size_t)b * n * p, *B_ = B + (size_t)b * m * p;
     double *Ao = Ap + (size_t)t * (size_t)rows * cols;
     __shared__ int s_nz[1024];                                       // non-empty flag per row (rows <= 2 * 512)
@@ -479,13 +487,13 @@ hipError_t qpn_launch_order_by_pivots(const int32_t *pivots, int32_t count, int3
     return hipGetLastError();
 }
 
-hipError_t qpn_launch_local_pieces(int32_t batch, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
+hipError_t qpn_launch_local_pieces(int32_t batch, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
                                    const double *qd, const double *Ad, const double *B, const double *l, const double *u,
                                    const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up, uint8_t *keep,
                                    hipStream_t stream)
 {
     if (batch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(local_pieces_kernel, dim3((unsigned)batch), dim3(256), 0, stream, batch, n, m, p, Qd, R, qd, Ad, B, l, u,
+    hipLaunchKernelGGL(local_pieces_kernel, dim3((unsigned)batch), dim3(256), 0, stream, batch, nodes, n, m, p, Qd, R, qd, Ad, B, l, u,
                        node_of, K, Ap, lp, up, keep);
     return hipGetLastError();
 }

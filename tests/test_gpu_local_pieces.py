@@ -78,6 +78,41 @@ def test_local_pieces_device_buffers(engine, oracle):
         assert np.array_equal(up[b].cpu().numpy(), uo) and np.array_equal(keep[b].cpu().numpy(), ko)
 
 
+def test_local_pieces_bad_node_index(engine, oracle):
+    """node_of outside 0 .. nodes-1: an argument error for host arrays; for DEVICE arrays (which the host does not read) the
+    kernel itself returns an empty piece -- every row dropped, infinite bounds, zero coefficients -- instead of reading records
+    that do not exist; the pieces next to it are untouched.  Codes outside a row's range mean "no condition" like code 0."""
+    import torch
+    from qpn_amd.engine import colmajor
+    n, m, p, cnt = 6, 7, 2, 3
+    Q, R, qd, A, B, l, u = _records(11, cnt, n, m, p)
+    rng = np.random.default_rng(2)
+    K = np.concatenate([rng.integers(1, 4, size=(4, n)), rng.integers(5, 9, size=(4, m))], axis=1).astype(np.uint8)
+    node_of = np.array([0, 7, 2, -1], np.int32)
+    args = (colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u)
+    with pytest.raises(Exception):
+        engine.local_pieces(*args, K, node_of=node_of)
+    t = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
+    Ap, lp, up, keep = engine.local_pieces(*[t(a) for a in args], t(K, torch.uint8), node_of=t(node_of, torch.int32))
+    torch.cuda.synchronize()
+    for tt in (1, 3):
+        assert not keep[tt].any() and not Ap[tt].any()
+        assert bool((lp[tt] == -INF).all()) and bool((up[tt] == INF).all())
+    for tt in (0, 2):
+        b = int(node_of[tt])
+        Ao, lo, uo, ko = oracle.local_piece(Q[b], R[b], qd[b], A[b], B[b], l[b], u[b], K[tt])
+        assert np.array_equal(Ap[tt].cpu().numpy().T, Ao) and np.array_equal(keep[tt].cpu().numpy(), ko)
+        assert np.array_equal(lp[tt].cpu().numpy(), lo) and np.array_equal(up[tt].cpu().numpy(), uo)
+    # code 0 and an out-of-range code: the same piece as the "free" codes (4 on x rows; nothing comparable on constraint rows:
+    # there 0 leaves the row unconditioned)
+    K0 = K[:1].copy(); K0[0, 0] = 0
+    K4 = K[:1].copy(); K4[0, 0] = 4
+    a0 = engine.local_pieces(*args, K0, node_of=np.zeros(1, np.int32))
+    a4 = engine.local_pieces(*args, K4, node_of=np.zeros(1, np.int32))
+    for x0, x4 in zip(a0, a4):
+        assert np.array_equal(np.asarray(x0), np.asarray(x4))
+
+
 def test_recipe_enumeration_is_the_cartesian_product(engine):
     rng = np.random.default_rng(3)
     for trial in range(5):

@@ -208,6 +208,29 @@ def test_exemplar_rule_open_bounds_and_implicit_bounds_on_the_oracle_engine():
     assert np.array_equal(Pn.A, [[1.0]]) and Pn.l[0] == -1.0 and Pn.u[0] == 2.0 and not Pn.open_lo[0] and Pn.open_hi[0]
 
 
+def test_exemplar_rule_hand_checked_edges_on_the_oracle_engine():
+    r"""Parity unpinned (the reference holds no fixture for `exemplar`): two edges of src/sets.jl:591-642 checked by hand.
+    (1) `isapprox(l, u; atol, rtol)` at :599 is a condition on the NORM of l - u, not elementwise: four components 0.009
+    apart pass an elementwise test at tol = 1e-2 but have norm 0.018 > max(atol, rtol * norm) = 0.01 -- the square-equality
+    shortcut must NOT be taken (the slack LP runs: eps is reported); the same rows 0.004 apart (norm 0.008) take the shortcut
+    (eps = NaN, x = A \ l).  (2) A polyhedron without a finite bound makes the slack LP unbounded (OSQP status 4, which the
+    reference does not handle): eps stops at -slack_cap and the set is non-empty."""
+    from oracle_engine import OracleEngine
+    eng = OracleEngine()
+    A = np.eye(4)
+    l = np.full(4, 0.1)
+    e, ex, eps = polyhedra.exemplar_slack_batch([(A, l, l + 0.009), (A, l, l + 0.004)], eng, tol=1e-2)
+    assert list(e) == [False, False]
+    assert np.isfinite(eps[0]) and eps[0] == pytest.approx(-0.0045, abs=1e-7)      # the LP ran: the centre of the box, slack 0.0045
+    assert np.isnan(eps[1]) and np.allclose(ex[1], l)                              # the shortcut: x = A \ l
+    assert polyhedra._isapprox(l, l + 0.004, 1e-2, 1e-2) and not polyhedra._isapprox(l, l + 0.009, 1e-2, 1e-2)
+    # infinite entries: the norm is not finite -> Julia falls back to the component-wise rule (Inf == Inf, -Inf != Inf)
+    assert polyhedra._isapprox([np.inf, 1.0], [np.inf, 1.005], 1e-2, 1e-2) and not polyhedra._isapprox([-np.inf], [np.inf], 1e-2, 1e-2)
+    free = (np.array([[1.0, 2.0]]), np.array([-np.inf]), np.array([np.inf]))
+    e, ex, eps = polyhedra.exemplar_slack_batch([free], eng, tol=1e-2, slack_cap=1.0)
+    assert list(e) == [False] and eps[0] == pytest.approx(-1.0) and ex[0].shape == (2,)
+
+
 @pytest.mark.gpu
 def test_exemplar_rule_and_implicit_bounds_on_the_hip_engine(engine):
     _check_slack_and_implicit(engine, 11)
