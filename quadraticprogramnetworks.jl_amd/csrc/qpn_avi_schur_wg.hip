@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
     extern __shared__ __attribute__((aligned(32))) double sm[];
     double *const sQ = sm + OFF_Q, *const sUv = sm + OFF_U + 64 * v, *const sPr = sm + OFF_PR;
     double *const sRed = sm + OFF_RED, *const sH = sm + OFF_H, *const sV = sm + OFF_BIG, *const sW = sm + OFF_BIG;
-    double *const sucol = sm + OFF_COL, *const sval = sm + OFF_VAL, *const sz = sm + OFF_Z;
+    double *const sval = sm + OFF_VAL, *const sz = sm + OFF_Z;
 
     const double *Q_ = a.nd.Qd + (size_t)b * n * n;
     const double *A_ = a.nd.Ad + (size_t)b * m * n;
