@@ -981,10 +981,15 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         // post-check, requested now so that the round trip hides behind the reduction and its LDS hops)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NODES && FULL32) {
-            {
-                const double *qc = Qe_ + (l < 32 ? l : 0);
+            // (x rows: this lane's row of Qd from global memory; constraint rows: this lane's row of Ad from the LDS block buffer
+            //  -- two exec-masked batches into the SAME registers, so that the post-check is ONE fma chain over the x columns)
+            if (l < 32) {
+                const double *qc = Qe_ + l;
 #pragma unroll
                 for (int j = 0; j < 32; ++j) mq32[j] = qc[(size_t)j * 32];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) mq32[j] = sA[j * SAS + (l - 32)];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1029,18 +1034,10 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         double rq = SQ(l), ra = rq;
         int j = 0;
         if constexpr (FULL32) {
-            // eight columns at a time, with both accumulators pinned in between: left alone the compiler sinks the `ra` chain
-            // below the lambda loop (only the constraint lanes keep it) and carries its 32 LDS operands there through scratch
+            // the x columns: ONE chain for every lane -- its operands (a row of Qd or a row of Ad) were fetched into mq32 by role
 #pragma unroll
-            for (int jb = 0; jb < 32; jb += 8) {
-#pragma unroll
-                for (int jj = jb; jj < jb + 8; ++jj) {
-                    const double zj = sz[jj];
-                    rq = fma(mq32[jj], zj, rq);
-                    ra = fma(sA[jj * SAS + aoff], zj, ra);
-                }
-                asm volatile("" : "+v"(ra), "+v"(rq));
-            }
+            for (int jj = 0; jj < 32; ++jj) rq = fma(mq32[jj], sz[jj], rq);
+            ra = rq;
             j = 32;
         }
         for (; j + 8 <= nn; j += 8) {
