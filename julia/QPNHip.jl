@@ -268,6 +268,16 @@ end
 # period (in calls) of the context's own refresh of that hint; 0 = off (default 16)
 set_auto_schedule!(period::Integer) = (ccall((:qpn_ctx_set_auto_schedule, LIB), Cint, (Ptr{Cvoid}, Int32), ctx(), Int32(period)); nothing)
 clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), C_NULL, Int32(0), QPN_MEM_HOST); nothing)
+# kernel routes with identical contracts (A/B measurements; include/qpn_hip.h, QPN_OPT_*): MID_ROUTE 1 = fused workgroup kernel per
+# node of 33 .. 128 variables or constraints (default), 2 / 0 = the routes it replaced; BIG_ROUTE 1 = blocked crash straight from
+# the records for nodes up to 256 x 256 (default), 0 = over an assembled M
+const QPN_OPT_MID_ROUTE = Int32(1)
+const QPN_OPT_BIG_ROUTE = Int32(2)
+function set_option!(option::Integer, value::Integer)
+    rc = ccall((:qpn_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Int32, Int32), ctx(), Int32(option), Int32(value))
+    rc == 0 || error("qpn_ctx_set_option failed ($rc)")
+    nothing
+end
 
 # ---- multi-GPU (one Julia process per GPU, e.g. under MPI.jl / Distributed): replicas of the iterate ----
 # The ABI works on DEVICE pointers here (the host-array routes above stage through the library's workspace):
