@@ -572,13 +572,18 @@ def run_config5(env, args):
     out = None
     x = torch.zeros((cnt, n), dtype=torch.float64, device=dev)
     prewarm_steps = 0 if args.no_prewarm else 200         # ~0.7 s: the GPU's idle power state (see the module docstring)
+    piv_sum = torch.zeros((), dtype=torch.float64, device=dev)
     for i in range(prewarm_steps + warmup):
         out = handle.solve(ring[i % RING], out=out, x_out=x)
+        # (the warm-up runs the SAME step as the timed loop, pivot-count reduction included: torch loads that reduction kernel's
+        #  module on first use -- tens of milliseconds that round 2's line carried inside its timed region)
+        piv_sum += out["pivots"].sum()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    piv_sum.zero_()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    piv_sum = torch.zeros((), dtype=torch.float64, device=dev)
     for i in range(steps):
         out = handle.solve(ring[(warmup + i) % RING], out=out, x_out=x)
         piv_sum += out["pivots"].sum()
