@@ -300,6 +300,11 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
     # for N > 1, the exchange): an upper bound of the solve kernel's own duration.  ("kernel_ms_all" = (ev1 - ev0) / K.)
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     evm = torch.cuda.Event(enable_timing=True)
+    # (torch creates the HIP event behind an Event object on its FIRST record(): each of the three is recorded once here, so that
+    #  no event creation sits between the start of the clock and the first launch)
+    for ev in (ev0, evm, ev1):
+        ev.record()
+    barrier()
     sweeps_before = handle.info()["sweeps"] if handle is not None else None      # (the window is NOT placed: a schedule
     t0 = time.perf_counter()                                                      #  re-sort falls where it falls, see below)
     ev0.record()
