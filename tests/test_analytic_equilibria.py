@@ -7,6 +7,9 @@ And quantity competition with linear demand (price a - b sum q, unit cost c; pla
 q_i >= 0) in its classical variants, on one, two and three levels of the network: Cournot-Nash with n firms q_i = (a - c) / ((n + 1) b);
 Stackelberg leader-follower (a - c) / (2b), (a - c) / (4b); a three-level chain (a - c) / (2b), / (4b), / (8b); a leader above
 two Nash followers (a - c) / (2b), then (a - c) / (6b) each.
+And the reference's own `four_player_matrix_game` example (examples/four_player_matrix_game.jl) under ten edge lists -- one to four
+levels, several players per level, a child with two parents -- against `backward_substitution`: the equilibrium of quadratic players
+whose constraints stay inactive, by elimination of the descendants' affine responses (linear solves only).
 Not reference-held vectors -- the reference has none for such nets -- but independent of every restatement in this repository."""
 import numpy as np
 import pytest
@@ -73,6 +76,75 @@ QUANTITY = [("Cournot, 2 firms", (2, 10.0, 1.0, 1.0), (), np.full(2, 3.0)),
             ("a leader above two Nash followers", (3, 10.0, 1.0, 1.0), ((0, 1), (0, 2)), np.array([4.5, 1.5, 1.5]))]
 
 
+def backward_substitution(net):
+    """An independent statement of the equilibrium of a network of QUADRATIC players while no constraint is active: player j
+    picks its own variables knowing the (affine) joint response of the sub-network of its descendants, everything else
+    held fixed; the sub-network's response is the simultaneous solution of its members' first-order conditions, each with
+    the total derivative through ITS descendants.  Plain linear algebra, no pivoting method, no polyhedra."""
+    nv = len(net.default_initialization)
+    pids = sorted(net.qps.keys())
+    own = {i: sorted(net.qps[i].var_indices) for i in pids}
+
+    def descendants(i, acc=None):
+        acc = set() if acc is None else acc
+        for c in net.network_edges[i]:
+            if c not in acc:
+                acc.add(c)
+                descendants(c, acc)
+        return acc
+
+    memo = {}
+
+    def response(D):
+        """x[V(D)] = K x[rest] + k for the players in D."""
+        if D in memo:
+            return memo[D]
+        VD = sorted(v for j in D for v in own[j])
+        rest = [v for v in range(nv) if v not in VD]
+        rows, rhs = [], []
+        for j in sorted(D):
+            Q = np.asarray(net.qps[j].f.Q, dtype=float)
+            Q = 0.5 * (Q + Q.T)
+            T = np.zeros((len(own[j]), nv))
+            for a, v in enumerate(own[j]):
+                T[a, v] = 1.0
+            Dj = frozenset(descendants(j))
+            if Dj:
+                Kj, _, VDj, restj = response(Dj)
+                for a, v in enumerate(own[j]):
+                    T[a, VDj] = Kj[:, restj.index(v)]
+            rows.append(T @ Q)
+            rhs.append(T @ np.asarray(net.qps[j].f.q, dtype=float))
+        Mx, c = np.vstack(rows), np.concatenate(rhs)
+        K = -np.linalg.solve(Mx[:, VD], Mx[:, rest])
+        k = -np.linalg.solve(Mx[:, VD], c)
+        memo[D] = (K, k, VD, rest)
+        return memo[D]
+
+    _, k, VD, _ = response(frozenset(pids))
+    x = np.zeros(nv)
+    x[VD] = k
+    return x
+
+
+# every shape of hierarchy four players allow up to relabelling that the example accepts: flat, one to four levels,
+# several players on a level, a child with two parents, two separate pairs
+HIERARCHIES = [[], [(1, 2)], [(1, 2), (2, 3)], [(1, 2), (1, 3)], [(1, 3), (2, 3)], [(1, 2), (2, 3), (3, 4)],
+               [(1, 2), (3, 4)], [(1, 2), (1, 3), (1, 4)], [(1, 2), (2, 3), (2, 4)], [(1, 3), (2, 3), (3, 4)]]
+
+
+def _check_hierarchies(engine):
+    from qpn_amd import examples
+    for edges in HIERARCHIES:
+        for seed in (1, 4):
+            net = examples.setup("four_player_matrix_game", edge_list=edges, seed=seed)
+            want = backward_substitution(net)
+            assert np.max(np.abs(want)) < 5.0, "the box of the example must stay inactive for the closed form to hold"
+            ret = algorithm.solve(net, engine=engine)
+            assert ret["solved"], (edges, seed)
+            assert np.max(np.abs(ret["x_opt"] - want)) <= 1e-9, (edges, seed, ret["x_opt"], want)
+
+
 def _check(engine):
     for name, A, reg, want in GAMES:
         ret = algorithm.solve(matrix_game(A, reg), engine=engine)
@@ -92,3 +164,13 @@ def test_analytic_equilibria_on_the_oracle_engine():
 @pytest.mark.gpu
 def test_analytic_equilibria_on_the_hip_engine(engine):
     _check(engine)
+
+
+def test_four_player_hierarchies_against_backward_substitution_on_the_oracle_engine():
+    from oracle_engine import OracleEngine
+    _check_hierarchies(OracleEngine())
+
+
+@pytest.mark.gpu
+def test_four_player_hierarchies_against_backward_substitution_on_the_hip_engine(engine):
+    _check_hierarchies(engine)
