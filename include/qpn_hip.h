@@ -212,7 +212,9 @@ int qpn_nodes_set_schedule(qpn_ctx *ctx, qpn_nodes *nodes, int32_t period);
 int qpn_nodes_free(qpn_ctx *ctx, qpn_nodes *nodes);
 /* info[0] = what is known about the general kernel's share of these records: 0 nothing yet, 1 the count of the first
  * sweep is on its way to the host, 2 no node needs it (sweeps are one launch), 3 some do; info[1] = that count (valid
- * in states 2, 3); info[2] = 1 when a longest-first schedule is installed; info[3] = sweeps since the last schedule reset. */
+ * in states 2, 3); info[2] = bit 0: a longest-first schedule is installed, bit 1: every Qd block of the records is bitwise
+ * symmetric (settled by one pass when the records arrive or Qd is replaced; QPN_OPT_SYM_ROUTE); info[3] = sweeps since the
+ * last schedule reset. */
 int qpn_nodes_info(qpn_ctx *ctx, qpn_nodes *nodes, int32_t info[4]);
 int qpn_solve_nodes_h(qpn_ctx *ctx, qpn_nodes *nodes, const double *w, int64_t stride_w, double *z,
                       int32_t *status, double *resid, int32_t *pivots, uint8_t *active,
@@ -246,9 +248,14 @@ int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period);
  *                      large nodes beyond), 0 = the route of large nodes.
  *                      The environment variable QPN_NODES_MID, read once by qpn_ctx_create, presets it.
  *   QPN_OPT_BIG_ROUTE  node records with 64 < n <= 256 and m <= 256 beyond the sizes above (BASELINE config 5): 1 = the blocked
- *                      matrix-core crash straight from the records (default), 0 = round 2's route over an assembled M. */
+ *                      matrix-core crash straight from the records (default), 0 = round 2's route over an assembled M.
+ *   QPN_OPT_SYM_ROUTE  resident records (qpn_nodes_upload) whose Qd blocks are ALL bitwise symmetric: 1 = kernel variants that
+ *                      use the symmetry of H and of S = A H^-1 A' (default; today n = m = 32: 8 of 88 fp64 MFMAs per solve less),
+ *                      0 = the general variants.  Records with any asymmetric Qd, and records passed per call, always take
+ *                      the general variants. */
 #define QPN_OPT_MID_ROUTE 1
 #define QPN_OPT_BIG_ROUTE 2
+#define QPN_OPT_SYM_ROUTE 3
 int qpn_ctx_set_option(qpn_ctx *ctx, int32_t option, int32_t value);
 
 /* ---- multi-GPU: replicas of the iterate on peer GPUs, written by the solve itself -----------------------

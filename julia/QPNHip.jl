@@ -273,6 +273,7 @@ clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{
 # the records for nodes up to 256 x 256 (default), 0 = over an assembled M
 const QPN_OPT_MID_ROUTE = Int32(1)
 const QPN_OPT_BIG_ROUTE = Int32(2)
+const QPN_OPT_SYM_ROUTE = Int32(3)
 function set_option!(option::Integer, value::Integer)
     rc = ccall((:qpn_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Int32, Int32), ctx(), Int32(option), Int32(value))
     rc == 0 || error("qpn_ctx_set_option failed ($rc)")

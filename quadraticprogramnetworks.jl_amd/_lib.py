@@ -31,6 +31,7 @@ SHARED_FINE_GRAINED = 1
 SWEEP_BOX_BYTES = 512
 OPT_MID_ROUTE = 1
 OPT_BIG_ROUTE = 2
+OPT_SYM_ROUTE = 3
 
 
 class LibraryMissing(RuntimeError):

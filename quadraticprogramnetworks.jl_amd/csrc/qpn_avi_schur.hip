@@ -114,10 +114,14 @@ constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resi
 // constant: no ragged-shape code, bounds predicates or padding selects, and (16) no MFMAs on the padding tiles.
 // FULL32 = (SHAPE == 32): the launch's nodes are n = m = 32 -- the hot shape gets its own instantiation, without the
 // ragged-shape code, predicates and padding selects (sizes are compile-time constants there)
-template <bool NODES, int STAGGER = 0, int SHAPE = 0>
+// SYM: every Qd of the launch is bitwise symmetric (settled once for resident records, qpn_nodes_upload): the lower-left tile
+// of H is never loaded or updated -- its pivot columns are the pivot rows of the upper-right tile --, and the lower-left tile
+// of S = A H^-1 A' is the transpose of the upper-right one: 8 of the 88 fp64 MFMAs per solve less.
+template <bool NODES, int STAGGER = 0, int SHAPE = 0, bool SYM = false>
 __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, SchurDebug dbg)
 {
     static_assert(SHAPE == 0 || SHAPE == 16 || SHAPE == 32, "compile-time shapes: 16 and 32");
+    static_assert(!SYM || (NODES && SHAPE == 32), "the symmetric variant exists for n = m = 32 node records");
     static_assert(NODES || SHAPE != 16, "explicit M: N alone settles the split only at N = 64");
     constexpr bool FULL32 = SHAPE == 32;
     constexpr bool HALF16 = SHAPE == 16;
@@ -302,7 +306,8 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             mabs = max_abs_nc(mabs, q_);                                                            \
         }                                                                                           \
         wave_sync();                                                                                \
-        M_LOADH(0, 0, FULL) M_LOADH(0, 1, FULL) M_LOADH(1, 0, FULL) M_LOADH(1, 1, FULL)             \
+        M_LOADH(0, 0, FULL) M_LOADH(0, 1, FULL) if constexpr (!SYM) M_LOADH(1, 0, FULL)             \
+        M_LOADH(1, 1, FULL)                                                                         \
         wave_sync();                                                                                \
         _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                            \
             const int cj = 2 * t + ch;                                                              \
@@ -430,14 +435,21 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         double vraw = TL(IP, J)[GP];                                                                \
         asm volatile("" : "+v"(vraw));      /* opaque: the copy itself is the compiler's (hazard-aware) */ \
         TL(0, J) = MFMA_NEGA(au0, vraw, TL(0, J));                                                  \
-        if constexpr (!HALF16) TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));     /* (16: rows 16.. are padding, U' = 0 there) */ \
+        if constexpr (!HALF16 && !(SYM && (J) == 0))                                                \
+            TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));     /* (16: rows 16.. are padding, U' = 0 there) */ \
     }
 #define M_STEP(KB, JP, GP)                                                                          \
     if (!fail && 4 * (KB) < n) {       /* a block of padded rows is an identity pivot: nothing moves */ \
         constexpr int p0 = 4 * (KB);                                                                \
         constexpr int cq = p0 & 15;                                                                 \
         const int kcol = lc - cq;                                                                   \
-        if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP, GP) M_GATHER(1, JP, GP) }                      \
+        if constexpr (SYM && (JP) == 0) {                                                           \
+            /* rows 16..31 of the pivot columns = the pivot rows' entries in tile (0, 1): one store per lane */ \
+            if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP, GP) }                                      \
+            sU[(16 + lc) * 4 + lq] = TL(0, 1)[GP];                                                  \
+        } else {                                                                                    \
+            if (kcol >= 0 && kcol < 4) { M_GATHER(0, JP, GP) M_GATHER(1, JP, GP) }                  \
+        }                                                                                           \
         wave_sync();                                                                                \
         /* P = L U (unit lower L, no pivoting; uniform, every lane) */                              \
         double pm[4][4];                                                                            \
@@ -534,7 +546,8 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         SB(0, 0) = M_SACC(a0_, TL(I, 2)[g], SB(0, 0));                                              \
         if constexpr (!HALF16) {           /* (16: the other three tiles of S are padding, zero) */    \
             SB(0, 1) = M_SACC(a0_, TL(I, 3)[g], SB(0, 1));                                          \
-            SB(1, 0) = M_SACC(a1_, TL(I, 2)[g], SB(1, 0)); SB(1, 1) = M_SACC(a1_, TL(I, 3)[g], SB(1, 1)); \
+            if constexpr (!SYM) SB(1, 0) = M_SACC(a1_, TL(I, 2)[g], SB(1, 0));                      \
+            SB(1, 1) = M_SACC(a1_, TL(I, 3)[g], SB(1, 1));                                          \
         }                                                                                           \
     }
     // bounds of pair l for Stage B: requested here so that the round trip hides behind the 32 MFMAs
@@ -545,6 +558,12 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     M_SK(0, 0, 0) M_SK(0, 1, 1) M_SK(0, 2, 2) M_SK(0, 3, 3) M_SK(1, 0, 4) M_SK(1, 1, 5) M_SK(1, 2, 6) M_SK(1, 3, 7)
 #undef M_SK
 #undef M_SACC
+    if constexpr (SYM) {
+        // S(1,0) = S(0,1)': register kb of a tile in the accumulator layout IS the A operand of its transpose's k-block kb
+        // (element (i = lc, k = lq) = X[4 kb + lq][lc]); B = rows 4 kb .. 4 kb + 3 of the identity.  Exact (x 1, + 0).
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) SB(1, 0) = MFMA(SB(0, 1)[kb], (lc == 4 * kb + lq) ? 1.0 : 0.0, SB(1, 0));
+    }
     wave_sync();
     // c_k = b_k - sum_j A[k][j] h_j, lane k <-> pair k (k < m)
     double xb = 0.0;
@@ -1170,6 +1189,11 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
     const bool stag = !no_stagger && resident[dev] == kResidentMI355X && a.batch > kResidentMI355X;
     const bool full = a.nd.n == 32 && a.nd.m == 32, half = a.nd.n == 16 && a.nd.m == 16;
     const dim3 grid((unsigned)a.batch), block(WAVE);
+    if (full && a.nd.sym) {
+        if (stag) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 32, true>), grid, block, pad, stream, a, d);
+        else hipLaunchKernelGGL((avi_solve_schur<true, 0, 32, true>), grid, block, pad, stream, a, d);
+        return hipGetLastError();
+    }
     if (stag && full) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 32>), grid, block, pad, stream, a, d);
     else if (stag && half) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 16>), grid, block, pad, stream, a, d);
     else if (stag) hipLaunchKernelGGL((avi_solve_schur<true, kResidentMI355X, 0>), grid, block, pad, stream, a, d);

@@ -41,6 +41,8 @@ struct qpn_ctx {
     // route of large node records (QPN_OPT_BIG_ROUTE): 1 the blocked crash straight from the records (qpn_avi_schur_big2.hip),
     // 0 round 2's route (M assembled, qpn_avi_schur_big.hip)
     int32_t big_route = 1;
+    // QPN_OPT_SYM_ROUTE: 1 = resident records whose Qd blocks are all bitwise symmetric take the kernel variants that use it
+    int32_t sym_route = 1;
 };
 
 namespace {
@@ -154,6 +156,10 @@ int qpn_ctx_set_option(qpn_ctx *ctx, int32_t option, int32_t value)
     case QPN_OPT_BIG_ROUTE:
         if (value < 0 || value > 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_BIG_ROUTE takes 0 or 1");
         ctx->big_route = value;
+        return QPN_OK;
+    case QPN_OPT_SYM_ROUTE:
+        if (value < 0 || value > 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_SYM_ROUTE takes 0 or 1");
+        ctx->sym_route = value;
         return QPN_OK;
     default:
         return fail_arg(ctx, "qpn_ctx_set_option: unknown option");
@@ -691,6 +697,8 @@ struct qpn_nodes {
     int32_t *key = nullptr;                     // smoothed pivot counts the order is made from
     bool order_valid = false;
     int32_t period = 16, calls = 0;
+    // every Qd block bitwise symmetric?  Settled when the records arrive (one pass, nodes_check_symmetry)
+    bool sym = false;
 };
 
 namespace {
@@ -699,6 +707,19 @@ struct NodeDev {                // device views of one qpn_solve_nodes call
     const double *Q, *R, *q, *A, *B, *l, *u, *w;
     double *z; int32_t *st; double *res; int32_t *pv; uint8_t *act;
 };
+
+// one pass over the resident Qd blocks (behind the copies on the context's stream); waits for the answer
+hipError_t nodes_check_symmetry(qpn_ctx *ctx, qpn_nodes *h)
+{
+    h->sym = false;
+    hipError_t e = hipMemsetAsync(h->decl_dev, 0, 4, ctx->stream);       // (the decline counter is idle: no solve is in flight)
+    if (e == hipSuccess) e = qpn_launch_qd_asymmetry(h->batch, h->n, h->f[QPN_NODE_QD], h->decl_dev, ctx->stream);
+    int32_t asym = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(&asym, h->decl_dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) h->sym = asym == 0;
+    return e;
+}
 
 void nodes_poll_declines(qpn_nodes *h)
 {
@@ -718,7 +739,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
     a.batch = batch; a.N = N; a.z = d.z; a.status = d.st; a.resid = d.res; a.pivots = d.pv; a.active = d.act;
     a.check_tol = o.check_tol; a.piv_tol = o.piv_tol; a.feas_tol = o.feas_tol; a.comp_tol = o.comp_tol;
     a.max_pivots = o.max_pivots; a.flags = o.flags & 0xFFFF;
-    a.nd = NodeSrc{n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w};
+    a.nd = NodeSrc{n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, (h && h->sym && ctx->sym_route == 1) ? 1 : 0};
 #ifdef QPN_STAMPS
     a.stamps = g_stamps;
 #endif
@@ -1038,6 +1059,7 @@ int qpn_nodes_upload(qpn_ctx *ctx, int32_t batch, int32_t n, int32_t m, int32_t 
         if (fb[i]) e = hipMemcpyAsync(h->f[i], src[i], fb[i], kind, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // the caller's arrays are free again on return
+    if (e == hipSuccess) e = nodes_check_symmetry(ctx, h);
     if (e != hipSuccess) { int rc = fail_hip(ctx, e, "qpn_nodes_upload"); qpn_nodes_free(ctx, h); return rc; }
     *h->decl_host = 0;
     *out = h;
@@ -1058,6 +1080,7 @@ int qpn_nodes_update(qpn_ctx *ctx, qpn_nodes *h, int32_t field, const double *da
     // what was known about the old records is void (an answer still in flight must not be read as the new one's)
     if (h->decl_state == 1) HIPCHK(ctx, hipEventSynchronize(h->decl_ev));
     h->decl_state = 0;
+    if (field == QPN_NODE_QD) HIPCHK(ctx, nodes_check_symmetry(ctx, h));
     return QPN_OK;
 }
 
@@ -1076,7 +1099,7 @@ int qpn_nodes_info(qpn_ctx *ctx, qpn_nodes *h, int32_t info[4])
     if (!h || !info) return fail_arg(ctx, "qpn_nodes_info: null argument");
     nodes_poll_declines(h);
     info[0] = h->decl_state; info[1] = h->decl_state >= 2 ? *h->decl_host : 0;
-    info[2] = h->order_valid ? 1 : 0; info[3] = h->calls;
+    info[2] = (h->order_valid ? 1 : 0) | (h->sym ? 2 : 0); info[3] = h->calls;
     return QPN_OK;
 }
 

@@ -12,6 +12,7 @@ struct NodeSrc {
     int32_t n, m, p;
     const double *Qd, *R, *qd, *Ad, *B, *l, *u, *w;
     int64_t stride_w;
+    int32_t sym;     // 1 = every Qd of these records is bitwise symmetric (known for resident records only)
 };
 
 // internal flag bits of AviBatchArgs::flags (above the ABI's QPN_AVI_FLAG_*)
@@ -147,6 +148,8 @@ hipError_t qpn_launch_sweep_status(const int32_t *status, const double *resid, i
                                    int32_t rank, int32_t world, const SweepBoxes &boxes, unsigned long long epoch,
                                    unsigned long long timeout_ticks, hipStream_t stream);
 // local pieces (local_piece) and recipe enumeration (all_Ks): all pointers device
+// flag[0] = 1 if any Qd block (n x n, column-major, `batch` of them) is not bitwise symmetric; flag[0] is left alone otherwise
+hipError_t qpn_launch_qd_asymmetry(int32_t batch, int32_t n, const double *Qd, int32_t *flag, hipStream_t stream);
 hipError_t qpn_launch_local_pieces(int32_t batch, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd, const double *R,
                                    const double *qd, const double *Ad, const double *B, const double *l, const double *u,
                                    const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up, uint8_t *keep,

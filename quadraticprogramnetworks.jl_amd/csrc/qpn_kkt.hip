@@ -471,6 +471,28 @@ __global__ __launch_bounds__(1024) void sweep_status_kernel(const int32_t *statu
 
 } // namespace
 
+// Are all Qd blocks of these records bitwise symmetric?  One pass when the records become resident (qpn_nodes_upload /
+// qpn_nodes_update); flag[0] is set to 1 by any pair (i, j), (j, i) whose bit patterns differ (-0.0 vs +0.0 counts as different).
+__global__ __launch_bounds__(256) void qd_asymmetry_kernel(long long total, int32_t n, const double *Qd, int32_t *flag)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long nn = (long long)n * n;
+    const long long b = idx / nn;
+    const int32_t e = (int32_t)(idx - b * nn), i = e % n, j = e / n;
+    if (i >= j) return;
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(Qd) + b * nn;
+    if (q[i + (long long)n * j] != q[j + (long long)n * i]) flag[0] = 1;
+}
+
+hipError_t qpn_launch_qd_asymmetry(int32_t batch, int32_t n, const double *Qd, int32_t *flag, hipStream_t stream)
+{
+    const long long total = (long long)batch * n * n;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(qd_asymmetry_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total, n, Qd, flag);
+    return hipGetLastError();
+}
+
 hipError_t qpn_launch_sweep_status(const int32_t *status, const double *resid, int32_t count, double *out,
                                    int32_t rank, int32_t world, const SweepBoxes &boxes, unsigned long long epoch,
                                    unsigned long long timeout_ticks, hipStream_t stream)

@@ -581,10 +581,10 @@ class Nodes:
         self.eng._chk(rc, "qpn_nodes_update")
 
     def info(self):
-        """dict(decline_state, declined, scheduled, sweeps) -- see qpn_nodes_info."""
+        """dict(decline_state, declined, scheduled, symmetric, sweeps) -- see qpn_nodes_info."""
         a = (C.c_int32 * 4)()
         self.eng._chk(self.eng.lib.qpn_nodes_info(self.eng.ctx, self.h, a), "qpn_nodes_info")
-        return dict(decline_state=a[0], declined=a[1], scheduled=bool(a[2]), sweeps=a[3])
+        return dict(decline_state=a[0], declined=a[1], scheduled=bool(a[2] & 1), symmetric=bool(a[2] & 2), sweeps=a[3])
 
     def set_schedule(self, period=16):
         self.eng._chk(self.eng.lib.qpn_nodes_set_schedule(self.eng.ctx, self.h, int(period)), "qpn_nodes_set_schedule")

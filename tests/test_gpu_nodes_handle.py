@@ -23,6 +23,22 @@ def _oracle(oracle, rec, w):
     return oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
 
 
+class _general_variants:
+    """Resident records whose Qd blocks are all symmetric take kernel variants of their own (QPN_OPT_SYM_ROUTE, n = m = 32):
+    equal to the general ones up to rounding, not bit for bit.  The tests below that compare the handle route with the
+    per-call route BIT FOR BIT (same kernels on the same data) switch the symmetric variants off for their duration."""
+    def __init__(self, engine):
+        self.engine = engine
+
+    def __enter__(self):
+        from qpn_amd import _lib
+        self.engine.set_option(_lib.OPT_SYM_ROUTE, 0)
+
+    def __exit__(self, *exc):
+        from qpn_amd import _lib
+        self.engine.set_option(_lib.OPT_SYM_ROUTE, 1)
+
+
 def _same(res, ref, n, tol=1e-9):
     assert np.array_equal(np.asarray(res["status"]), ref["status"])
     assert np.array_equal(np.asarray(res["active"]), ref["active"])
@@ -37,7 +53,8 @@ def test_handle_host_route_equals_per_call_route_and_oracle(engine, oracle, n, m
     rng = np.random.default_rng(1)
     for sweep in range(4):                       # new parameters every sweep, same records
         w = rng.standard_normal(8)
-        a = nodes.solve(w)
+        with _general_variants(engine):
+            a = nodes.solve(w)
         b = engine.solve_nodes(*abi, w)
         for k in ("z", "status", "resid", "pivots", "active"):
             assert np.array_equal(a[k], b[k]), k
@@ -53,7 +70,8 @@ def test_handle_with_per_node_parameters_and_primal_blocks_only(engine, oracle):
     nodes = engine.upload_nodes(*abi)
     W = np.random.default_rng(2).standard_normal((cnt, 8))
     x = np.zeros((cnt, 40))
-    out = nodes.solve(W, want=(), x_out=x)                         # only statuses and the primal blocks come back
+    with _general_variants(engine):
+        out = nodes.solve(W, want=(), x_out=x)                     # only statuses and the primal blocks come back
     assert out["z"] is None and np.all(out["status"] == 1)
     ref = engine.solve_nodes(*abi, W)
     assert np.array_equal(x[:, :n], ref["z"][:, :n]) and np.all(x[:, n:] == 0)
@@ -103,7 +121,8 @@ def test_handle_keeps_resolving_nodes_that_need_the_general_kernel(engine, oracl
     rng = np.random.default_rng(4)
     for sweep in range(4):
         w = rng.standard_normal(8)
-        a = nodes.solve(w)
+        with _general_variants(engine):
+            a = nodes.solve(w)
         b = engine.solve_nodes(*abi2, w)
         for k in ("z", "status", "pivots", "active"):
             assert np.array_equal(a[k], b[k]), k
@@ -210,4 +229,82 @@ def test_handle_fast_path_notices_swapped_or_dropped_output_buffers(engine, orac
     bad = dict(status=torch.zeros(cnt, dtype=torch.int64, device="cuda:0"))
     with pytest.raises(QpnError):
         nodes.solve(w, out=bad)
+    nodes.close()
+
+
+def _skewed(rec, eps=0.05):
+    """The same records with a skew part added to every Qd: x'Qx is unchanged (still strictly convex), Q is not symmetric."""
+    from qpn_amd.engine import colmajor
+    Q, R, qd, A, B, l, u = rec
+    K = np.random.default_rng(77).standard_normal(Q.shape) * eps
+    Q2 = Q + (K - K.transpose(0, 2, 1))
+    return (Q2, R, qd, A, B, l, u), (colmajor(Q2), colmajor(R), qd, colmajor(A), colmajor(B), l, u)
+
+
+def test_symmetric_records_take_the_symmetric_variants(engine, oracle):
+    """n = m = 32 with every Qd bitwise symmetric: the handle knows (info), the sweep runs avi_solve_schur<.., SYM> (the lower-left
+    tile of H is never formed, S(1,0) is the transpose of S(0,1)).  Same statuses, masks and pivot counts as the general
+    variant, primals equal to rounding; both within the bar against the oracle.  Also above one resident round (the
+    staggered instantiation)."""
+    from qpn_amd import _lib
+    n, m = 32, 32
+    for seed, cnt in ((31, 200), (32, 4500)):
+        rec, abi = _records(seed, cnt, n, m)
+        nodes = engine.upload_nodes(*abi)
+        assert nodes.info()["symmetric"]
+        rng = np.random.default_rng(seed)
+        for sweep in range(3):
+            w = rng.standard_normal(8)
+            a = {k: np.array(v) for k, v in nodes.solve(w).items()}
+            with _general_variants(engine):
+                g = {k: np.array(v) for k, v in nodes.solve(w).items()}
+            for k in ("status", "active", "pivots"):
+                assert np.array_equal(a[k], g[k]), k
+            assert np.max(np.abs(a["z"] - g["z"])) <= 1e-11 * max(1.0, np.max(np.abs(g["z"])))
+            assert float(a["resid"].max()) <= 1e-8
+            if cnt <= 200 or sweep == 0:
+                sub = slice(0, 200)
+                ref = _oracle(oracle, tuple(x[sub] for x in rec), w)
+                _same({k: a[k][sub] for k in ("status", "active", "z")}, ref, n)
+        nodes.close()
+    assert engine.set_option(_lib.OPT_SYM_ROUTE, 1) is None
+
+
+def test_asymmetric_records_take_the_general_variants(engine, oracle):
+    """One skew part in the Qd blocks and the handle must not use the symmetric variants: bit for bit the per-call route's
+    answer, and the oracle's within the bar (the AVI is still strictly monotone: the skew part does not change x'Qx)."""
+    n, m, cnt = 32, 32, 150
+    rec, _ = _records(41, cnt, n, m)
+    rec2, abi2 = _skewed(rec)
+    nodes = engine.upload_nodes(*abi2)
+    assert not nodes.info()["symmetric"]
+    w = np.random.default_rng(5).standard_normal(8)
+    a = nodes.solve(w)
+    b = engine.solve_nodes(*abi2, w)
+    for k in ("z", "status", "resid", "pivots", "active"):
+        assert np.array_equal(a[k], b[k]), k
+    _same(a, _oracle(oracle, rec2, w), n)
+    # a single asymmetric entry pair in ONE node out of many is enough
+    rec3, abi3 = _records(42, cnt, n, m)
+    Q3 = rec3[0].copy(); Q3[cnt - 1, 30, 31] += 1e-13
+    from qpn_amd.engine import colmajor
+    nodes3 = engine.upload_nodes(colmajor(Q3), *abi3[1:])
+    assert not nodes3.info()["symmetric"]
+    nodes.close(); nodes3.close()
+
+
+def test_update_of_qd_settles_the_symmetry_again(engine, oracle):
+    n, m, cnt = 32, 32, 64
+    rec, abi = _records(43, cnt, n, m)
+    rec2, abi2 = _skewed(rec)
+    nodes = engine.upload_nodes(*abi)
+    w = P.shared_params()
+    assert nodes.info()["symmetric"]
+    _same(nodes.solve(w), _oracle(oracle, rec, w), n)
+    nodes.update("Qd", abi2[0])                        # (column-major, as uploaded)
+    assert not nodes.info()["symmetric"]
+    _same(nodes.solve(w), _oracle(oracle, rec2, w), n)
+    nodes.update("Qd", abi[0])
+    assert nodes.info()["symmetric"]
+    _same(nodes.solve(w), _oracle(oracle, rec, w), n)
     nodes.close()
