@@ -85,6 +85,14 @@ __device__ __forceinline__ void wave_sync()
 // on the original blocks, and 1e-15 is far inside the 1e-9 parity bar.
 // max(a, |b|) in ONE instruction (fmax(a, fabs(b)) costs three: the compiler canonicalises both operands first; the
 // callers feed no NaNs that matter: a NaN entry fails the pivot test and the item goes to the general kernel)
+// v[l] + v[l ^ 32] in every lane (gfx950: v_permlane32_swap exchanges the upper half of one register with the lower half of another)
+__device__ __forceinline__ double sum_halves(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
 __device__ __forceinline__ double min_abs_nc(double a, double b)      // min(a, |b|)
 {
     double r;
@@ -438,6 +446,22 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         if constexpr (!HALF16 && !(SYM && (J) == 0))                                                \
             TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));     /* (16: rows 16.. are padding, U' = 0 there) */ \
     }
+#define M_USOLVE                                                                                    \
+        if (l < 32) {                                                                           \
+            const int lr_ = l;                                                                  \
+            const d4 ur = *reinterpret_cast<const d4 *>(sU + lr_ * 4);                          \
+            const double y0 = ur[0] * rd[0];                                                    \
+            const double y1 = fma(-y0, pm[0][1], ur[1]) * rd[1];                                \
+            const double y2 = fma(-y1, pm[1][2], fma(-y0, pm[0][2], ur[2])) * rd[2];            \
+            const double y3 = fma(-y2, pm[2][3], fma(-y1, pm[1][3], fma(-y0, pm[0][3], ur[3]))) * rd[3]; \
+            d4 up;                                                                              \
+            up[3] = y3;                                                                         \
+            up[2] = fma(-up[3], pm[3][2], y2);                                                  \
+            up[1] = fma(-up[3], pm[3][1], fma(-up[2], pm[2][1], y1));                           \
+            up[0] = fma(-up[3], pm[3][0], fma(-up[2], pm[2][0], fma(-up[1], pm[1][0], y0)));    \
+            kx -= fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));                   \
+            *reinterpret_cast<d4 *>(sU + lr_ * 4) = up;                                         \
+        }
 #define M_STEP(KB, JP, GP)                                                                          \
     if (!fail && 4 * (KB) < n) {       /* a block of padded rows is an identity pivot: nothing moves */ \
         constexpr int p0 = 4 * (KB);                                                                \
@@ -472,25 +496,14 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
                 _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]); \
             }                                                                                       \
         }                                                                                           \
+        /* U' = U P^-1, row l of the panel: solve x L U = u (pivot rows hold P - I, so theirs   \
+           is I - P^-1), and the extra column kx_l -= U'[l] . x_piv */                          \
+        /* (tried: the solve on every lane and ahead of the branch on the pivot test, so that it interleaves with the \
+           factorisation -- 0.3 % slower) */                                                        \
         if (!ubool(okp)) { fail = true; }                                                           \
         else {                                                                                      \
             if constexpr (!NODES) { if (l == 0) sMinPiv[0] = fmin(sMinPiv[0], minpiv); }            \
-            /* U' = U P^-1, row l of the panel: solve x L U = u (pivot rows hold P - I, so theirs   \
-               is I - P^-1), and the extra column kx_l -= U'[l] . x_piv */                          \
-            if (l < 32) {                                                                           \
-                const d4 ur = *reinterpret_cast<const d4 *>(sU + l * 4);                            \
-                const double y0 = ur[0] * rd[0];                                                    \
-                const double y1 = fma(-y0, pm[0][1], ur[1]) * rd[1];                                \
-                const double y2 = fma(-y1, pm[1][2], fma(-y0, pm[0][2], ur[2])) * rd[2];            \
-                const double y3 = fma(-y2, pm[2][3], fma(-y1, pm[1][3], fma(-y0, pm[0][3], ur[3]))) * rd[3]; \
-                d4 up;                                                                              \
-                up[3] = y3;                                                                         \
-                up[2] = fma(-up[3], pm[3][2], y2);                                                  \
-                up[1] = fma(-up[3], pm[3][1], fma(-up[2], pm[2][1], y1));                           \
-                up[0] = fma(-up[3], pm[3][0], fma(-up[2], pm[2][0], fma(-up[1], pm[1][0], y0)));    \
-                kx -= fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));                   \
-                *reinterpret_cast<d4 *>(sU + l * 4) = up;                                           \
-            }                                                                                       \
+            M_USOLVE                                                                                \
             wave_sync();                                                                            \
             const double au0 = sU[(0 + lc) * 4 + lq], au1 = sU[(16 + lc) * 4 + lq];    /* T -= U' V: NEG on A */ \
             if ((JP) <= 0) M_COLTILE(0, JP, GP)                                                     \
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     M_STEP(0, 0, 0) M_STEP(1, 0, 1) M_STEP(2, 0, 2) M_STEP(3, 0, 3)
     M_STEP(4, 1, 0) M_STEP(5, 1, 1) M_STEP(6, 1, 2) M_STEP(7, 1, 3)
 #undef M_STEP
+#undef M_USOLVE
 #undef M_COLTILE
 #undef M_GATHER
     if (fail) { decline(); return; }
@@ -561,20 +575,55 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     if constexpr (SYM) {
         // S(1,0) = S(0,1)': register kb of a tile in the accumulator layout IS the A operand of its transpose's k-block kb
         // (element (i = lc, k = lq) = X[4 kb + lq][lc]); B = rows 4 kb .. 4 kb + 3 of the identity.  Exact (x 1, + 0).
+#ifdef QPN_SYM_MFMA_TRANSPOSE
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) SB(1, 0) = MFMA(SB(0, 1)[kb], (lc == 4 * kb + lq) ? 1.0 : 0.0, SB(1, 0));
+#else
+        // through the idle Stage A block of sbuf (128 doubles), eight rows per round; row r of a round sits at
+        // r * 16 + ((c + 4 (r >> 1)) & 15): the writes fill four whole rows, the 32 reading lanes (lc >> 3 == round) hit 32 banks
+        const int rr_ = lc & 7, rot_ = 4 * (rr_ >> 1);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int r = 4 * gg + lq;
+                sbuf[r * 16 + ((lc + 4 * (r >> 1)) & 15)] = SB(0, 1)[2 * hh + gg];
+            }
+            wave_sync();
+            if ((lc >> 3) == hh) {
+#pragma unroll
+                for (int g2 = 0; g2 < 4; ++g2) SB(1, 0)[g2] = sbuf[rr_ * 16 + ((4 * g2 + lq + rot_) & 15)];
+            }
+            wave_sync();
+        }
+#endif
     }
     wave_sync();
     // c_k = b_k - sum_j A[k][j] h_j, lane k <-> pair k (k < m)
     double xb = 0.0;
     {
         const bool lowr = l < m;
+        if constexpr (FULL32) {
+            // both halves of the wavefront work on the 32 rows: lane l and lane l + 32 take 16 columns each of row l & 31
+            const int ls = l & 31, j0 = (l >> 5) << 4;
+            double acc = 0.0;
+            if constexpr (NODES) acc = lowr ? SQ(n + ls) : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
+            double acc2 = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < 16; j += 2) {
+                acc = fma(-sA[(j0 + j) * SAS + ls], sz[j0 + j], acc);
+                acc2 = fma(-sA[(j0 + j + 1) * SAS + ls], sz[j0 + j + 1], acc2);
+            }
+            const double both = sum_halves(acc + acc2);        // (every lane takes part: not inside the select)
+            xb = lowr ? both : 0.0;
+        } else {
         const int ls = lowr ? l : 0;
         double acc;
         if constexpr (NODES) acc = lowr ? SQ(n + ls) : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
 #pragma unroll 8
         for (int j = 0; j < 32; ++j) acc = fma(-sA[j * SAS + ls], sz[j], acc);          // zero columns beyond n
         xb = lowr ? acc : 0.0;
+        }
     }
     STAMP(6);   // crash on the matrix cores
 
@@ -1054,8 +1103,11 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
         int j = 0;
         if constexpr (FULL32) {
             // the x columns: ONE chain for every lane -- its operands (a row of Qd or a row of Ad) were fetched into mq32 by role
+            // (two accumulators: the chain is latency-bound, not issue-bound)
+            double rq2 = 0.0;
 #pragma unroll
-            for (int jj = 0; jj < 32; ++jj) rq = fma(mq32[jj], sz[jj], rq);
+            for (int jj = 0; jj < 32; jj += 2) { rq = fma(mq32[jj], sz[jj], rq); rq2 = fma(mq32[jj + 1], sz[jj + 1], rq2); }
+            rq += rq2;
             ra = rq;
             j = 32;
         }
@@ -1075,8 +1127,15 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             rq = fma(qcol[(size_t)j * nn], zj, rq);
             ra = fma(sA[j * SAS + aoff], zj, ra);
         }
+        if constexpr (FULL32) {
+            double rl2 = 0.0;                                                       // columns of lambda: -A' (x rows), two chains
+#pragma unroll 8
+            for (int k = 0; k < 32; k += 2) { rq = fma(-sA[roff + k], sz[32 + k], rq); rl2 = fma(-sA[roff + k + 1], sz[32 + k + 1], rl2); }
+            rq += rl2;
+        } else {
 #pragma unroll 8
         for (int k = 0; k < nm; ++k) rq = fma(-sA[roff + k], sz[nn + k], rq);      // columns of lambda: -A' (x rows)
+        }
         rk = isx ? rq : ra;
     } else {
         rk = act ? ae.q[vo + l] : 0.0;
