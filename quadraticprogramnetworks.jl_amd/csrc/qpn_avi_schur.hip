@@ -427,6 +427,12 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     // (kept in an idle LDS slot, not in a register pair across the eight steps)
     double *const sMinPiv = sbuf + 191;
     if constexpr (!NODES) { if (l == 0) sMinPiv[0] = QINF; }
+    // NEGF (node path): the factorisation carries the opposite sign throughout -- nrd = -1 / u_ss, the multipliers kept in pm are
+    // -l_is, the panel solve yields -U' -- so that every step is a plain fma and no operand is negated by an instruction of
+    // its own (the compiler materialised three negated copies per step); bit for bit the same numbers.  The explicit-M
+    // instantiations keep the plain signs (there the sign-flipped form costs registers: the ragged one spills).
+    constexpr bool NEGF = NODES;
+#define FMS(a_, b_, c_) (NEGF ? fma((a_), (b_), (c_)) : fma(-(a_), (b_), (c_)))
 #define M_GATHER(I, JP, GP)                                                                         \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
         const int rr = 16 * (I) + 4 * g + lq;                                                       \
@@ -442,24 +448,28 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
            of the accumulator tile TL(IP, J) (else the compiler moves the whole tile out and back) */ \
         double vraw = TL(IP, J)[GP];                                                                \
         asm volatile("" : "+v"(vraw));      /* opaque: the copy itself is the compiler's (hazard-aware) */ \
-        TL(0, J) = MFMA_NEGA(au0, vraw, TL(0, J));                                                  \
+        TL(0, J) = NEGF ? MFMA(au0, vraw, TL(0, J)) : MFMA_NEGA(au0, vraw, TL(0, J));   /* T -= U' V */ \
         if constexpr (!HALF16 && !(SYM && (J) == 0))                                                \
-            TL(1, J) = MFMA_NEGA(au1, vraw, TL(1, J));     /* (16: rows 16.. are padding, U' = 0 there) */ \
+            TL(1, J) = NEGF ? MFMA(au1, vraw, TL(1, J)) : MFMA_NEGA(au1, vraw, TL(1, J));     /* (16: rows 16.. are padding) */ \
     }
 #define M_USOLVE                                                                                    \
         if (l < 32) {                                                                           \
             const int lr_ = l;                                                                  \
             const d4 ur = *reinterpret_cast<const d4 *>(sU + lr_ * 4);                          \
-            const double y0 = ur[0] * rd[0];                                                    \
-            const double y1 = fma(-y0, pm[0][1], ur[1]) * rd[1];                                \
-            const double y2 = fma(-y1, pm[1][2], fma(-y0, pm[0][2], ur[2])) * rd[2];            \
-            const double y3 = fma(-y2, pm[2][3], fma(-y1, pm[1][3], fma(-y0, pm[0][3], ur[3]))) * rd[3]; \
+            /* (NEGF: n_k = -y_k, up = -U') */                                                  \
+            const double n0 = ur[0] * nrd[0];                                                   \
+            const double n1 = FMS(n0, pm[0][1], ur[1]) * nrd[1];                                \
+            const double n2 = FMS(n1, pm[1][2], FMS(n0, pm[0][2], ur[2])) * nrd[2];             \
+            const double n3 = FMS(n2, pm[2][3], FMS(n1, pm[1][3], FMS(n0, pm[0][3], ur[3]))) * nrd[3]; \
             d4 up;                                                                              \
-            up[3] = y3;                                                                         \
-            up[2] = fma(-up[3], pm[3][2], y2);                                                  \
-            up[1] = fma(-up[3], pm[3][1], fma(-up[2], pm[2][1], y1));                           \
-            up[0] = fma(-up[3], pm[3][0], fma(-up[2], pm[2][0], fma(-up[1], pm[1][0], y0)));    \
-            kx -= fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));                   \
+            up[3] = n3;                                                                         \
+            up[2] = FMS(up[3], pm[3][2], n2);                                                   \
+            up[1] = FMS(up[3], pm[3][1], FMS(up[2], pm[2][1], n1));                             \
+            up[0] = FMS(up[3], pm[3][0], FMS(up[2], pm[2][0], FMS(up[1], pm[1][0], n0)));       \
+            {                                                                                   \
+                const double t_ = fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));   \
+                kx = NEGF ? kx + t_ : kx - t_;                                                  \
+            }                                                                                   \
             *reinterpret_cast<d4 *>(sU + lr_ * 4) = up;                                         \
         }
 #define M_STEP(KB, JP, GP)                                                                          \
@@ -481,19 +491,21 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             const d4 row = *reinterpret_cast<const d4 *>(sP + i * 4);                               \
             pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];             \
         }                                                                                           \
+        /* (tried twice: these four entries of the extra column through LDS with the pivot block instead of eight v_readlane: \
+           0.8 - 0.9 % slower) */                                                                   \
         const double x0 = readlane_f64(kx, p0), x1 = readlane_f64(kx, p0 + 1);                      \
         const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);                  \
         bool okp = true;                                                                            \
         double minpiv = QINF;                                                                       \
-        double rd[4];                                   /* reciprocals of the pivots u_ss */        \
+        double nrd[4];                                  /* 1 / u_ss (NEGF: -1 / u_ss) */            \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
             okp = okp && fabs(pm[s][s]) >= diag_thr;                                                \
             if constexpr (!NODES) minpiv = min_abs_nc(minpiv, pm[s][s]);                            \
-            rd[s] = rcp64(pm[s][s]);                                                                \
+            nrd[s] = NEGF ? rcp64(-pm[s][s]) : rcp64(pm[s][s]);                                     \
             _Pragma("unroll") for (int i = s + 1; i < 4; ++i) {                                     \
-                const double f = pm[i][s] * rd[s];      /* l_is, kept in place */                   \
+                const double f = pm[i][s] * nrd[s];     /* l_is (NEGF: -l_is), kept in place */     \
                 pm[i][s] = f;                                                                       \
-                _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]); \
+                _Pragma("unroll") for (int j = s + 1; j < 4; ++j) pm[i][j] = FMS(f, pm[s][j], pm[i][j]); \
             }                                                                                       \
         }                                                                                           \
         /* U' = U P^-1, row l of the panel: solve x L U = u (pivot rows hold P - I, so theirs   \
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             if constexpr (!NODES) { if (l == 0) sMinPiv[0] = fmin(sMinPiv[0], minpiv); }            \
             M_USOLVE                                                                                \
             wave_sync();                                                                            \
-            const double au0 = sU[(0 + lc) * 4 + lq], au1 = sU[(16 + lc) * 4 + lq];    /* T -= U' V: NEG on A */ \
+            const double au0 = sU[(0 + lc) * 4 + lq], au1 = sU[(16 + lc) * 4 + lq];    /* U' (NEGF: -U') */    \
             if ((JP) <= 0) M_COLTILE(0, JP, GP)                                                     \
             if constexpr (!HALF16) { if ((JP) <= 1) M_COLTILE(1, JP, GP) }     /* (16: columns 16.. of H and of C are zero) */ \
             M_COLTILE(2, JP, GP)                                                                    \
@@ -517,6 +529,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     M_STEP(4, 1, 0) M_STEP(5, 1, 1) M_STEP(6, 1, 2) M_STEP(7, 1, 3)
 #undef M_STEP
 #undef M_USOLVE
+#undef FMS
 #undef M_COLTILE
 #undef M_GATHER
     if (fail) { decline(); return; }
@@ -1128,10 +1141,16 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             ra = fma(sA[j * SAS + aoff], zj, ra);
         }
         if constexpr (FULL32) {
-            double rl2 = 0.0;                                                       // columns of lambda: -A' (x rows), two chains
+            const int rof2 = (l & 31) * SAS + ((l >> 5) << 4);
+            const double *const szl = sz + 32 + ((l >> 5) << 4);
+            double rl1 = 0.0, rl2 = 0.0;                                            // columns of lambda: -A' (x rows), two chains
 #pragma unroll 8
-            for (int k = 0; k < 32; k += 2) { rq = fma(-sA[roff + k], sz[32 + k], rq); rl2 = fma(-sA[roff + k + 1], sz[32 + k + 1], rl2); }
-            rq += rl2;
+            for (int k = 0; k < 16; k += 2) { rl1 = fma(-sA[rof2 + k], szl[k], rl1); rl2 = fma(-sA[rof2 + k + 1], szl[k + 1], rl2); }
+#ifdef V1
+            rq += rl1 + rl2;
+#else
+            rq += sum_halves(rl1 + rl2);
+#endif
         } else {
 #pragma unroll 8
         for (int k = 0; k < nm; ++k) rq = fma(-sA[roff + k], sz[nn + k], rq);      // columns of lambda: -A' (x rows)
