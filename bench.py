@@ -370,12 +370,14 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
                    "sharding": f"node ranges over {world} GPU(s)", "scaling": scaling, "exchange": exchange,
                    "w_ring": 1 if args.fixed_w else RING, "schedule": "longest-first/16" if use_sched else "natural",
                    "nodes_needing_general_kernel": (info["declined"] if info and info["decline_state"] >= 2 else None),
+                   "qd_blocks_bitwise_symmetric": (bool(info.get("symmetric")) if info else None),
                    "schedule_resorts_in_timed_region": resorts,
                    "max_resid": max_resid, "solved": solved},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "frac_definition": "value / n_gpus x algorithmic_bytes_per_solve / peak (the driver's clock over all K steps)",
-                     "kernel": "avi_solve_schur<nodes>" if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
+                     "kernel": ("avi_solve_schur<nodes" + (", symmetric Qd>" if info and info.get("symmetric") and n == 32 and m == 32 else ">"))
+                               if not args.unfused else "assemble + avi_solve", "kernel_ms": kern_ms,
                      "frac_from_kernel_events": achieved_ev / HBM_PEAK_GBS,
                      "kernel_ms_all": kern_ms_all, "launches_averaged": max(steps - 1, 1),
                      "algorithmic_bytes_per_solve": per_solve, "solves_per_launch": cnt} | committed_counters(),
