@@ -55,6 +55,8 @@ def parse_args():
                     help="4: 10 000 nodes x 32 variables (BASELINE configs[3], the metric's config); 5: 512 nodes x 256 variables")
     ap.add_argument("--big-route", type=int, choices=(0, 1), default=1,
                     help="--config 5, A/B: 1 = blocked crash straight from the records (default), 0 = round 2's route over an assembled M")
+    ap.add_argument("--sym-route", type=int, choices=(0, 1), default=1,
+                    help="A/B: 1 (default) = resident records whose Qd blocks are all symmetric take the kernel variants that use it, 0 = never")
     ap.add_argument("--nodes", type=int, default=None, help="nodes in the whole net (strong) / per GPU (weak)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: shard ONE net (strong, BASELINE configs[3]) or give every GPU its own (weak)")
@@ -119,6 +121,8 @@ def main():
 
     import qpn_amd
     eng = qpn_amd.Engine(local_rank)
+    from qpn_amd import _lib as _qlib
+    eng.set_option(_qlib.OPT_SYM_ROUTE, args.sym_route)
     env = dict(eng=eng, dist=dist, use_dist=use_dist, world=world, rank=rank, dev=torch.device(f"cuda:{local_rank}"),
                np=np, torch=torch)
     if args.config == 5:
@@ -573,6 +577,7 @@ def run_config5(env, args):
     ring = t(ring_host)
     from qpn_amd import _lib as qlib
     eng.set_option(qlib.OPT_BIG_ROUTE, args.big_route)
+    eng.set_option(qlib.OPT_SYM_ROUTE, args.sym_route)
     handle = eng.upload_nodes(*drec)
     steps = min(args.steps, 50)
     warmup = min(args.warmup, 5)

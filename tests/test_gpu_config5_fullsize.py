@@ -60,9 +60,21 @@ def test_config5_full_batch_solved_and_certified(engine, full5):
 def test_config5_handle_route_and_shards(engine, full5):
     import torch
     host, dev, res, _ = full5
+    from qpn_amd import _lib
     nodes = engine.upload_nodes(*dev[:-1])
-    out = nodes.solve(dev[-1])
-    torch.cuda.synchronize()
+    assert nodes.info()["symmetric"]
+    # resident records with symmetric Qd blocks form only the upper triangle of S = A H^-1 A' (QPN_OPT_SYM_ROUTE): equal to the
+    # per-call route to rounding; with the option off the handle runs the per-call route's kernels -- bit for bit its answer
+    sym = {k: v.cpu().numpy() for k, v in nodes.solve(dev[-1]).items()}
+    for k in ("status", "active", "pivots"):
+        assert np.array_equal(sym[k], res[k]), k
+    assert np.max(np.abs(sym["z"] - res["z"])) <= 1e-10 * max(1.0, np.max(np.abs(res["z"])))
+    engine.set_option(_lib.OPT_SYM_ROUTE, 0)
+    try:
+        out = nodes.solve(dev[-1])
+        torch.cuda.synchronize()
+    finally:
+        engine.set_option(_lib.OPT_SYM_ROUTE, 1)
     for k in ("z", "status", "active", "pivots"):
         assert np.array_equal(out[k].cpu().numpy(), res[k]), k
     # row A8 at this size: every node's verify_solution accepts its AVI solution, duals = the AVI's multipliers
