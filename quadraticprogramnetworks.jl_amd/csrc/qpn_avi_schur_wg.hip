@@ -834,6 +834,8 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
         const int gk = k >= n;
         double rk = sQ[k];
         // row k of [[Qd, -Ad'],[Ad, 0]] times z, columns ascending (finite blocks: a zero z_j contributes exactly nothing)
+        // (tried: two lanes per row -- the workgroup has twice as many threads as the item has rows --, all of a lane's entries of
+        //  Qd requested at once, two accumulators, v_permlane32_swap to add the halves: 1 % slower at 4 000 nodes and at 256)
         if (!gk) {
             int j = 0;
             for (; j + 8 <= n; j += 8) {
@@ -899,6 +901,15 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
 #ifdef QPN_STAMPS
     if (tid == 0 && a.stamps) {
         for (int k = 0; k < 8; ++k) a.stamps[(size_t)b * 8 + k] = stamp_acc[k];
+    }
+    // where the waves of this workgroup ran (tools/wg_simd_probe.py): SIMD of wave v in bits 48 + 2 v of slot 0, the CU's id in bits 56..
+    __syncthreads();
+    if (l == 0 && a.stamps) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned long long bits = (unsigned long long)((hw >> 4) & 3u) << (48 + 2 * v);
+        if (v == 0) bits |= (unsigned long long)((hw >> 8) & 0xFu) << 56;
+        atomicOr(&a.stamps[(size_t)b * 8 + 0], bits);
     }
 #endif
 }

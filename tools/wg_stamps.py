@@ -35,7 +35,7 @@ for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
         for _ in range(2):
             res = eng.solve_nodes(*args)
         torch.cuda.synchronize()
-        sall = st.cpu().numpy().astype(np.float64)
+        sall = (st.cpu().numpy().astype(np.uint64) & np.uint64((1 << 48) - 1)).astype(np.float64)      # (bits 48.. of slot 0: SIMD ids, tools/wg_simd_probe.py)
         lp = float(res["pivots"].double().mean()) - n
         steps = n // 4 + (n % 4 > 0)
         if n > 64:      # csrc/qpn_avi_schur_wg2.hip: the LEADER's stamps (C wave 0), then H wave 0's
