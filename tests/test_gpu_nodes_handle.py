@@ -131,6 +131,15 @@ def test_handle_keeps_resolving_nodes_that_need_the_general_kernel(engine, oracl
         assert np.max(np.abs(a["z"] - ref["z"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["z"])))
     info = nodes.info()
     assert info["decline_state"] == 3 and info["declined"] >= 2
+    # the same records through the symmetric variants (all Qd blocks are symmetric): the declined nodes take the general kernel
+    # as before, everything matches the oracle
+    assert info["symmetric"]
+    w = rng.standard_normal(8)
+    a = nodes.solve(w)
+    ref = _oracle(oracle, rec2, w)
+    assert np.array_equal(a["status"], ref["status"]) and np.array_equal(a["active"], ref["active"])
+    assert np.max(np.abs(a["z"] - ref["z"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["z"])))
+    assert nodes.info()["declined"] >= 2
 
 
 def test_handle_update_replaces_a_field_and_forgets_what_it_knew(engine, oracle):
