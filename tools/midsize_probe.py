@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Developer aid: node-solve rate across node sizes (where the kernel families hand over)."""
+"""Developer aid: node-solve rate across node sizes (where the kernel families hand over), per-call route (records passed every call,
+outputs allocated per call, wall clock).  n = m = 64 twice: 2 000 nodes are 1.95 rounds of the 1 024 workgroups resident at once (the
+second round nearly empty at the end), 4 096 are four full rounds."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -9,7 +11,7 @@ import problems as P
 from qpn_amd.engine import colmajor
 eng = qpn_amd.Engine(0)
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
-for n, m, cnt in [(16, 16, 10000), (32, 32, 10000), (33, 33, 4000), (40, 40, 4000), (48, 48, 4000), (64, 64, 2000), (96, 96, 1000), (128, 128, 1000), (256, 256, 512)]:
+for n, m, cnt in [(16, 16, 10000), (32, 32, 10000), (33, 33, 4000), (40, 40, 4000), (48, 48, 4000), (64, 64, 2000), (64, 64, 4096), (96, 96, 1000), (128, 128, 1000), (256, 256, 512)]:
     Q, R_, qd, A, B, l, u = P.synth_nodes(5000 + n, cnt, n, m)
     args = [t(colmajor(Q)), t(colmajor(R_)), t(qd), t(colmajor(A)), t(colmajor(B)), t(l), t(u), t(P.shared_params())]
     out = None
