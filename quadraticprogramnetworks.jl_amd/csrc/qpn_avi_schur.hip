@@ -1159,6 +1159,24 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     } else {
         rk = act ? ae.q[vo + l] : 0.0;
         int j = 0;
+        if constexpr (FULL32) {
+            // N = 64: two batches of 32 columns, each requested at once (the W tiles are dead: their registers hold the batch),
+            // two chains per batch
+            double rk2 = 0.0;
+#pragma unroll 1
+            for (; j < 64; j += 32) {
+                double mv[32];
+#pragma unroll
+                for (int q = 0; q < 32; ++q) mv[q] = Mge[(size_t)(j + q) * 64 + l];
+#pragma unroll
+                for (int q = 0; q < 32; q += 2) {
+                    const double za = sz[j + q], zb = sz[j + q + 1];
+                    rk = (za != 0.0) ? fma(mv[q], za, rk) : rk;
+                    rk2 = (zb != 0.0) ? fma(mv[q + 1], zb, rk2) : rk2;
+                }
+            }
+            rk += rk2;
+        }
 #pragma unroll 1
         for (; j + 8 <= N; j += 8) {
             double mv[8];
