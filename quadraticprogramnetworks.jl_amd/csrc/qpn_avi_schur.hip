@@ -616,26 +616,21 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
     double xb = 0.0;
     {
         const bool lowr = l < m;
-        if constexpr (FULL32) {
-            // both halves of the wavefront work on the 32 rows: lane l and lane l + 32 take 16 columns each of row l & 31
-            const int ls = l & 31, j0 = (l >> 5) << 4;
+        {
+            // both halves of the wavefront work on the (up to) 32 rows: lane l and lane l + 32 take half of the columns each of row
+            // l & 31 (columns beyond n are zero in the buffer; n = m = 16: 16 columns in all)
+            constexpr int HC = HALF16 ? 8 : 16;
+            const int ls = l & 31, j0 = (l >> 5) * HC;
             double acc = 0.0;
             if constexpr (NODES) acc = lowr ? SQ(n + ls) : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
             double acc2 = 0.0;
 #pragma unroll 8
-            for (int j = 0; j < 16; j += 2) {
+            for (int j = 0; j < HC; j += 2) {
                 acc = fma(-sA[(j0 + j) * SAS + ls], sz[j0 + j], acc);
                 acc2 = fma(-sA[(j0 + j + 1) * SAS + ls], sz[j0 + j + 1], acc2);
             }
             const double both = sum_halves(acc + acc2);        // (every lane takes part: not inside the select)
             xb = lowr ? both : 0.0;
-        } else {
-        const int ls = lowr ? l : 0;
-        double acc;
-        if constexpr (NODES) acc = lowr ? SQ(n + ls) : 0.0; else acc = lowr ? qelem(n + ls) : 0.0;
-#pragma unroll 8
-        for (int j = 0; j < 32; ++j) acc = fma(-sA[j * SAS + ls], sz[j], acc);          // zero columns beyond n
-        xb = lowr ? acc : 0.0;
         }
     }
     STAMP(6);   // crash on the matrix cores
