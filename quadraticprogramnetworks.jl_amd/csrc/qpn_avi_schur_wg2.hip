@@ -1002,26 +1002,41 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
     int32_t *const pe_ = kp->pivots;
     int bad = 0;
     double nres = 0.0;
-    if (tid < N) {
-        const int k = tid;
-        const int gk = k >= n;
-        double rk = sQ[k];
-        // row k of [[Qd, -Ad'],[Ad, 0]] times z, columns ascending (finite blocks: a zero z_j contributes exactly nothing)
-        if (!gk) {
-            int j = 0;
-            for (; j + 8 <= n; j += 8) {
-                double mv[8];
+    // Four lanes per row: the workgroup has 128 NR threads for at most 32 NR rows, and with one workgroup per CU nothing else
+    // hides a 2 x 128-term chain and its loads.  Lanes lc, lc + 16, lc + 32, lc + 48 of wave v take a quarter each of row
+    // 16 v + lc of [[Qd, -Ad'],[Ad, 0]] z; all of a lane's entries of Qd (at most 32) are requested at once; `xsum_rows` adds the
+    // quarters.  Finite blocks: a zero z_j contributes exactly nothing.
+    const int k = 16 * v + lc;
+    const bool rowok = k < N;
+    const int gk = k >= n;
+    double part;
+    {
+        const int jq = (n + 3) >> 2, jlo = lq * jq, jcnt = jlo < n ? (n - jlo < jq ? n - jlo : jq) : 0;      // this quarter's columns of x
+        double pa = 0.0, pb = 0.0;
+        if (rowok && !gk) {
+            double mv[32];
+            const int jb = jcnt > 0 ? jlo : 0;
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = Qe_[(size_t)(j + q8) * n + k];
+            for (int q = 0; q < 32; ++q) mv[q] = Qe_[(size_t)(q < jcnt ? jlo + q : jb) * n + k];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) rk = fma(mv[q8], sz[j + q8], rk);
+            for (int q = 0; q < 32; q += 2) {
+                pa = (q < jcnt) ? fma(mv[q], sz[jb + q], pa) : pa;
+                pb = (q + 1 < jcnt) ? fma(mv[q + 1], sz[jb + q + 1], pb) : pb;
             }
-            for (; j < n; ++j) rk = fma(Qe_[(size_t)j * n + k], sz[j], rk);
-            for (int i = 0; i < m; ++i) rk = fma(-sAd[k * LDA + i], sz[n + i], rk);
-        } else {
-            const int r = k - n;
-            for (int j = 0; j < n; ++j) rk = fma(sAd[j * LDA + r], sz[j], rk);
+            const int iq = (m + 3) >> 2, ilo = lq * iq, ihi = ilo + iq < m ? ilo + iq : m;                  // ... and of lambda: -Ad'
+            int i = ilo;
+            for (; i + 2 <= ihi; i += 2) { pa = fma(-sAd[k * LDA + i], sz[n + i], pa); pb = fma(-sAd[k * LDA + i + 1], sz[n + i + 1], pb); }
+            if (i < ihi) pa = fma(-sAd[k * LDA + i], sz[n + i], pa);
+        } else if (rowok) {
+            const int r = k - n, jhi = jlo + jcnt;
+            int j = jlo;
+            for (; j + 2 <= jhi; j += 2) { pa = fma(sAd[j * LDA + r], sz[j], pa); pb = fma(sAd[(j + 1) * LDA + r], sz[j + 1], pb); }
+            if (j < jhi) pa = fma(sAd[j * LDA + r], sz[j], pa);
         }
+        part = xsum_rows(pa + pb);                          // (every lane takes part)
+    }
+    if (rowok && lq == 0) {
+        const double rk = sQ[k] + part;
         const double zk = sz[k];
         const double lk = gk ? le_[(size_t)b * m + (k - n)] : -QINF, uk = gk ? ue_[(size_t)b * m + (k - n)] : QINF;
         const double p = gk ? rk : zk, d = gk ? zk : rk;
