@@ -472,10 +472,6 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_sprod(AviBatchArgs a, Schu
     }
     const int Is = wave;
     const bool sown = Is < mct;
-    // every Qd of the records symmetric (known for resident records, qpn_nodes_upload): S = A H^-1 A' is symmetric, a wave
-    // forms only the tiles on and right of the diagonal of its block row and stores each of them twice (136 of 256 tile
-    // products at m = 256)
-    const bool sym = a.nd.sym != 0;
     const int nkc = (nrt + 3) / 4;                  // 64-row blocks of W
     const int ncc = (mct + 1 + JC - 1) / JC;        // chunks of column tiles (the last tile is h)
     constexpr int CHS = 16 * 256;                   // doubles per buffer: 4 block rows x JC tiles
@@ -519,19 +515,15 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_sprod(AviBatchArgs a, Schu
                         acc[jj][g] = (JC * cc + jj == mct && lc == 0 && ri < m) ? bv : 0.0;
                     }
             }
-            // (symmetric records: a block row left of this chunk's tiles, the h column apart, has nothing to do here)
-            if (!sym || JC * cc + JC - 1 >= Is || (mct >= JC * cc && mct < JC * cc + JC)) {
             double aop[16];
             al(kc, aop);
             const double *const vb = sV + (it & 1) * CHS;
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj) {
-                const int Jt = JC * cc + jj;
-                if (Jt <= mct && (!sym || Jt >= Is || Jt == mct)) {          // (Jt == mct: the h column, every block row needs it)
+                if (JC * cc + jj <= mct) {
 #pragma unroll
                     for (int s = 0; s < 16; ++s) acc[jj] = MFMA(aop[s], vb[((s >> 2) * 4 + jj) * 256 + (s & 3) * 64 + lane], acc[jj]);
                 }
-            }
             }
             if (kc == nkc - 1) {
 #pragma unroll
@@ -540,11 +532,7 @@ __global__ __launch_bounds__(TPB2, 1) void schur_big2_sprod(AviBatchArgs a, Schu
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int ri = 16 * Is + 4 * g + lq, cj = 16 * J + lc;
-                        if (J < mct) {                                      // straight into the Lemke dictionary
-                            const size_t ld = (size_t)((m + 1 + 15) & ~15);
-                            if (ri < m && cj < m && (!sym || J >= Is)) Sg[(size_t)ri * ld + cj] = acc[jj][g];
-                            if (sym && J > Is && ri < m && cj < m) Sg[(size_t)cj * ld + ri] = acc[jj][g];          // ... and its mirror image
-                        }
+                        if (J < mct) { if (ri < m && cj < m) Sg[(size_t)ri * ((m + 1 + 15) & ~15) + cj] = acc[jj][g]; }       // straight into the Lemke dictionary
                         else if (J == mct && lc == 0 && ri < m) cg[ri] = acc[jj][g];
                     }
                 }
