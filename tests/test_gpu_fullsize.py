@@ -205,3 +205,40 @@ def test_automatic_schedule_changes_nothing_in_the_results(engine, full):
         assert np.array_equal(r["z"].cpu().numpy(), res["z"])
     finally:
         engine.set_auto_schedule(16)
+
+
+def test_full_batch_on_the_bench_route(engine, oracle, full):
+    """The route the bench times: resident records, whose Qd blocks are all symmetric -> the symmetric kernel variant, staggered
+    instantiation (10 000 nodes > 4 096 resident wavefronts).  Same statuses, masks and pivot counts as the per-call route's
+    general variant on all 10 000 nodes, primals to rounding; certified by the independent check kernel; a subset against the
+    oracle; a node range uploaded on its own gives bit-identical rows (what sharding relies on, on THIS route)."""
+    import torch
+    host, dev, res, _ = full
+    nodes = engine.upload_nodes(*dev[:-1])
+    assert nodes.info()["symmetric"]
+    x = torch.zeros((NODES, N_), dtype=torch.float64, device="cuda:0")
+    out = nodes.solve(dev[-1], x_out=x)
+    torch.cuda.synchronize()
+    h = {k: v.cpu().numpy() for k, v in out.items()}
+    for k in ("status", "active", "pivots"):
+        assert np.array_equal(h[k], res[k]), k
+    assert np.max(np.abs(h["z"] - res["z"])) <= 1e-11 * max(1.0, np.max(np.abs(res["z"])))
+    assert np.max(h["resid"]) <= 1e-8 and np.array_equal(x.cpu().numpy(), h["z"][:, :N_])
+    Mc, q, lo, hi, kind = engine.assemble_nodes(*dev)
+    degree, _ = engine.check_avi_batch(Mc, q, lo, hi, out["z"], kind=kind, tol=1e-6)
+    torch.cuda.synchronize()
+    assert int(degree.sum().item()) == 0
+    idx = np.random.default_rng(6).choice(NODES, 300, replace=False)
+    M, q2, lo2, hi2, kind2 = P.reduced_blocks(host["Q"][idx], host["R"][idx], host["qd"][idx], host["A"][idx], host["B"][idx],
+                                              host["l"][idx], host["u"][idx], host["w"])
+    rc = oracle.solve_avi_batch(M, q2, lo2, hi2, kind=kind2)
+    assert np.array_equal(h["status"][idx], rc["status"]) and np.array_equal(h["active"][idx], rc["active"])
+    assert np.max(np.abs(h["z"][idx] - rc["z"])) <= 1e-9
+    nodes.close()
+    for lo_, hi_ in [(0, 1250), (8750, 10_000), (2000, 7000)]:
+        part = engine.upload_nodes(*[a[lo_:hi_] for a in dev[:-1]])
+        r = part.solve(dev[-1])
+        torch.cuda.synchronize()
+        assert np.array_equal(r["z"].cpu().numpy(), h["z"][lo_:hi_])
+        assert np.array_equal(r["active"].cpu().numpy(), h["active"][lo_:hi_])
+        part.close()
