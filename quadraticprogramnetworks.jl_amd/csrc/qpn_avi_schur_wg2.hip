@@ -175,7 +175,20 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
 {
     constexpr int pad = 16 * NR;
     const int b = blockIdx.x;
-    const int v = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // Which hardware wave plays which part: the wavefronts of a workgroup that has the CU to itself go to the SIMDs round-robin,
+    // so the hardware waves 2, 6, 10, 14 share a SIMD.  For NR <= 6 they all become C waves -- the first of them the leader --, so
+    // that no H wave's exchange runs on the SIMD on which the leader takes its turn: +3 % at 65 .. 80, +2 % at 96 (with 14 or 16
+    // waves the H waves would crowd on three SIMDs: -0.5 % at 112, nothing at 128 -- those keep the plain order).
+    const int hwv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int v = hwv;
+    if constexpr (NR <= 6) {
+        constexpr int nq = (2 * NR + 1) / 4;                 // hardware waves == 2 (mod 4) among the 2 NR
+        if ((hwv & 3) == 2) v = NR + (hwv >> 2);             // C waves 0 .. nq - 1
+        else {
+            const int rank = hwv - ((hwv + 1) >> 2);         // its position among the others
+            v = rank < NR ? rank : NR + nq + (rank - NR);
+        }
+    }
     const bool isH = v < NR;                            // H wave (row tile v) or C wave (row tile v - NR)
     const int I = isH ? v : v - NR;
     int l = (int)threadIdx.x & 63, lc = l & 15, lq = l >> 4, tid = 64 * v + l;
