@@ -586,13 +586,10 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
 #undef M_SK
 #undef M_SACC
     if constexpr (SYM) {
-        // S(1,0) = S(0,1)': register kb of a tile in the accumulator layout IS the A operand of its transpose's k-block kb
-        // (element (i = lc, k = lq) = X[4 kb + lq][lc]); B = rows 4 kb .. 4 kb + 3 of the identity.  Exact (x 1, + 0).
-#ifdef QPN_SYM_MFMA_TRANSPOSE
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) SB(1, 0) = MFMA(SB(0, 1)[kb], (lc == 4 * kb + lq) ? 1.0 : 0.0, SB(1, 0));
-#else
-        // through the idle Stage A block of sbuf (128 doubles), eight rows per round; row r of a round sits at
+        // S(1,0) = S(0,1)'.  (Also exact and 0.5 % slower: on the matrix cores -- register kb of a tile in the accumulator layout IS
+        // the A operand of its transpose's k-block kb, element (i = lc, k = lq) = X[4 kb + lq][lc], with B = rows 4 kb .. 4 kb + 3
+        // of the identity: X' = sum_kb MFMA(X[kb], I[4 kb .. 4 kb + 3][.]).)
+        // Here: through the idle Stage A block of sbuf (128 doubles), eight rows per round; row r of a round sits at
         // r * 16 + ((c + 4 (r >> 1)) & 15): the writes fill four whole rows, the 32 reading lanes (lc >> 3 == round) hit 32 banks
         const int rr_ = lc & 7, rot_ = 4 * (rr_ >> 1);
 #pragma unroll
@@ -609,7 +606,6 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             }
             wave_sync();
         }
-#endif
     }
     wave_sync();
     // c_k = b_k - sum_j A[k][j] h_j, lane k <-> pair k (k < m)
