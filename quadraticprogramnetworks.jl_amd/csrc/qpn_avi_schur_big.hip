@@ -723,7 +723,12 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
     const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
     // (row stride of T_base: a multiple of 16 doubles -- with m + 1 every 16-column run of a row straddles two cache lines and
     // the fold's tile stores are partial-sector writes)
-    const int m = w.nred[b], XC = m, VTH = 2 * m, ld = (m + 1 + 15) & ~15;
+    const int m = w.nred[b], XC = m, VTH = 2 * m;
+    // (an item's slot in `dict` is N (N + 1) doubles: with very few free rows -- n (2 m + n + 1) < 15 m, e.g. n = 5, m = 99 -- the
+    //  padded rows do not fit it and the plain stride is used; the blocked crash from the records, the only writer that
+    //  fills T_base itself (s_rowmajor == 2), has n > 64 and always fits)
+    const int ldp = (m + 1 + 15) & ~15;
+    const int ld = ((long long)m * ldp <= (long long)a.N * (a.N + 1)) ? ldp : m + 1;
     if (m < m_lo || m > m_hi) return;                // this launch's LDS is sized for m_hi
     const size_t vo = (size_t)b * (size_t)a.N;
     __shared__ SbRed S;

@@ -31,6 +31,28 @@ def test_large_reduced_nodes(engine, oracle, n, m, cnt):
     _cmp(rg, rc, f"large n={n} m={m}")
 
 
+@pytest.mark.parametrize("n,m,cnt", [(5, 99, 7), (1, 100, 5), (3, 70, 6), (7, 120, 4), (1, 300, 3)])
+def test_large_items_with_very_few_free_rows(engine, oracle, n, m, cnt):
+    """n (2 m + n + 1) < 15 m: the padded row stride of the delayed-update Lemke's dictionary (m + 1 rounded up to 16) would
+    not fit an item's N (N + 1) slot of the workspace -- the rows of one item ran into the next item's slot and, behind the
+    last item, into the crash's outputs (found by tools/wg2_fuzz.py at n = 5, m = 99: item 0 of 7 came back FAILURE with the
+    oracle's pivot count).  Such items take the plain stride.  Explicit M and node records (the large-node route)."""
+    from qpn_amd import _lib
+    from qpn_amd.engine import colmajor
+    Q, R, qd, A, B, l, u = P.synth_nodes(7300 + m, cnt, n, m)
+    w = P.shared_params()
+    M, q, lo, hi, kind = P.reduced_blocks(Q, R, qd, A, B, l, u, w)
+    rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kind)
+    rg = engine.solve_avi_batch(colmajor(M), q, lo, hi, kind=kind)
+    _cmp(rg, rc, f"few free rows, explicit M, n={n} m={m}")
+    engine.set_option(_lib.OPT_MID_ROUTE, 0)
+    try:
+        rn = engine.solve_nodes(colmajor(Q), colmajor(R), qd, colmajor(A), colmajor(B), l, u, w)
+    finally:
+        engine.set_option(_lib.OPT_MID_ROUTE, 1)
+    _cmp(rn, rc, f"few free rows, node records on the large-node route, n={n} m={m}")
+
+
 def test_large_box_mcp_and_device_path(engine, oracle):
     import torch
     from qpn_amd.engine import colmajor
