@@ -17,7 +17,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 worst = 0.0; items = 0; t0 = time.time()
 
 
+BIG = os.environ.get("BIG") == "1"                 # BIG=1: sides up to 500 (N <= 1000: the ABI's limit is 1024), few items
+
+
 def dim(kind):
+    if BIG:
+        return int({0: rng.integers(1, 65), 1: rng.integers(65, 257), 2: rng.integers(257, 501), 3: rng.integers(257, 501),
+                    4: rng.integers(1, 8)}[kind])
     return int({0: rng.integers(1, 33), 1: rng.integers(33, 65), 2: rng.integers(65, 129), 3: rng.integers(129, 257),
                 4: rng.integers(1, 8)}[kind])
 
@@ -26,7 +32,7 @@ for t in range(trials):
     n, m = dim(int(rng.integers(0, 5))), dim(int(rng.integers(0, 5)))
     if rng.random() < 0.03:
         m = 0
-    p = int(rng.integers(0, 9)); cnt = int(rng.integers(1, 7))
+    p = int(rng.integers(0, 9)); cnt = int(rng.integers(1, 3 if BIG else 7))
     Q, Rm, qd, A, B, l, u = P.synth_nodes(30_000 + t, cnt, n, max(m, 1), max(p, 1))
     if m == 0:
         A = A[:, :0, :]; B = B[:, :0, :]; l = l[:, :0]; u = u[:, :0]
