@@ -259,16 +259,29 @@ def implicit_bounds_batch(polys, engine, tol=1e-4):
         dmax = max(trips[b][0].shape[1] for b, _, _ in jobs); mmax = max(trips[b][0].shape[0] for b, _, _ in jobs)
         A2 = np.zeros((len(jobs), mmax, dmax)); l2 = np.full((len(jobs), mmax), -INF); u2 = np.full((len(jobs), mmax), INF)
         cost = np.zeros((len(jobs), dmax))
+        big = np.zeros(len(jobs))
         for k, (b, i, sg) in enumerate(jobs):
             A, l, u = trips[b]
             n, d = A.shape
             A2[k, :n, :d] = A; l2[k, :n] = l; u2[k, :n] = u
             cost[k, :d] = sg * A[i]
+            # The objective IS row i, so the LP is unbounded only through that row's own open side.  The pivoting method does
+            # not always end an unbounded degenerate LP in a ray (it may stop at a point its own post-check then rejects), so
+            # that side is closed far out and an optimum AT the far bound is read as "unbounded" (the reference reads OSQP's
+            # dual-infeasible status the same way, :691-693, :704-706).
+            fin = np.concatenate([l[np.isfinite(l)], u[np.isfinite(u)], [1.0]])
+            big[k] = 1e6 * max(1.0, float(np.max(np.abs(fin))))
+            if sg > 0 and l[i] == -INF:
+                l2[k, i] = -big[k]
+            if sg < 0 and u[i] == INF:
+                u2[k, i] = big[k]
         st, x, _ = _solve_lps(cost, A2, l2, u2, engine)
         ext = {}
         for k, (b, i, sg) in enumerate(jobs):
             if st[k] == 1:
                 v = float(trips[b][0][i] @ x[k, :trips[b][0].shape[1]])
+                if abs(v) >= big[k] * (1.0 - 1e-6):
+                    v = -INF if sg > 0 else INF                 # at the far bound: unbounded in that direction
             elif st[k] == 2:
                 v = -INF if sg > 0 else INF                     # unbounded in that direction (:691-693, :704-706)
             else:

@@ -177,7 +177,11 @@ def _check_slack_and_implicit(engine, seed):
     for (A, l, u), (eq, vals) in zip(keep + [pinned], res):
         for i in range(A.shape[0]):
             lo = _lp(A[i], A, l, u); hi = _lp(-A[i], A, l, u)
-            vlo = -np.inf if lo.status == 3 else lo.fun; vhi = np.inf if hi.status == 3 else -hi.fun
+            if lo.status not in (0, 2, 3) or hi.status not in (0, 2, 3):
+                continue                                    # (HiGHS gave no answer: model_status Unknown)
+            # (the polyhedron is non-empty -- it has a point with margin -- so HiGHS' "infeasible" here is its presolve's
+            #  "infeasible or unbounded": unbounded)
+            vlo = -np.inf if lo.status in (2, 3) else lo.fun; vhi = np.inf if hi.status in (2, 3) else -hi.fun
             want = bool(abs(l[i] - u[i]) <= 1e-4) or (np.isfinite(vlo) and np.isfinite(vhi) and abs(vlo - vhi) <= 1e-4)
             assert eq[i] == want, (i, vlo, vhi)
             if eq[i] and not abs(l[i] - u[i]) <= 1e-4:
