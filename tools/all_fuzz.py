@@ -46,14 +46,23 @@ for t in range(trials):
     eq = (kind == 4) & (rng.random(l.shape) < 0.01)
     u = np.where(eq, l, u)
     w = rng.standard_normal(p)
+    # OPTS=1: a pivot budget that some items exhaust (status MAX_ITERS on both sides, the same items), parameters per node
+    oo = og = None
+    if os.environ.get("OPTS") == "1":
+        if rng.random() < 0.5 and p > 0:
+            w = rng.standard_normal((cnt, p))
+        if rng.random() < 0.6:
+            mp = n + int(rng.integers(0, 12))
+            oo = binding.default_opts(); oo.max_pivots = mp
+            og = eng.default_opts(); og.max_pivots = mp
     M, q, lo, hi, kd = P.reduced_blocks(Q, Rm, qd, A, B, l, u, w)
-    rc = binding.solve_avi_batch(M, q, lo, hi, kind=kd)
-    routes = [("nodes", eng.solve_nodes(colmajor(Q), colmajor(Rm), qd, colmajor(A), colmajor(B), l, u, w)),
-              ("explicit", eng.solve_avi_batch(colmajor(M), q, lo, hi, kind=kd))]
+    rc = binding.solve_avi_batch(M, q, lo, hi, kind=kd, opts=oo)
+    routes = [("nodes", eng.solve_nodes(colmajor(Q), colmajor(Rm), qd, colmajor(A), colmajor(B), l, u, w, opts=og)),
+              ("explicit", eng.solve_avi_batch(colmajor(M), q, lo, hi, kind=kd, opts=og))]
     if t % 3 == 0:                                  # ... and the resident-records route (second sweep: the handle knows its records)
         h = eng.upload_nodes(colmajor(Q), colmajor(Rm), qd, colmajor(A), colmajor(B), l, u)
-        h.solve(w)
-        routes.append(("handle", {k: np.array(v) for k, v in h.solve(w).items()}))
+        h.solve(w, opts=og)
+        routes.append(("handle", {k: np.array(v) for k, v in h.solve(w, opts=og).items()}))
         h.close()
     for name, r in routes:
         tag = (name, t, n, m, p, cnt)
