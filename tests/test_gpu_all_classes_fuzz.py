@@ -1,0 +1,61 @@
+"""Random node shapes across ALL size classes and both extreme aspect ratios (sides from 1 (m from 0) to 256: one-wavefront kernels,
+the fused workgroup kernels of 33-64 and 65-128, the blocked crash of config 5, the general kernels), mixed bound kinds, a few
+equality rows, pivot budgets that some items exhaust -- through node records per call, a resident handle and explicit M, all against
+the CPU oracle: statuses, pivot counts and active-set masks equal, primals within 1e-9 relative.  The committed, seeded slice of
+tools/all_fuzz.py (which ran 5 000 shapes per seed; its first relative, tools/wg2_fuzz.py, found the padded-stride defect of
+test_large_items_with_very_few_free_rows)."""
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_random_shapes_three_routes_against_the_oracle(engine, oracle, seed):
+    from qpn_amd.engine import colmajor
+    rng = np.random.default_rng(seed)
+    dim = lambda k: int({0: rng.integers(1, 33), 1: rng.integers(33, 65), 2: rng.integers(65, 129), 3: rng.integers(129, 257),
+                         4: rng.integers(1, 8)}[k])
+    for t in range(90):
+        n, m = dim(int(rng.integers(0, 5))), dim(int(rng.integers(0, 5)))
+        if rng.random() < 0.04:
+            m = 0
+        p = int(rng.integers(0, 9)); cnt = int(rng.integers(1, 6))
+        Q, Rm, qd, A, B, l, u = P.synth_nodes(90_000 + 1000 * seed + t, cnt, n, max(m, 1), max(p, 1))
+        if m == 0:
+            A = A[:, :0, :]; B = B[:, :0, :]; l = l[:, :0]; u = u[:, :0]
+        if p == 0:
+            Rm = np.zeros((cnt, n, 0)); B = np.zeros((cnt, m, 0))
+        else:
+            Rm = Rm[:, :, :p]; B = rng.standard_normal((cnt, m, p)) * 0.1
+        kind = rng.integers(0, 6, size=l.shape)
+        l = np.where(kind == 1, -np.inf, l); u = np.where(kind == 2, np.inf, u)
+        l = np.where(kind == 3, -np.inf, l); u = np.where(kind == 3, np.inf, u)
+        u = np.where((kind == 4) & (rng.random(l.shape) < 0.01), l, u)
+        w = rng.standard_normal((cnt, p)) if (p > 0 and rng.random() < 0.3) else rng.standard_normal(p)
+        oo = og = None
+        if rng.random() < 0.3:
+            mp = n + int(rng.integers(0, 12))
+            oo = oracle.default_opts(); oo.max_pivots = mp
+            og = engine.default_opts(); og.max_pivots = mp
+        M, q, lo, hi, kd = P.reduced_blocks(Q, Rm, qd, A, B, l, u, w)
+        rc = oracle.solve_avi_batch(M, q, lo, hi, kind=kd, opts=oo)
+        abi = (colmajor(Q), colmajor(Rm), qd, colmajor(A), colmajor(B), l, u)
+        routes = [("nodes", engine.solve_nodes(*abi, w, opts=og)), ("explicit", engine.solve_avi_batch(colmajor(M), q, lo, hi, kind=kd, opts=og))]
+        if t % 3 == 0:
+            h = engine.upload_nodes(*abi)
+            h.solve(w, opts=og)
+            routes.append(("handle", {k: np.array(v) for k, v in h.solve(w, opts=og).items()}))
+            h.close()
+        ok = rc["status"] == 1
+        for name, r in routes:
+            tag = (name, seed, t, n, m, p, cnt)
+            assert np.array_equal(np.asarray(r["status"]), rc["status"]), (tag, np.asarray(r["status"]), rc["status"])
+            assert np.array_equal(np.asarray(r["active"])[ok], rc["active"][ok]), tag
+            if name != "explicit":
+                assert np.array_equal(np.asarray(r["pivots"])[ok], rc["pivots"][ok]), tag
+            if ok.any():
+                d = np.max(np.abs(np.asarray(r["z"])[ok] - rc["z"][ok])) / max(1.0, np.max(np.abs(rc["z"][ok])))
+                assert d <= 1e-9, (tag, d)
