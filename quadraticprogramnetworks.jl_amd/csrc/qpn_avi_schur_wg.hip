@@ -910,6 +910,12 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
         unsigned long long bits = (unsigned long long)((hw >> 4) & 3u) << (48 + 2 * v);
         if (v == 0) bits |= (unsigned long long)((hw >> 8) & 0xFu) << 56;
         atomicOr(&a.stamps[(size_t)b * 8 + 0], bits);
+        if (v == 0) {
+            // ... and the whole identity of the leader's slot in bits 48.. of slot 1: HW_ID[15:0] (wave slot, SIMD, pipe, CU, SH, SE) and XCC_ID
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            atomicOr(&a.stamps[(size_t)b * 8 + 1], ((unsigned long long)(hw & 0xFFFFu) << 48) | ((unsigned long long)(xcc & 0xFu) << 44));
+        }
     }
 #endif
 }

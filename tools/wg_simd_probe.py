@@ -28,3 +28,19 @@ simd = np.stack([(s0 >> np.uint64(48 + 2 * v)) & np.uint64(3) for v in range(nw)
 print("leader (wave 0) SIMD histogram:", np.bincount(simd[:, 0], minlength=4))
 for v in range(1, nw):
     print(f"wave {v}: SIMD relative to the leader's (mod 4):", np.bincount((simd[:, v] - simd[:, 0]) % 4, minlength=4))
+
+# per CU: which SIMDs do the leaders of the workgroups that are resident TOGETHER sit on?  (first round: the first 4 (5) x 256 workgroups)
+s1 = st[:, 1].cpu().numpy().astype(np.uint64)
+hw = (s1 >> np.uint64(48)).astype(np.int64) & 0xFFFF
+xcc = (s1 >> np.uint64(44)).astype(np.int64) & 0xF
+cu_key = (xcc << 16) | (hw & 0xFF00)                 # XCC, SE, SH, CU
+slot = hw & 0xF
+first = np.arange(cnt) < (1280 if nw == 3 else 1024)
+from collections import Counter, defaultdict
+per_cu = defaultdict(list)
+for b in np.nonzero(first)[0]:
+    per_cu[int(cu_key[b])].append((int(simd[b, 0]), int(slot[b])))
+pat = Counter(tuple(sorted(Counter(s for s, _ in v).values(), reverse=True)) for v in per_cu.values())
+print(f"first round: {len(per_cu)} CUs; leaders per SIMD on a CU (sorted counts) -> number of CUs:", dict(pat))
+same = sum(1 for v in per_cu.values() for (s, w) in v if s == (w & 3))
+print("leader's SIMD id == its wave-slot id (mod 4) in", same, "of", int(first.sum()), "first-round workgroups; slot histogram:", np.bincount(slot[first], minlength=8)[:8])
