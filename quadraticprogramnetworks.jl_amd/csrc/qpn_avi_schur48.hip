@@ -1,0 +1,609 @@
+// Fused node-AVI solve for node records with 33 <= max(n, m) <= 48 on ONE wavefront per node (src/avi.jl:205-251, :305-377 assembly;
+// :63-77 solve; :148-156 post-check; src/avi_solutions.jl:511-562 masks) -- the algorithm and the tile layout of the 32-class kernel
+// (qpn_avi_schur.hip: crash of the x block as rank-4 block pivots on the fp64 matrix cores, Lemke with the Harris two-pass ratio
+// test on the Schur dictionary in registers, post-check on the original blocks), with THREE 16 x 16 tiles a side instead of two.
+// 48 rows fit the 64 lanes of a wavefront (one row per lane in the ratio test), and at two wavefronts per SIMD a wave may use 256
+// VGPRs: 18 tiles of [H | C~] in the crash, 9 + 9 tiles (dictionary + W~) in the Lemke phase.  The fused workgroup kernel of the
+// 33-64 class (qpn_avi_schur_wg.hip) spends 12 K VALU instructions per node at n = m = 48 on three waves that each factor the
+// pivot block, keep their own bookkeeping and meet at two barriers per pivot; this kernel has no barrier at all.
+// Sizes inside the class are padded to 48: identity rows in H, zero rows / columns elsewhere.  Items the crash cannot take
+// (an equality row, a block pivot below the threshold) are flagged status = -1 for the general path, as in the other kernels.
+#include "qpn_internal.h"
+
+#define QINF __builtin_huge_val()
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+#define MFMA_NEGA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 1)      // D = C - A B (gfx950 NEG bits)
+
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double rcp64_(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+constexpr int T3 = 3, NP = 48, SAS = 50;       // tiles a side, padded size, column stride of the LDS block buffer
+
+__global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
+{
+    const int l = threadIdx.x, lc = l & 15, lq = l >> 4;
+    int b = blockIdx.x;
+    if (a.order) { b = a.order[blockIdx.x]; if ((unsigned)b >= (unsigned)a.batch) return; }
+    const int n = a.nd.n, m = a.nd.m, np_ = a.nd.p, N = n + m;
+    auto decline = [&]() {
+        if (l == 0) { a.status[b] = -1; if (a.decl_count) atomicAdd(a.decl_count, 1); }
+    };
+    if (!(n >= 1 && n <= NP && m >= 0 && m <= NP)) { decline(); return; }
+
+    // block buffer: Qd while the H tiles are built, then Ad ([column of x][constraint row]) for the rest of the solve; the two
+    // spare slots per column hold q in item order
+    __shared__ __attribute__((aligned(32))) double sA[NP * SAS];
+    __shared__ __attribute__((aligned(32))) double sbuf[384];
+#define SQ(i) sA[((i) >> 1) * SAS + NP + ((i) & 1)]
+    double *const sU = sbuf;                    // Stage A: pivot columns, [48][4]
+    double *const sP = sbuf + 192;              // Stage A: the raw 4 x 4 pivot block
+    double *const sucol = sbuf;                 // Stage B: entering column, permuted [4][12] (+ the extra entry)
+    double *const svrow = sbuf + 64;            // Stage B: pivot row [49]
+    double *const sval = sbuf;                  // read-back: values by variable id [97]
+    double *const sz = sbuf + 256;              // h, then the solution in item order [96]
+
+    const double *Q_ = a.nd.Qd + (size_t)b * n * n;
+    const double *A_ = a.nd.Ad + (size_t)b * m * n;
+    const double *R_ = a.nd.R + (size_t)b * n * np_;
+    const double *B_ = a.nd.B + (size_t)b * m * np_;
+    const double *w_ = a.nd.w + (size_t)b * (size_t)a.nd.stride_w;
+
+    // ---- q = [qd + R w; B w] in item order (two rounds of 64 rows), the p terms in ascending order
+    for (int it = l; it < N; it += 64) {
+        const bool isx = it < n;
+        const double *col = isx ? R_ + it : B_ + (it - n);
+        const size_t cs = isx ? (size_t)n : (size_t)m;
+        double s = isx ? a.nd.qd[(size_t)b * n + it] : 0.0;
+        for (int k = 0; k < np_; ++k) s = fma(col[(size_t)k * cs], w_[k], s);
+        SQ(it) = s;
+    }
+    // ---- Qd -> LDS (zero-padded), column by column: lane <-> row, 16 columns in flight
+    double mabs = 0.0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NP; c0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = c0 + t;
+            const bool ok = c < n && l < n;
+            const double x = Q_[ok ? (size_t)c * n + l : 0];
+            v[t] = ok ? x : 0.0;
+        }
+        if (l < NP) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { sA[(c0 + t) * SAS + l] = v[t]; mabs = fmax(mabs, fabs(v[t])); }
+        }
+    }
+    wsync();
+    // the top half [H | C~] in the accumulator layout of v_mfma_f64_16x16x4_f64: tile (I, J), register g, lane (lq, lc) holds
+    // row 16 I + 4 g + lq, column 16 J + lc
+    d4 T[T3][2 * T3];
+#pragma unroll
+    for (int I = 0; I < T3; ++I)
+#pragma unroll
+        for (int J = 0; J < T3; ++J)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rr = 16 * I + 4 * g + lq, cc = 16 * J + lc;
+                double v = sA[cc * SAS + rr];
+                if (rr == cc && rr >= n) v = 1.0;                     // padded x rows: identity
+                T[I][J][g] = v;
+            }
+    wsync();
+    // ---- Ad -> LDS: sA[x column j][constraint row r] (zero-padded)
+#pragma unroll 1
+    for (int c0 = 0; c0 < NP; c0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = c0 + t;
+            const bool ok = j < n && l < m;
+            const double x = A_[ok ? (size_t)j * m + l : 0];
+            v[t] = ok ? x : 0.0;
+        }
+        if (l < NP) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { sA[(c0 + t) * SAS + l] = v[t]; mabs = fmax(mabs, fabs(v[t])); }
+        }
+    }
+    wsync();
+    // the tiles hold -C = +Ad' (W~ = -W: S = D - A W = A W~, x = W~ lambda - h)
+#pragma unroll
+    for (int I = 0; I < T3; ++I)
+#pragma unroll
+        for (int J = 0; J < T3; ++J)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rr = 16 * I + 4 * g + lq, ck = 16 * J + lc;
+                T[I][T3 + J][g] = sA[rr * SAS + ck];                   // zero outside n x m already
+            }
+    // extra column: g = q of the x rows, lane l <-> row l (lanes >= 48 idle)
+    double kx = (l < n) ? SQ(l) : 0.0;
+    const double mscale = wave_max_f64(mabs);
+    const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
+
+    // ---- Stage A: 12 rank-4 block pivots of the top half on the matrix cores (pivot rows carry P - I in U, so that the update
+    // T -= (U P^-1) V turns them into P^-1 V themselves)
+    bool fail = false;
+#pragma unroll
+    for (int KB = 0; KB < 12; ++KB) {
+        if (!fail && 4 * KB < n) {            // a block of padded rows is an identity pivot: nothing moves
+            const int JP = KB >> 2, GP = KB & 3, p0 = 4 * KB;
+            const int kcol = lc - 4 * GP;
+            if (kcol >= 0 && kcol < 4) {
+#pragma unroll
+                for (int I = 0; I < T3; ++I)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int rr = 16 * I + 4 * g + lq;
+                        double v = T[I][JP][g];
+                        if (I == JP && g == GP) sP[lq * 4 + kcol] = v;                 // the pivot block itself, raw
+                        if (I == JP && g == GP && lq == kcol) v -= 1.0;
+                        sU[rr * 4 + kcol] = v;
+                    }
+            }
+            wsync();
+            double pm[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const d4 row = *reinterpret_cast<const d4 *>(sP + i * 4);
+                pm[i][0] = row[0]; pm[i][1] = row[1]; pm[i][2] = row[2]; pm[i][3] = row[3];
+            }
+            const double x0 = readlane_f64(kx, p0), x1 = readlane_f64(kx, p0 + 1);
+            const double x2 = readlane_f64(kx, p0 + 2), x3 = readlane_f64(kx, p0 + 3);
+            bool okp = true;
+            double rd[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                okp = okp && fabs(pm[s][s]) >= diag_thr;
+                rd[s] = rcp64_(pm[s][s]);
+#pragma unroll
+                for (int i = s + 1; i < 4; ++i) {
+                    const double f = pm[i][s] * rd[s];
+                    pm[i][s] = f;
+#pragma unroll
+                    for (int j = s + 1; j < 4; ++j) pm[i][j] = fma(-f, pm[s][j], pm[i][j]);
+                }
+            }
+            if (!ubool(okp)) { fail = true; }
+            else {
+                if (l < NP) {
+                    const d4 ur = *reinterpret_cast<const d4 *>(sU + l * 4);
+                    const double y0 = ur[0] * rd[0];
+                    const double y1 = fma(-y0, pm[0][1], ur[1]) * rd[1];
+                    const double y2 = fma(-y1, pm[1][2], fma(-y0, pm[0][2], ur[2])) * rd[2];
+                    const double y3 = fma(-y2, pm[2][3], fma(-y1, pm[1][3], fma(-y0, pm[0][3], ur[3]))) * rd[3];
+                    d4 up;
+                    up[3] = y3;
+                    up[2] = fma(-up[3], pm[3][2], y2);
+                    up[1] = fma(-up[3], pm[3][1], fma(-up[2], pm[2][1], y1));
+                    up[0] = fma(-up[3], pm[3][0], fma(-up[2], pm[2][0], fma(-up[1], pm[1][0], y0)));
+                    kx -= fma(up[3], x3, fma(up[2], x2, fma(up[1], x1, up[0] * x0)));
+                    *reinterpret_cast<d4 *>(sU + l * 4) = up;
+                }
+                wsync();
+                double au[T3];
+#pragma unroll
+                for (int I = 0; I < T3; ++I) au[I] = sU[(16 * I + lc) * 4 + lq];
+#pragma unroll
+                for (int J = 0; J < 2 * T3; ++J) {
+                    if (J >= JP) {                       // (columns left of the pivot tile are dead: H^-1 itself is never needed)
+                        double vraw = T[JP][J][GP];
+                        asm volatile("" : "+v"(vraw));
+#pragma unroll
+                        for (int I = 0; I < T3; ++I) T[I][J] = MFMA_NEGA(au[I], vraw, T[I][J]);
+                    }
+                }
+                wsync();
+            }
+        }
+    }
+    if (fail) { decline(); return; }
+
+    // ---- S = A W~ on the matrix cores (W~ = rows of x, an aligned group of 4 rows is a B operand), c = b - A h
+    d4 SB[T3][T3];
+    {
+        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int Ib = 0; Ib < T3; ++Ib)
+#pragma unroll
+            for (int Jb = 0; Jb < T3; ++Jb) SB[Ib][Jb] = z4;
+    }
+    if (l < NP) sz[l] = kx;
+    // bounds of pair l: requested here so that the round trip hides behind the MFMAs
+    double lo = -QINF, hi = QINF;
+    if (l < m) { lo = a.nd.l[(size_t)b * m + l]; hi = a.nd.u[(size_t)b * m + l]; }
+#pragma unroll
+    for (int I = 0; I < T3; ++I)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kk = 4 * I + g;
+            if (4 * kk < n) {                 // rows of W~ beyond n are zero
+                double ao[T3];
+#pragma unroll
+                for (int Ib = 0; Ib < T3; ++Ib) ao[Ib] = sA[(4 * kk + lq) * SAS + 16 * Ib + lc];
+#pragma unroll
+                for (int Ib = 0; Ib < T3; ++Ib)
+#pragma unroll
+                    for (int Jb = 0; Jb < T3; ++Jb) SB[Ib][Jb] = MFMA(ao[Ib], T[I][T3 + Jb][g], SB[Ib][Jb]);
+            }
+        }
+    wsync();
+    double xb = 0.0;
+    {
+        const bool lowr = l < m;
+        const int ls = lowr ? l : 0;
+        double acc = lowr ? SQ(n + ls) : 0.0, acc2 = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < NP; j += 2) {
+            acc = fma(-sA[j * SAS + ls], sz[j], acc);
+            acc2 = fma(-sA[(j + 1) * SAS + ls], sz[j + 1], acc2);
+        }
+        xb = lowr ? acc + acc2 : 0.0;
+    }
+
+    // W~ leaves the registers for the Lemke phase: it takes Ad's place in the block buffer, [x row][constraint], for the read-back
+    // (the post-check reads Ad from memory again: the records of this node are a few microseconds old in L2 / the memory-side cache)
+    wsync();
+#pragma unroll
+    for (int I = 0; I < T3; ++I)
+#pragma unroll
+        for (int Jb = 0; Jb < T3; ++Jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sA[(16 * I + 4 * g + lq) * SAS + 16 * Jb + lc] = T[I][T3 + Jb][g];
+
+    // ================= Stage B: Lemke on the Schur dictionary (48 pairs, tile layout) =================
+    // pair k (k < 48) <-> item row n + k:  p_k = (S lambda + c)_k in [l_k, u_k],  d_k = lambda_k.
+    // ids: p_k -> k, d_k -> 48 + k, artificial -> 96; column index 48 = the extra (covering) column.
+    constexpr int NBP = NP, XC = NP, VTH = 2 * NP;
+    const bool actb = l < NBP;
+    if (qpn_ballot(actb && lo == hi)) { decline(); return; }      // equality rows need their multiplier crashed in: general kernel
+    const double lo0 = lo, hi0 = hi;
+    const int clsv = (lo0 == -QINF && hi0 == QINF) ? 2 : 0;
+    const double rngv = hi0 - lo0;
+    int satv = 0;
+    int rowvar = actb ? l : -1, colvar = actb ? NBP + l : (l == XC ? VTH : -1);
+    double nbval = 0.0, tcol = 0.0;
+    wsync();
+    // the dictionary: SDV(Jb, 4 Ib + g) = row 16 Ib + 4 g + lq, column 16 Jb + lc -- 36 NAMED scalars (an array indexed under a
+    // switch is turned into a dynamically indexed array by the optimiser, and that lives in scratch memory)
+#define SDV(J, K) sd_##J##_##K
+#define FOR_K(M, J) M(J, 0) M(J, 1) M(J, 2) M(J, 3) M(J, 4) M(J, 5) M(J, 6) M(J, 7) M(J, 8) M(J, 9) M(J, 10) M(J, 11)
+#define FOR_JK(M) FOR_K(M, 0) FOR_K(M, 1) FOR_K(M, 2)
+#define M_DECL(J, K) double SDV(J, K) = SB[(K) >> 2][J][(K) & 3];
+    FOR_JK(M_DECL)
+#undef M_DECL
+    auto col_of = [&](int v) -> int { return wave_first(colvar == v); };
+    int pivots = n;
+    const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
+    int status = QPN_FAILURE;
+    int c = XC;
+    bool sneg = true;
+    double self_lim = 0.0, elo = 0.0, ehi = QINF;
+    const double slack = 1e-10, ptol = a.piv_tol;
+    {
+        double viol = 0.0;
+        if (actb) viol = xb < lo ? lo - xb : (xb > hi ? xb - hi : 0.0);
+        const double theta0 = wave_max_f64(viol);
+        if (ubool(theta0 <= a.feas_tol)) status = QPN_SUCCESS;
+        else {
+            if (actb) {
+                double cov = 0.0;
+                if (xb < lo) {
+                    double tgt = lo + (theta0 - (lo - xb));
+                    if (hi < QINF) { double mid = 0.5 * (lo + hi); if (tgt > mid) tgt = mid; }
+                    cov = (tgt - xb) / theta0; xb = tgt;
+                } else if (xb > hi) {
+                    double tgt = hi - (theta0 - (xb - hi));
+                    if (lo > -QINF) { double mid = 0.5 * (lo + hi); if (tgt < mid) tgt = mid; }
+                    cov = (tgt - xb) / theta0; xb = tgt;
+                }
+                tcol = cov;
+            }
+            if (l == XC) nbval = theta0;
+            self_lim = theta0;
+            status = QPN_MAX_ITERS;
+        }
+    }
+    // row i of a column sits at (i & 3) * 12 + 4 * (i >> 4) + ((i >> 2) & 3): a lane group reads its 12 rows as 12 consecutive doubles
+    const int myslot = (l & 3) * 12 + ((l >> 4) << 2) + ((l >> 2) & 3);
+    while (status == QPN_MAX_ITERS) {
+        if (pivots >= max_piv) break;
+        c = uni(c);
+        // ---- entering column -> sucol
+        if (c == XC) { if (actb) sucol[myslot] = tcol; }
+        else if (lc == (c & 15)) {
+            double *const dst = sucol + lq * 12;
+            const int Jc = c >> 4;
+#define M_PUB(J, K) dst[K] = SDV(J, K);
+            if (Jc == 0) { FOR_K(M_PUB, 0) } else if (Jc == 1) { FOR_K(M_PUB, 1) } else { FOR_K(M_PUB, 2) }
+#undef M_PUB
+        }
+        wsync();
+        const double cm = actb ? sucol[myslot] : 0.0;
+        // ---- ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
+        const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
+        const double rc = rcp64_(gdir);
+        const bool gneg = __double2hiint(gdir) < 0;
+        const double tb = gneg ? lo : hi;
+        const bool cnd = actb && (fabs(gdir) > ptol) && (fabs(tb) < QINF);
+        const double arc = fabs(rc);
+        const double dd = cnd ? (tb - xb) * rc : QINF;
+        const double d1 = fma(slack, arc, dd);
+        const double dmax = fmin(wave_min_f64(d1), self_lim);
+        if (uni(__double2hiint(dmax)) == 0x7ff00000 && uni(__double2loint(dmax)) == 0) { status = QPN_RAY_TERM; break; }
+        const unsigned long long bal = qpn_ballot(dd <= dmax);
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, inv = 0.0;
+        int rsel = 0, rq = 0, cnext = -1;
+        bool pivoted = false, stop = false;
+        int rW = 63, veW = 0, cW = 63, vlW = 0, kW = 63, auW = 0;
+        double eloW = 0.0, ehiW = 0.0, nbW = 0.0;
+        if (bal == 0ull) {
+            // the entering variable reaches its own opposite bound first: no basis change
+            const double dl = sneg ? -self_lim : self_lim;
+            if (actb) xb = fma(dl, cm, xb);
+            const int ve = readlane_i32(colvar, c);
+            if (ve == VTH) { nbW = 0.0; status = QPN_SUCCESS; stop = true; }
+            else {
+                const int k = ve;
+                const int au = sneg ? 0 : 1;
+                nbW = au ? readlane_f64(hi0, k) : readlane_f64(lo0, k);
+                kW = k; auW = au;
+                pivots++;
+                cnext = col_of(NBP + k);
+                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
+                sneg = au != 0;
+                self_lim = QINF;
+                if (au) { elo = -QINF; ehi = 0.0; } else { elo = 0.0; ehi = QINF; }
+            }
+        } else {
+            int r;
+            if (__popcll(bal) == 1) r = __ffsll((long long)bal) - 1;
+            else {
+                const bool cand = dd <= dmax;
+                double ag = cand ? fabs(gdir) : -1.0;
+                if (cand && rowvar == VTH) ag = QINF;
+                const double bestg = wave_max_f64(ag);
+                r = wave_first(cand && ag == bestg);
+            }
+            r = uni(r);
+            rq = r & 3;
+            rsel = ((r >> 4) << 2) | ((r >> 2) & 3);              // register 4 Ib + g of row r
+            {
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+#define M_PICK(K) case K: p0 = SDV(0, K); p1 = SDV(1, K); p2 = SDV(2, K); break;
+                switch (rsel) { M_PICK(0) M_PICK(1) M_PICK(2) M_PICK(3) M_PICK(4) M_PICK(5) M_PICK(6) M_PICK(7) M_PICK(8) M_PICK(9) M_PICK(10) default: p0 = SDV(0, 11); p1 = SDV(1, 11); p2 = SDV(2, 11); break; }
+#undef M_PICK
+                if (lq == rq) { svrow[lc] = p0; svrow[16 + lc] = p1; svrow[32 + lc] = p2; }
+            }
+            wsync();
+            // the row's extra-column entry rides along as "column 48"; the entry of the pivot column itself is replaced by -1 so
+            // that row * inv carries -inv there
+            if (l == r) { svrow[XC] = tcol; svrow[c] = -1.0; }
+            double step = readlane_f64(dd, r);
+            if (step < 0.0) step = 0.0;
+            const double leave_val = readlane_f64(tb, r);
+            const double rcr = readlane_f64(rc, r);
+            inv = sneg ? -rcr : rcr;
+            const double delta = sneg ? -step : step;
+            const int vl = readlane_i32(rowvar, r);
+            const double enter_val = readlane_f64(nbval, c) + delta;
+            wsync();
+            {
+                const double pa = svrow[lc], pb = svrow[16 + lc], pc = svrow[32 + lc], px = svrow[XC];
+                v0 = pa * inv; v1 = pb * inv; v2 = pc * inv;
+                const double vx = px * inv;
+                const double tc0 = (c == XC) ? 0.0 : tcol;
+                double xbn = fma(delta, cm, xb);
+                double tcn = fma(-cm, vx, tc0);
+                if (l == r) { xbn = enter_val; tcn = -vx; }
+                xb = xbn; tcol = tcn;
+            }
+            pivoted = true;
+            rW = r; veW = readlane_i32(colvar, c); eloW = elo; ehiW = ehi;
+            cW = c; vlW = vl; nbW = leave_val;
+            pivots++;
+            if (vl == VTH) { status = QPN_SUCCESS; stop = true; }
+            else {
+                int vn;
+                const int k = vl < NBP ? vl : vl - NBP;
+                const int cls = readlane_i32(clsv, k);
+                int au = readlane_i32(satv, k);
+                if (vl < NBP) {
+                    au = uni(__double2hiint(rcr)) >= 0 ? 1 : 0; kW = k; auW = au;
+                    vn = NBP + k;
+                    sneg = au != 0;
+                    self_lim = QINF;
+                    if (cls == 2) { elo = 0.0; ehi = 0.0; }
+                    else if (au) { elo = -QINF; ehi = 0.0; }
+                    else { elo = 0.0; ehi = QINF; }
+                } else {
+                    vn = k;
+                    sneg = au != 0;
+                    self_lim = readlane_f64(rngv, k);
+                    if (cls == 2) sneg = false;
+                    elo = readlane_f64(lo0, k); ehi = readlane_f64(hi0, k);
+                }
+                cnext = (vn == veW) ? -1 : col_of(vn);
+                if (cnext < 0) { status = QPN_FAILURE; stop = true; }
+            }
+        }
+        // ---- write-back of the single-lane bookkeeping updates (a write that does not apply goes to idle lane 63)
+        if (l == rW) { rowvar = veW; lo = eloW; hi = ehiW; }
+        if (l == cW) colvar = vlW;
+        if (l == c) nbval = nbW;
+        if (l == kW) satv = auW;
+        if (stop) break;
+        // ---- the exchange (a bound flip changes no entry)
+        if (pivoted) {
+            const double *const up = sucol + lq * 12;
+            double ua[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) ua[k] = up[k];
+#define M_XCH(J, K) SDV(J, K) = fma(-ua[K], v##J, SDV(J, K));
+            FOR_JK(M_XCH)
+#undef M_XCH
+            // column c: T[i][c] = u_i * inv on the 4 lanes that own it (none when c is the extra column)
+            if (c < XC && lc == (c & 15)) {
+                const int Jc = c >> 4;
+#define M_COLFIX(J, K) SDV(J, K) = ua[K] * inv;
+                if (Jc == 0) { FOR_K(M_COLFIX, 0) } else if (Jc == 1) { FOR_K(M_COLFIX, 1) } else { FOR_K(M_COLFIX, 2) }
+#undef M_COLFIX
+            }
+            // row r: T[r][j] = -v_j on the 16 lanes that own it (v carries -inv at column c)
+            if (lq == rq) {
+#define M_ROWFIX(K) case K: SDV(0, K) = -v0; SDV(1, K) = -v1; SDV(2, K) = -v2; break;
+                switch (rsel) { M_ROWFIX(0) M_ROWFIX(1) M_ROWFIX(2) M_ROWFIX(3) M_ROWFIX(4) M_ROWFIX(5) M_ROWFIX(6) M_ROWFIX(7) M_ROWFIX(8) M_ROWFIX(9) M_ROWFIX(10) default: SDV(0, 11) = -v0; SDV(1, 11) = -v1; SDV(2, 11) = -v2; break; }
+#undef M_ROWFIX
+            }
+        }
+        c = cnext;
+        wsync();
+    }
+
+    // ---- read back: lambda_k, then x = W~ lambda - h -------------------------------------------------------------
+    wsync();
+    if (actb) sval[rowvar] = xb;
+    if (l <= XC) sval[colvar] = nbval;
+    wsync();
+    // x_l = (W~ lambda)_l - h_l, lane l <-> row l: W~ from the block buffer, lambda broadcast from sval
+    double wl = 0.0;
+    {
+        double w2 = 0.0;
+        const int ls = l < NP ? l : 0;
+#pragma unroll 8
+        for (int k = 0; k < NP; k += 2) {
+            wl = fma(sA[ls * SAS + k], sval[NBP + k], wl);
+            w2 = fma(sA[ls * SAS + k + 1], sval[NBP + k + 1], w2);
+        }
+        wl += w2;
+    }
+    // item order: rows < n are x, rows n.. are lambda (two rounds of 64 item rows)
+    double zk0 = 0.0, zk1 = 0.0;
+    {
+        const int i0 = l, i1 = 64 + l;
+        if (i0 < N) zk0 = i0 < n ? wl - kx : sval[NBP + (i0 - n)];
+        if (i1 < N) zk1 = sval[NBP + (i1 - n)];                  // (n <= 48 < 64: the second round holds multipliers only)
+    }
+    wsync();
+    if (l < N) sz[l] = zk0;
+    if (64 + l < N) sz[64 + l] = zk1;
+    wsync();
+
+    // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
+    int bad = 0;
+    double nres = 0.0;
+    const double tol = a.check_tol, ct = a.comp_tol;
+    auto check_row = [&](int k, double zk) {
+        const bool isx = k < n;
+        double rk = SQ(k);
+        if (isx) {
+            const double *qcol = Q_ + k;
+            double r2 = 0.0;
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+                double mv[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = qcol[(size_t)(j + q8) * n];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(mv[q8], sz[j + q8], rk); r2 = fma(mv[q8 + 1], sz[j + q8 + 1], r2); }
+            }
+            for (; j < n; ++j) rk = fma(qcol[(size_t)j * n], sz[j], rk);
+            {                                                                          // columns of lambda: -A'
+                const double *arow = A_ + (size_t)k * m;                                  // column k of Ad: A[i][k], i contiguous
+                int i = 0;
+                for (; i + 8 <= m; i += 8) {
+                    double av[8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) av[q8] = arow[i + q8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8 += 2) { r2 = fma(-av[q8], sz[n + i + q8], r2); rk = fma(-av[q8 + 1], sz[n + i + q8 + 1], rk); }
+                }
+                for (; i < m; ++i) r2 = fma(-arow[i], sz[n + i], r2);
+            }
+            rk += r2;
+        } else {
+            const int r = k - n;
+            double r2 = 0.0;
+            int j = 0;
+            const double *acol = A_ + r;                                                  // row r of Ad: A[r][j], lanes <-> r contiguous
+            for (; j + 8 <= n; j += 8) {
+                double av[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) av[q8] = acol[(size_t)(j + q8) * m];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(av[q8], sz[j + q8], rk); r2 = fma(av[q8 + 1], sz[j + q8 + 1], r2); }
+            }
+            for (; j < n; ++j) rk = fma(acol[(size_t)j * m], sz[j], rk);
+            rk += r2;
+        }
+        const int gk = !isx;
+        const double lk = gk ? a.nd.l[(size_t)b * m + (k - n)] : -QINF, uk = gk ? a.nd.u[(size_t)b * m + (k - n)] : QINF;
+        const double pp = gk ? rk : zk, dv = gk ? zk : rk;
+        if (dv > tol && fabs(pp - lk) > tol) bad++;
+        if (dv < -tol && fabs(pp - uk) > tol) bad++;
+        if (pp - lk < -tol) bad++;
+        if (pp - uk > tol) bad++;
+        if (isnan(pp) || isnan(dv)) bad++;
+        double tt = pp - dv;
+        if (tt < lk) tt = lk;
+        if (tt > uk) tt = uk;
+        double e = fabs(pp - tt);
+        if (isnan(e)) e = QINF;
+        nres = fmax(nres, e);
+        unsigned mask = 0;
+        auto approx = [&](double x, double y) { return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= ct); };
+        if (!approx(lk, uk)) {
+            if (approx(pp, lk) && dv >= -ct) mask |= 1u;
+            if (lk - ct <= pp && pp <= uk + ct && fabs(dv) <= ct) mask |= 2u;
+            if (approx(pp, uk) && dv <= ct) mask |= 4u;
+        } else mask = 8u;
+        if (gk) mask <<= 4;
+        a.z[(size_t)b * N + k] = zk;
+        if (a.x && isx) {
+            const size_t xo = (size_t)b * (size_t)a.stride_x + k;
+            a.x[xo] = zk;
+            for (int q = 0; q < a.n_mirror; ++q) a.mirror[q][xo] = zk;
+        }
+        if (a.active) a.active[(size_t)b * N + k] = (uint8_t)mask;
+    };
+    if (l < N) check_row(l, zk0);
+    if (64 + l < N) check_row(64 + l, zk1);
+    bad = wave_sum_i32(bad);
+    nres = wave_max_f64(nres);
+    if (bad > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
+    if (l == 0) {
+        a.status[b] = status;
+        if (a.resid) a.resid[b] = nres;
+        if (a.pivots) a.pivots[b] = pivots;
+        if (a.sched_key) { const int k0 = a.sched_key[b]; a.sched_key[b] = k0 > 0 ? k0 - (k0 >> 5) + pivots : 32 * pivots; }
+    }
+#undef SQ
+#undef SDV
+#undef FOR_K
+#undef FOR_JK
+}
+
+} // namespace
+
+bool qpn_schur48_shape(int n, int m) { return n >= 1 && m >= 0 && n <= 48 && m <= 48 && (n > 32 || m > 32); }
+
+hipError_t qpn_launch_avi_solve_schur48_nodes(const AviBatchArgs &a, hipStream_t stream)
+{
+    if (a.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(avi_solve_schur48, dim3((unsigned)a.batch), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}

@@ -140,7 +140,7 @@ int qpn_ctx_create(int device_id, qpn_ctx **out)
     }
     ctx->stream = ctx->own_stream;
     // developer default of the mid-size route, read ONCE here (never per call); qpn_ctx_set_option overrides it
-    if (const char *e = getenv("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '2' && !e[1]) ctx->mid_route = e[0] - '0'; }
+    if (const char *e = getenv("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '3' && !e[1]) ctx->mid_route = e[0] - '0'; }
     *out = ctx;
     return QPN_OK;
 }
@@ -150,7 +150,7 @@ int qpn_ctx_set_option(qpn_ctx *ctx, int32_t option, int32_t value)
     if (!ctx) return QPN_ERR_ARG;
     switch (option) {
     case QPN_OPT_MID_ROUTE:
-        if (value < 0 || value > 2) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_MID_ROUTE takes 0, 1 or 2");
+        if (value < 0 || value > 3) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_MID_ROUTE takes 0, 1, 2 or 3");
         ctx->mid_route = value;
         return QPN_OK;
     case QPN_OPT_BIG_ROUTE:
@@ -838,6 +838,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                 }
             }
             if (qpn_schur_wg2_shape(n, m)) HIPCHK(ctx, qpn_launch_schur_wg2_nodes(a, s));
+            else if (ctx->mid_route == 3 && qpn_schur48_shape(n, m)) HIPCHK(ctx, qpn_launch_avi_solve_schur48_nodes(a, s));
             else HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
             a.x = nullptr; a.n_mirror = 0;
         } else HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
@@ -912,7 +913,7 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
     // mid-size nodes: the fused workgroup kernel (no workspace) or, for A/B runs, the routes it replaced (ctx->mid_route)
     const bool mid_ok = qpn_schur_mid_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
     const bool wg2_ok = qpn_schur_wg2_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
-    const bool wg_shape = ctx->mid_route == 1 && (mid_ok || wg2_ok);
+    const bool wg_shape = (ctx->mid_route == 1 || ctx->mid_route == 3) && (mid_ok || wg2_ok);
     const bool mid_shape = ctx->mid_route == 2 && mid_ok;
     const bool need_ws = !(h && (mfma_shape || mid_shape || wg_shape) && h->decl_state == 2);
 

@@ -124,7 +124,10 @@ hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream
 
 // qpn_avi_schur_wg.hip: the same node records in ONE fused workgroup kernel (crash, Lemke, read-back, post-check; no workspace)
 bool qpn_schur_wg_shape(int n, int m);
-hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream);              // a.nd set; declined nodes keep status -1
+hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream);
+// one wavefront per node, 33 <= max(n, m) <= 48 (qpn_avi_schur48.hip)
+bool qpn_schur48_shape(int n, int m);
+hipError_t qpn_launch_avi_solve_schur48_nodes(const AviBatchArgs &a, hipStream_t stream);              // a.nd set; declined nodes keep status -1
 
 // qpn_avi_schur_wg2.hip: the fused workgroup kernel for n, m <= 128 (one of them > 64): two wavefronts per row tile
 bool qpn_schur_wg2_shape(int n, int m);
