@@ -30,6 +30,12 @@ __device__ __forceinline__ double rcp64_(double x)
     const double e = fma(-x, r, 1.0);
     return fma(r, e, r);
 }
+#ifdef QPN_STAMPS
+#define STAMP(slot) do { unsigned long long now__ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); stamp_acc[slot] += now__ - stamp_last; stamp_last = now__; } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 constexpr int T3 = 3, NP = 48, SAS = 50;       // tiles a side, padded size, column stride of the LDS block buffer
 
 __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
@@ -42,6 +48,10 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         if (l == 0) { a.status[b] = -1; if (a.decl_count) atomicAdd(a.decl_count, 1); }
     };
     if (!(n >= 1 && n <= NP && m >= 0 && m <= NP)) { decline(); return; }
+#ifdef QPN_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 
     // block buffer: Qd while the H tiles are built, then Ad ([column of x][constraint row]) for the rest of the solve; the two
     // spare slots per column hold q in item order
@@ -67,7 +77,13 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         const double *col = isx ? R_ + it : B_ + (it - n);
         const size_t cs = isx ? (size_t)n : (size_t)m;
         double s = isx ? a.nd.qd[(size_t)b * n + it] : 0.0;
-        for (int k = 0; k < np_; ++k) s = fma(col[(size_t)k * cs], w_[k], s);
+        for (int k0 = 0; k0 < np_; k0 += 8) {            // eight terms in flight together, added in ascending order
+            double rv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[k] = col[k0 + k < np_ ? (size_t)(k0 + k) * cs : 0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = (k0 + k < np_) ? fma(rv[k], w_[k0 + k < np_ ? k0 + k : 0], s) : s;
+        }
         SQ(it) = s;
     }
     // ---- Qd -> LDS (zero-padded), column by column: lane <-> row, 16 columns in flight
@@ -130,6 +146,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
                 const int rr = 16 * I + 4 * g + lq, ck = 16 * J + lc;
                 T[I][T3 + J][g] = sA[rr * SAS + ck];                   // zero outside n x m already
             }
+    STAMP(0);   // loads + tiles
     // extra column: g = q of the x rows, lane l <-> row l (lanes >= 48 idle)
     double kx = (l < n) ? SQ(l) : 0.0;
     const double mscale = wave_max_f64(mabs);
@@ -212,6 +229,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         }
     }
     if (fail) { decline(); return; }
+    STAMP(1);   // stage A
 
     // ---- S = A W~ on the matrix cores (W~ = rows of x, an aligned group of 4 rows is a B operand), c = b - A h
     d4 SB[T3][T3];
@@ -265,6 +283,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) sA[(16 * I + 4 * g + lq) * SAS + 16 * Jb + lc] = T[I][T3 + Jb][g];
 
+    STAMP(2);   // S product, c, W~ parked
     // ================= Stage B: Lemke on the Schur dictionary (48 pairs, tile layout) =================
     // pair k (k < 48) <-> item row n + k:  p_k = (S lambda + c)_k in [l_k, u_k],  d_k = lambda_k.
     // ids: p_k -> k, d_k -> 48 + k, artificial -> 96; column index 48 = the extra (covering) column.
@@ -278,14 +297,19 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     int rowvar = actb ? l : -1, colvar = actb ? NBP + l : (l == XC ? VTH : -1);
     double nbval = 0.0, tcol = 0.0;
     wsync();
-    // the dictionary: SDV(Jb, 4 Ib + g) = row 16 Ib + 4 g + lq, column 16 Jb + lc -- 36 NAMED scalars (an array indexed under a
-    // switch is turned into a dynamically indexed array by the optimiser, and that lives in scratch memory)
-#define SDV(J, K) sd_##J##_##K
+    // the dictionary: SJ<Jb>[4 Ib + g] = row 16 Ib + 4 g + lq, column 16 Jb + lc -- three 16-element register vectors (12 used):
+    // static element accesses are plain registers, the pivot row is read with a wave-uniform DYNAMIC index (s_set_gpr_idx:
+    // no branch tree, no scratch), and the exchange is one asm block per column tile, so that every dictionary register has ONE
+    // definition per iteration (a C++ switch over named scalars compiled to 334 register copies per pivot)
+    typedef double d16 __attribute__((ext_vector_type(16)));
+    d16 SJ0, SJ1, SJ2;
+#define SDV(J, K) SJ##J[K]
 #define FOR_K(M, J) M(J, 0) M(J, 1) M(J, 2) M(J, 3) M(J, 4) M(J, 5) M(J, 6) M(J, 7) M(J, 8) M(J, 9) M(J, 10) M(J, 11)
 #define FOR_JK(M) FOR_K(M, 0) FOR_K(M, 1) FOR_K(M, 2)
-#define M_DECL(J, K) double SDV(J, K) = SB[(K) >> 2][J][(K) & 3];
-    FOR_JK(M_DECL)
-#undef M_DECL
+#define M_INIT(J, K) SDV(J, K) = SB[(K) >> 2][J][(K) & 3];
+    FOR_JK(M_INIT)
+#undef M_INIT
+    SJ0[12] = SJ0[13] = SJ0[14] = SJ0[15] = 0.0; SJ1[12] = SJ1[13] = SJ1[14] = SJ1[15] = 0.0; SJ2[12] = SJ2[13] = SJ2[14] = SJ2[15] = 0.0;
     auto col_of = [&](int v) -> int { return wave_first(colvar == v); };
     int pivots = n;
     const int max_piv = a.max_pivots > 0 ? a.max_pivots : 50 * N + 100;
@@ -383,10 +407,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
             rq = r & 3;
             rsel = ((r >> 4) << 2) | ((r >> 2) & 3);              // register 4 Ib + g of row r
             {
-                double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-#define M_PICK(K) case K: p0 = SDV(0, K); p1 = SDV(1, K); p2 = SDV(2, K); break;
-                switch (rsel) { M_PICK(0) M_PICK(1) M_PICK(2) M_PICK(3) M_PICK(4) M_PICK(5) M_PICK(6) M_PICK(7) M_PICK(8) M_PICK(9) M_PICK(10) default: p0 = SDV(0, 11); p1 = SDV(1, 11); p2 = SDV(2, 11); break; }
-#undef M_PICK
+                const double p0 = SJ0[rsel], p1 = SJ1[rsel], p2 = SJ2[rsel];          // uniform dynamic register index
                 if (lq == rq) { svrow[lc] = p0; svrow[16 + lc] = p1; svrow[32 + lc] = p2; }
             }
             wsync();
@@ -447,33 +468,64 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         if (l == c) nbval = nbW;
         if (l == kW) satv = auW;
         if (stop) break;
-        // ---- the exchange (a bound flip changes no entry)
-        if (pivoted) {
-            const double *const up = sucol + lq * 12;
-            double ua[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) ua[k] = up[k];
-#define M_XCH(J, K) SDV(J, K) = fma(-ua[K], v##J, SDV(J, K));
-            FOR_JK(M_XCH)
-#undef M_XCH
-            // column c: T[i][c] = u_i * inv on the 4 lanes that own it (none when c is the extra column)
-            if (c < XC && lc == (c & 15)) {
-                const int Jc = c >> 4;
-#define M_COLFIX(J, K) SDV(J, K) = ua[K] * inv;
-                if (Jc == 0) { FOR_K(M_COLFIX, 0) } else if (Jc == 1) { FOR_K(M_COLFIX, 1) } else { FOR_K(M_COLFIX, 2) }
-#undef M_COLFIX
-            }
-            // row r: T[r][j] = -v_j on the 16 lanes that own it (v carries -inv at column c)
-            if (lq == rq) {
-#define M_ROWFIX(K) case K: SDV(0, K) = -v0; SDV(1, K) = -v1; SDV(2, K) = -v2; break;
-                switch (rsel) { M_ROWFIX(0) M_ROWFIX(1) M_ROWFIX(2) M_ROWFIX(3) M_ROWFIX(4) M_ROWFIX(5) M_ROWFIX(6) M_ROWFIX(7) M_ROWFIX(8) M_ROWFIX(9) M_ROWFIX(10) default: SDV(0, 11) = -v0; SDV(1, 11) = -v1; SDV(2, 11) = -v2; break; }
-#undef M_ROWFIX
-            }
+        // ---- the exchange: ONE asm block per column tile, run every iteration (a bound flip runs it with v = 0 and empty lane
+        // masks: a no-op), so the dictionary registers are never copied, selected or spilled whatever the control flow around
+        {
+            const d4 *const up = reinterpret_cast<const d4 *>(sucol + lq * 12);
+            const d4 ua = up[0], ub = up[1], uc = up[2];
+            const double inv_s = udbl(inv);
+            const int cx = uni(pivoted ? c : XC), rs = uni(rsel);
+            const unsigned long long mrow = pivoted ? 0xFFFFull << (16 * rq) : 0ull;
+            const unsigned long long mcol = (pivoted && cx < XC) ? 0x0001000100010001ull << (cx & 15) : 0ull;
+#define M_XBLOCK(J, VJ)                                                                                                             \
+            asm volatile(                                                                                                           \
+                "v_fma_f64 %[s0], -%[u0], %[v], %[s0]\n\tv_fma_f64 %[s1], -%[u1], %[v], %[s1]\n\t"                                  \
+                "v_fma_f64 %[s2], -%[u2], %[v], %[s2]\n\tv_fma_f64 %[s3], -%[u3], %[v], %[s3]\n\t"                                  \
+                "v_fma_f64 %[s4], -%[u4], %[v], %[s4]\n\tv_fma_f64 %[s5], -%[u5], %[v], %[s5]\n\t"                                  \
+                "v_fma_f64 %[s6], -%[u6], %[v], %[s6]\n\tv_fma_f64 %[s7], -%[u7], %[v], %[s7]\n\t"                                  \
+                "v_fma_f64 %[s8], -%[u8], %[v], %[s8]\n\tv_fma_f64 %[s9], -%[u9], %[v], %[s9]\n\t"                                  \
+                "v_fma_f64 %[s10], -%[u10], %[v], %[s10]\n\tv_fma_f64 %[s11], -%[u11], %[v], %[s11]\n\t"                            \
+                /* column c (this tile's iff c >> 4 == J): T[i][c] = u_i * inv on the 4 lanes that own it */                       \
+                "s_cmp_eq_u32 %[ct], " #J "\n\ts_cbranch_scc0 20f\n\t"                                                              \
+                "s_mov_b64 exec, %[mc]\n\t"                                                                                         \
+                "v_mul_f64 %[s0], %[u0], %[iv]\n\tv_mul_f64 %[s1], %[u1], %[iv]\n\tv_mul_f64 %[s2], %[u2], %[iv]\n\t"             \
+                "v_mul_f64 %[s3], %[u3], %[iv]\n\tv_mul_f64 %[s4], %[u4], %[iv]\n\tv_mul_f64 %[s5], %[u5], %[iv]\n\t"             \
+                "v_mul_f64 %[s6], %[u6], %[iv]\n\tv_mul_f64 %[s7], %[u7], %[iv]\n\tv_mul_f64 %[s8], %[u8], %[iv]\n\t"             \
+                "v_mul_f64 %[s9], %[u9], %[iv]\n\tv_mul_f64 %[s10], %[u10], %[iv]\n\tv_mul_f64 %[s11], %[u11], %[iv]\n"            \
+                "20:\n\t"                                                                                                           \
+                /* row r: T[r][j] = -v_j on the 16 lanes that own it (v carries -inv at column c) */                                \
+                "s_mov_b64 exec, %[mr]\n\t"                                                                                         \
+                "s_cmp_gt_i32 %[rs], 5\n\ts_cbranch_scc1 26f\n\t"                                                                  \
+                "s_cmp_gt_i32 %[rs], 2\n\ts_cbranch_scc1 23f\n\t"                                                                  \
+                "s_cmp_eq_u32 %[rs], 0\n\ts_cbranch_scc0 21f\n\tv_mul_f64 %[s0], %[v], -1.0\n\ts_branch 32f\n"                     \
+                "21:\n\ts_cmp_eq_u32 %[rs], 1\n\ts_cbranch_scc0 22f\n\tv_mul_f64 %[s1], %[v], -1.0\n\ts_branch 32f\n"             \
+                "22:\n\tv_mul_f64 %[s2], %[v], -1.0\n\ts_branch 32f\n"                                                             \
+                "23:\n\ts_cmp_eq_u32 %[rs], 3\n\ts_cbranch_scc0 24f\n\tv_mul_f64 %[s3], %[v], -1.0\n\ts_branch 32f\n"             \
+                "24:\n\ts_cmp_eq_u32 %[rs], 4\n\ts_cbranch_scc0 25f\n\tv_mul_f64 %[s4], %[v], -1.0\n\ts_branch 32f\n"             \
+                "25:\n\tv_mul_f64 %[s5], %[v], -1.0\n\ts_branch 32f\n"                                                             \
+                "26:\n\ts_cmp_gt_i32 %[rs], 8\n\ts_cbranch_scc1 29f\n\t"                                                          \
+                "s_cmp_eq_u32 %[rs], 6\n\ts_cbranch_scc0 27f\n\tv_mul_f64 %[s6], %[v], -1.0\n\ts_branch 32f\n"                     \
+                "27:\n\ts_cmp_eq_u32 %[rs], 7\n\ts_cbranch_scc0 28f\n\tv_mul_f64 %[s7], %[v], -1.0\n\ts_branch 32f\n"             \
+                "28:\n\tv_mul_f64 %[s8], %[v], -1.0\n\ts_branch 32f\n"                                                             \
+                "29:\n\ts_cmp_eq_u32 %[rs], 9\n\ts_cbranch_scc0 30f\n\tv_mul_f64 %[s9], %[v], -1.0\n\ts_branch 32f\n"             \
+                "30:\n\ts_cmp_eq_u32 %[rs], 10\n\ts_cbranch_scc0 31f\n\tv_mul_f64 %[s10], %[v], -1.0\n\ts_branch 32f\n"           \
+                "31:\n\tv_mul_f64 %[s11], %[v], -1.0\n"                                                                            \
+                "32:\n\ts_mov_b64 exec, -1"                                                                                        \
+                : [s0] "+v"(SDV(J, 0)), [s1] "+v"(SDV(J, 1)), [s2] "+v"(SDV(J, 2)), [s3] "+v"(SDV(J, 3)), [s4] "+v"(SDV(J, 4)),    \
+                  [s5] "+v"(SDV(J, 5)), [s6] "+v"(SDV(J, 6)), [s7] "+v"(SDV(J, 7)), [s8] "+v"(SDV(J, 8)), [s9] "+v"(SDV(J, 9)),    \
+                  [s10] "+v"(SDV(J, 10)), [s11] "+v"(SDV(J, 11))                                                                  \
+                : [u0] "v"(ua[0]), [u1] "v"(ua[1]), [u2] "v"(ua[2]), [u3] "v"(ua[3]), [u4] "v"(ub[0]), [u5] "v"(ub[1]),            \
+                  [u6] "v"(ub[2]), [u7] "v"(ub[3]), [u8] "v"(uc[0]), [u9] "v"(uc[1]), [u10] "v"(uc[2]), [u11] "v"(uc[3]),          \
+                  [v] "v"(VJ), [iv] "s"(inv_s), [mc] "s"(mcol), [mr] "s"(mrow), [ct] "s"(cx >> 4), [rs] "s"(rs)                    \
+                : "scc");
+            M_XBLOCK(0, v0) M_XBLOCK(1, v1) M_XBLOCK(2, v2)
+#undef M_XBLOCK
         }
         c = cnext;
         wsync();
     }
 
+    STAMP(3);   // Lemke
     // ---- read back: lambda_k, then x = W~ lambda - h -------------------------------------------------------------
     wsync();
     if (actb) sval[rowvar] = xb;
@@ -503,6 +555,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     if (64 + l < N) sz[64 + l] = zk1;
     wsync();
 
+    STAMP(4);   // read-back
     // ---- post-check against the ORIGINAL blocks, src/avi.jl:71-76 / :148-156 -------------------------------
     int bad = 0;
     double nres = 0.0;
@@ -591,6 +644,10 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         if (a.pivots) a.pivots[b] = pivots;
         if (a.sched_key) { const int k0 = a.sched_key[b]; a.sched_key[b] = k0 > 0 ? k0 - (k0 >> 5) + pivots : 32 * pivots; }
     }
+    STAMP(5);   // post-check + stores
+#ifdef QPN_STAMPS
+    if (a.stamps && l == 0) for (int i = 0; i < 8; ++i) a.stamps[(size_t)b * 8 + i] = stamp_acc[i];
+#endif
 #undef SQ
 #undef SDV
 #undef FOR_K
