@@ -86,7 +86,8 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         }
         SQ(it) = s;
     }
-    // ---- Qd -> LDS (zero-padded), column by column: lane <-> row, 16 columns in flight
+    // ---- Qd -> LDS (zero-padded), column by column: lane <-> row, 16 columns in flight (all 48 + 48 columns of Qd and Ad in
+    // flight at once shorten a lone node by 2 % and cost 4 % at 4 000 nodes: the resident waves' bursts collide)
     double mabs = 0.0;
 #pragma unroll 1
     for (int c0 = 0; c0 < NP; c0 += 16) {
@@ -410,10 +411,9 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
                 const double p0 = SJ0[rsel], p1 = SJ1[rsel], p2 = SJ2[rsel];          // uniform dynamic register index
                 if (lq == rq) { svrow[lc] = p0; svrow[16 + lc] = p1; svrow[32 + lc] = p2; }
             }
-            wsync();
             // the row's extra-column entry rides along as "column 48"; the entry of the pivot column itself is replaced by -1 so
             // that row * inv carries -inv there
-            if (l == r) { svrow[XC] = tcol; svrow[c] = -1.0; }
+            if (l == r) { svrow[XC] = tcol; svrow[c] = -1.0; }      // (one lane, program order after the owners' stores above)
             double step = readlane_f64(dd, r);
             if (step < 0.0) step = 0.0;
             const double leave_val = readlane_f64(tb, r);
@@ -462,6 +462,10 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
                 if (cnext < 0) { status = QPN_FAILURE; stop = true; }
             }
         }
+        // the exchange's column operands: requested here so that the LDS trip overlaps the write-backs below
+        const d4 *const up = reinterpret_cast<const d4 *>(sucol + lq * 12);
+        const d4 ua = up[0], ub = up[1], uc = up[2];
+        __builtin_amdgcn_sched_barrier(0);
         // ---- write-back of the single-lane bookkeeping updates (a write that does not apply goes to idle lane 63)
         if (l == rW) { rowvar = veW; lo = eloW; hi = ehiW; }
         if (l == cW) colvar = vlW;
@@ -471,8 +475,6 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         // ---- the exchange: ONE asm block per column tile, run every iteration (a bound flip runs it with v = 0 and empty lane
         // masks: a no-op), so the dictionary registers are never copied, selected or spilled whatever the control flow around
         {
-            const d4 *const up = reinterpret_cast<const d4 *>(sucol + lq * 12);
-            const d4 ua = up[0], ub = up[1], uc = up[2];
             const double inv_s = udbl(inv);
             const int cx = uni(pivoted ? c : XC), rs = uni(rsel);
             const unsigned long long mrow = pivoted ? 0xFFFFull << (16 * rq) : 0ull;
