@@ -243,9 +243,10 @@ int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period);
 
 /* Per-context options that select between kernel routes with IDENTICAL contracts (A/B measurements, tests of a route
  * against the one it replaced).  Results never depend on them beyond rounding.
- *   QPN_OPT_MID_ROUTE  node records with n, m <= 128 and one of them > 32 (qpn_solve_nodes*): 1 = one fused workgroup kernel
- *                      per node (default), 2 = round 2's routes (three kernels with an HBM workspace up to 64, the route of
- *                      large nodes beyond), 0 = the route of large nodes.
+ *   QPN_OPT_MID_ROUTE  node records with n, m <= 128 and one of them > 32 (qpn_solve_nodes*): 1 = one fused kernel per node
+ *                      (default: ONE wavefront per node for max(n, m) <= 48, one workgroup per node beyond), 3 = the workgroup
+ *                      kernel also for 33 .. 48, 2 = round 2's routes (three kernels with an HBM workspace up to 64, the route
+ *                      of large nodes beyond), 0 = the route of large nodes.
  *                      The environment variable QPN_NODES_MID, read once by qpn_ctx_create, presets it.
  *   QPN_OPT_BIG_ROUTE  node records with 64 < n <= 256 and m <= 256 beyond the sizes above (BASELINE config 5): 1 = the blocked
  *                      matrix-core crash straight from the records (default), 0 = round 2's route over an assembled M.

@@ -36,7 +36,7 @@ __device__ __forceinline__ double rcp64_(double x)
 #define STAMP(slot) do { } while (0)
 #endif
 
-constexpr int T3 = 3, NP = 48, SAS = 50;       // tiles a side, padded size, column stride of the LDS block buffer
+constexpr int T3 = 3, NP = 48, SAS = 49;       // tiles a side, padded size, column stride of the LDS block buffer (odd: conflict-free)
 
 __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 {
@@ -53,17 +53,19 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    // block buffer: Qd while the H tiles are built, then Ad ([column of x][constraint row]) for the rest of the solve; the two
-    // spare slots per column hold q in item order
+    // block buffer: Qd while the H tiles are built, then Ad ([column of x][constraint row]) through the S product, then W~ for the
+    // read-back, then the solution in item order.  18 816 + 1 664 B = 20 480 B: EIGHT wavefronts per CU (two per SIMD); q never
+    // goes to LDS (three values per lane, in registers).
     __shared__ __attribute__((aligned(32))) double sA[NP * SAS];
-    __shared__ __attribute__((aligned(32))) double sbuf[384];
-#define SQ(i) sA[((i) >> 1) * SAS + NP + ((i) & 1)]
+    __shared__ __attribute__((aligned(32))) double sbuf[208];
     double *const sU = sbuf;                    // Stage A: pivot columns, [48][4]
     double *const sP = sbuf + 192;              // Stage A: the raw 4 x 4 pivot block
-    double *const sucol = sbuf;                 // Stage B: entering column, permuted [4][12] (+ the extra entry)
+    double *const sh = sbuf;                    // h for c = b - A h [48]
+    double *const sucol = sbuf;                 // Stage B: entering column, permuted [4][12]
     double *const svrow = sbuf + 64;            // Stage B: pivot row [49]
     double *const sval = sbuf;                  // read-back: values by variable id [97]
-    double *const sz = sbuf + 256;              // h, then the solution in item order [96]
+    // the solution in item order lies over the first two columns of the block buffer (entries 48 of a column are skipped)
+#define SZ(i) sA[(i) + ((i) >= NP ? 1 : 0)]
 
     const double *Q_ = a.nd.Qd + (size_t)b * n * n;
     const double *A_ = a.nd.Ad + (size_t)b * m * n;
@@ -71,21 +73,24 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     const double *B_ = a.nd.B + (size_t)b * m * np_;
     const double *w_ = a.nd.w + (size_t)b * (size_t)a.nd.stride_w;
 
-    // ---- q = [qd + R w; B w] in item order (two rounds of 64 rows), the p terms in ascending order
-    for (int it = l; it < N; it += 64) {
-        const bool isx = it < n;
-        const double *col = isx ? R_ + it : B_ + (it - n);
-        const size_t cs = isx ? (size_t)n : (size_t)m;
-        double s = isx ? a.nd.qd[(size_t)b * n + it] : 0.0;
-        for (int k0 = 0; k0 < np_; k0 += 8) {            // eight terms in flight together, added in ascending order
+    // ---- q = [qd + R w; B w]: item rows l and 64 + l (for the post-check) and row n + l (c of pair l), the p terms in ascending
+    // order, eight in flight together
+    auto qterm = [&](int it) -> double {
+        const bool in = it < N, isx = it < n;
+        const int its = in ? it : 0;
+        const double *col = (isx || !in) ? R_ + (isx ? its : 0) : B_ + (its - n);
+        const size_t cs = (isx || !in) ? (size_t)n : (size_t)m;
+        double s = (in && isx) ? a.nd.qd[(size_t)b * n + its] : 0.0;
+        for (int k0 = 0; k0 < np_; k0 += 8) {
             double rv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) rv[k] = col[k0 + k < np_ ? (size_t)(k0 + k) * cs : 0];
+            for (int k = 0; k < 8; ++k) rv[k] = col[(in && k0 + k < np_) ? (size_t)(k0 + k) * cs : 0];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s = (k0 + k < np_) ? fma(rv[k], w_[k0 + k < np_ ? k0 + k : 0], s) : s;
+            for (int k = 0; k < 8; ++k) s = (in && k0 + k < np_) ? fma(rv[k], w_[k0 + k < np_ ? k0 + k : 0], s) : s;
         }
-        SQ(it) = s;
-    }
+        return s;
+    };
+    const double qv0 = qterm(l), qv1 = (N > 64) ? qterm(64 + l) : 0.0, qvc = (l < m) ? qterm(n + l) : 0.0;
     // ---- Qd -> LDS (zero-padded), column by column: lane <-> row, 16 columns in flight (all 48 + 48 columns of Qd and Ad in
     // flight at once shorten a lone node by 2 % and cost 4 % at 4 000 nodes: the resident waves' bursts collide)
     double mabs = 0.0;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
             }
     STAMP(0);   // loads + tiles
     // extra column: g = q of the x rows, lane l <-> row l (lanes >= 48 idle)
-    double kx = (l < n) ? SQ(l) : 0.0;
+    double kx = (l < n) ? qv0 : 0.0;
     const double mscale = wave_max_f64(mabs);
     const double diag_thr = 1e-4 * (mscale > 1.0 ? mscale : 1.0);
 
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 #pragma unroll
             for (int Jb = 0; Jb < T3; ++Jb) SB[Ib][Jb] = z4;
     }
-    if (l < NP) sz[l] = kx;
+    if (l < NP) sh[l] = kx;
     // bounds of pair l: requested here so that the round trip hides behind the MFMAs
     double lo = -QINF, hi = QINF;
     if (l < m) { lo = a.nd.l[(size_t)b * m + l]; hi = a.nd.u[(size_t)b * m + l]; }
@@ -265,11 +270,11 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     {
         const bool lowr = l < m;
         const int ls = lowr ? l : 0;
-        double acc = lowr ? SQ(n + ls) : 0.0, acc2 = 0.0;
+        double acc = lowr ? qvc : 0.0, acc2 = 0.0;
 #pragma unroll 8
         for (int j = 0; j < NP; j += 2) {
-            acc = fma(-sA[j * SAS + ls], sz[j], acc);
-            acc2 = fma(-sA[(j + 1) * SAS + ls], sz[j + 1], acc2);
+            acc = fma(-sA[j * SAS + ls], sh[j], acc);
+            acc2 = fma(-sA[(j + 1) * SAS + ls], sh[j + 1], acc2);
         }
         xb = lowr ? acc + acc2 : 0.0;
     }
@@ -553,8 +558,8 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         if (i1 < N) zk1 = sval[NBP + (i1 - n)];                  // (n <= 48 < 64: the second round holds multipliers only)
     }
     wsync();
-    if (l < N) sz[l] = zk0;
-    if (64 + l < N) sz[64 + l] = zk1;
+    if (l < N) SZ(l) = zk0;
+    if (64 + l < N) SZ(64 + l) = zk1;
     wsync();
 
     STAMP(4);   // read-back
@@ -562,9 +567,9 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     int bad = 0;
     double nres = 0.0;
     const double tol = a.check_tol, ct = a.comp_tol;
-    auto check_row = [&](int k, double zk) {
+    auto check_row = [&](int k, double zk, double qk) {
         const bool isx = k < n;
-        double rk = SQ(k);
+        double rk = qk;
         if (isx) {
             const double *qcol = Q_ + k;
             double r2 = 0.0;
@@ -574,9 +579,9 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 #pragma unroll
                 for (int q8 = 0; q8 < 8; ++q8) mv[q8] = qcol[(size_t)(j + q8) * n];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(mv[q8], sz[j + q8], rk); r2 = fma(mv[q8 + 1], sz[j + q8 + 1], r2); }
+                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(mv[q8], SZ(j + q8), rk); r2 = fma(mv[q8 + 1], SZ(j + q8 + 1), r2); }
             }
-            for (; j < n; ++j) rk = fma(qcol[(size_t)j * n], sz[j], rk);
+            for (; j < n; ++j) rk = fma(qcol[(size_t)j * n], SZ(j), rk);
             {                                                                          // columns of lambda: -A'
                 const double *arow = A_ + (size_t)k * m;                                  // column k of Ad: A[i][k], i contiguous
                 int i = 0;
@@ -585,9 +590,9 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 #pragma unroll
                     for (int q8 = 0; q8 < 8; ++q8) av[q8] = arow[i + q8];
 #pragma unroll
-                    for (int q8 = 0; q8 < 8; q8 += 2) { r2 = fma(-av[q8], sz[n + i + q8], r2); rk = fma(-av[q8 + 1], sz[n + i + q8 + 1], rk); }
+                    for (int q8 = 0; q8 < 8; q8 += 2) { r2 = fma(-av[q8], SZ(n + i + q8), r2); rk = fma(-av[q8 + 1], SZ(n + i + q8 + 1), rk); }
                 }
-                for (; i < m; ++i) r2 = fma(-arow[i], sz[n + i], r2);
+                for (; i < m; ++i) r2 = fma(-arow[i], SZ(n + i), r2);
             }
             rk += r2;
         } else {
@@ -600,9 +605,9 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 #pragma unroll
                 for (int q8 = 0; q8 < 8; ++q8) av[q8] = acol[(size_t)(j + q8) * m];
 #pragma unroll
-                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(av[q8], sz[j + q8], rk); r2 = fma(av[q8 + 1], sz[j + q8 + 1], r2); }
+                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(av[q8], SZ(j + q8), rk); r2 = fma(av[q8 + 1], SZ(j + q8 + 1), r2); }
             }
-            for (; j < n; ++j) rk = fma(acol[(size_t)j * m], sz[j], rk);
+            for (; j < n; ++j) rk = fma(acol[(size_t)j * m], SZ(j), rk);
             rk += r2;
         }
         const int gk = !isx;
@@ -635,8 +640,8 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         }
         if (a.active) a.active[(size_t)b * N + k] = (uint8_t)mask;
     };
-    if (l < N) check_row(l, zk0);
-    if (64 + l < N) check_row(64 + l, zk1);
+    if (l < N) check_row(l, zk0, qv0);
+    if (64 + l < N) check_row(64 + l, zk1, qv1);
     bad = wave_sum_i32(bad);
     nres = wave_max_f64(nres);
     if (bad > 0 && status == QPN_SUCCESS) status = QPN_FAILURE;
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
 #ifdef QPN_STAMPS
     if (a.stamps && l == 0) for (int i = 0; i < 8; ++i) a.stamps[(size_t)b * 8 + i] = stamp_acc[i];
 #endif
-#undef SQ
+#undef SZ
 #undef SDV
 #undef FOR_K
 #undef FOR_JK

@@ -35,8 +35,8 @@ struct qpn_ctx {
     int32_t mirror_count = 0;
     double *mirror_peer[QPN_MAX_MIRRORS] = {};
     // route of mid-size node records (qpn_ctx_set_option QPN_OPT_MID_ROUTE; the environment variable QPN_NODES_MID, read ONCE
-    // when the context is created, sets the default): 1 the fused workgroup kernel, 2 round 2's three kernels, 0 the route of
-    // the large nodes
+    // when the context is created, sets the default): 1 the fused kernels (one wavefront per node up to 48, one workgroup per node
+    // beyond), 3 the workgroup kernel also for 33 .. 48, 2 round 2's three kernels, 0 the route of the large nodes
     int32_t mid_route = 1;
     // route of large node records (QPN_OPT_BIG_ROUTE): 1 the blocked crash straight from the records (qpn_avi_schur_big2.hip),
     // 0 round 2's route (M assembled, qpn_avi_schur_big.hip)
@@ -838,7 +838,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                 }
             }
             if (qpn_schur_wg2_shape(n, m)) HIPCHK(ctx, qpn_launch_schur_wg2_nodes(a, s));
-            else if (ctx->mid_route == 3 && qpn_schur48_shape(n, m)) HIPCHK(ctx, qpn_launch_avi_solve_schur48_nodes(a, s));
+            else if (ctx->mid_route == 1 && qpn_schur48_shape(n, m)) HIPCHK(ctx, qpn_launch_avi_solve_schur48_nodes(a, s));
             else HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
             a.x = nullptr; a.n_mirror = 0;
         } else HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));

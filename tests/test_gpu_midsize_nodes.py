@@ -1,6 +1,7 @@
-"""Mid-size node records (n, m <= 64, one of them > 32): the fused one-workgroup-per-node kernel of
-csrc/qpn_avi_schur_wg.hip (crash on the matrix cores straight from the records, Lemke spread over the workgroup's
-wavefronts, read-back and post-check from the records: ONE launch, no workspace) against
+"""Mid-size node records (n, m <= 64, one of them > 32): the fused kernels -- ONE wavefront per node up to max(n, m) = 48
+(csrc/qpn_avi_schur48.hip: the 32-class kernel with three tiles a side), one workgroup per node beyond
+(csrc/qpn_avi_schur_wg.hip: crash on the matrix cores straight from the records, Lemke spread over the workgroup's
+wavefronts; QPN_OPT_MID_ROUTE = 3 runs it for 33 .. 48 too) -- read-back and post-check from the records, ONE launch, no workspace, against
 * the oracle (status, active-set masks bit-exact, primals within 1e-9 relative: the bar of DESIGN.md section 2),
 * the two routes these sizes took before (qpn_ctx_set_option QPN_OPT_MID_ROUTE = 2: round 2's three kernels with an HBM
   workspace; = 0: assembled blocks + the workgroup crash of the large nodes): same statuses and masks, primals within 1e-9
@@ -42,7 +43,7 @@ def _same(res, ref, tol=1e-9):
 
 
 SHAPES = [(33, 33, 8), (40, 50, 3), (48, 48, 8), (64, 64, 8), (64, 5, 2), (5, 64, 2), (40, 20, 4), (33, 1, 0), (17, 64, 8),
-          (64, 33, 1), (49, 31, 5)]
+          (64, 33, 1), (49, 31, 5), (35, 47, 2), (10, 48, 3), (1, 40, 2), (48, 1, 1), (44, 44, 8)]
 
 
 @pytest.mark.parametrize("n,m,p", SHAPES)
@@ -55,7 +56,7 @@ def test_mid_nodes_against_oracle_and_previous_route(engine, oracle, n, m, p):
     ref = _oracle(oracle, rec, w)
     _same(res, ref)
     from qpn_amd._lib import OPT_MID_ROUTE
-    for route in (2, 0):
+    for route in (3, 2, 0):          # 3: the workgroup kernel also where one wavefront per node is the default (max(n, m) <= 48)
         engine.set_option(OPT_MID_ROUTE, route)
         try:
             old = engine.solve_nodes(*abi, w)
