@@ -269,7 +269,8 @@ end
 set_auto_schedule!(period::Integer) = (ccall((:qpn_ctx_set_auto_schedule, LIB), Cint, (Ptr{Cvoid}, Int32), ctx(), Int32(period)); nothing)
 clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), C_NULL, Int32(0), QPN_MEM_HOST); nothing)
 # kernel routes with identical contracts (A/B measurements; include/qpn_hip.h, QPN_OPT_*): MID_ROUTE 1 = fused workgroup kernel per
-# node of 33 .. 128 variables or constraints (default), 2 / 0 = the routes it replaced; BIG_ROUTE 1 = blocked crash straight from
+# node of 33 .. 128 variables or constraints (default; one wavefront per node up to 48), 3 = the workgroup kernel also below 49,
+# 2 / 0 = the routes it replaced; BIG_ROUTE 1 = blocked crash straight from
 # the records for nodes up to 256 x 256 (default), 0 = over an assembled M
 # SYM_ROUTE 1 = resident records whose Qd blocks are all bitwise symmetric take the kernel variants that use it (default), 0 = never.
 const QPN_OPT_MID_ROUTE = Int32(1)

@@ -11,7 +11,7 @@ from qpn_amd.engine import colmajor
 _lib.LIB_PATH = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "libqpn_hip_stamps.so")
 _lib._lib = None
 eng = qpn_amd.Engine(0)
-eng.set_option(_lib.OPT_MID_ROUTE, 3)
+eng.set_option(_lib.OPT_MID_ROUTE, 1)
 names = ["loads + tiles", "stage A", "S product, c, W~ parked", "Lemke", "read-back", "post-check + stores"]
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
 for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:

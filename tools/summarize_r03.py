@@ -34,25 +34,25 @@ v = pmc("calib_fetch/*/*counter_collection.csv", "FETCH_SIZE", "calib_read8")
 if v: cal["read8"] = (1 << 30) / 1024.0 / v[0]
 v = pmc("calib_write/*/*counter_collection.csv", "WRITE_SIZE", "calib_write8")
 if v: cal["write8"] = (64 << 20) / 1024.0 / v[0]
-f = pmc("pmc_fetch_mid48/*/*counter_collection.csv", "FETCH_SIZE", "schur_wg_nodes")
-wv = pmc("pmc_write_mid48/*/*counter_collection.csv", "WRITE_SIZE", "schur_wg_nodes")
+f = pmc("pmc_fetch_mid48/*/*counter_collection.csv", "FETCH_SIZE", "avi_solve_schur48")
+wv = pmc("pmc_write_mid48/*/*counter_collection.csv", "WRITE_SIZE", "avi_solve_schur48")
 summ = {"calibration_factor_known_over_reported": cal}
 if f and wv:
     fk = sum(f) / len(f); wk = sum(wv) / len(wv)
     n = m = 48; p = 8; nodes = 4000
     rec = 8 * (n * n + n * p + n + m * n + m * p + 2 * m) * nodes
     outb = (8 * (n + m) + (n + m) + 8 + 4 + 4) * nodes
-    summ["schur_wg_nodes<3,3> (n = m = 48, 4000 nodes per launch)"] = {
+    summ["avi_solve_schur48 (n = m = 48, 4000 nodes per launch)"] = {
         "launches": len(f), "FETCH_SIZE_KiB_raw": fk, "FETCH_bytes_corrected": fk * cal.get("read8", 2.0) * 1024.0,
         "WRITE_SIZE_bytes": wk * cal.get("write8", 1.0) * 1024.0,
         "hbm_bytes_per_launch": (fk * cal.get("read8", 2.0) + wk * cal.get("write8", 1.0)) * 1024.0,
         "records_bytes_per_launch": rec, "outputs_bytes_per_launch": outb}
 sq = {}
 for r in rows("pmc_sq_mid48/*/*counter_collection.csv"):
-    if "schur_wg_nodes" in r["Kernel_Name"]:
+    if "avi_solve_schur48" in r["Kernel_Name"]:
         sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if sq:
-    summ["schur_wg_nodes_sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
+    summ["avi_solve_schur48_sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
 json.dump(summ, open(os.path.join(dst, "r03_mid48_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1)[:3000])
 
