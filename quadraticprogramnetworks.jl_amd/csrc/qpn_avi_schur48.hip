@@ -364,6 +364,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         }
         wsync();
         const double cm = actb ? sucol[myslot] : 0.0;
+        STAMP(6);   // (diagnostic builds: entering column through LDS)
         // ---- ratio test (two-pass Harris with 1e-10 slack; largest pivot among ties, the artificial first)
         const double gdir = __hiloint2double(__double2hiint(cm) ^ (sneg ? (int)0x80000000 : 0), __double2loint(cm));
         const double rc = rcp64_(gdir);
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         const double dmax = fmin(wave_min_f64(d1), self_lim);
         if (uni(__double2hiint(dmax)) == 0x7ff00000 && uni(__double2loint(dmax)) == 0) { status = QPN_RAY_TERM; break; }
         const unsigned long long bal = qpn_ballot(dd <= dmax);
+        STAMP(7);   // (... ratio test)
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, inv = 0.0;
         int rsel = 0, rq = 0, cnext = -1;
         bool pivoted = false, stop = false;
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
         }
         c = cnext;
         wsync();
+        STAMP(3);   // (... row, bookkeeping, exchange)
     }
 
     STAMP(3);   // Lemke

@@ -12,7 +12,8 @@ _lib.LIB_PATH = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "libqpn_hi
 _lib._lib = None
 eng = qpn_amd.Engine(0)
 eng.set_option(_lib.OPT_MID_ROUTE, 1)
-names = ["loads + tiles", "stage A", "S product, c, W~ parked", "Lemke", "read-back", "post-check + stores"]
+names = ["loads + tiles", "stage A", "S product, c, W~ parked", "Lemke: row, bookkeeping, exchange", "read-back", "post-check + stores",
+         "Lemke: entering column through LDS", "Lemke: ratio test"]
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
 for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
     for cnt in [int(x) for x in os.environ.get("CNT", "256,4000").split(",")]:
@@ -25,6 +26,6 @@ for n in [int(x) for x in os.environ.get("NN", "48").split(",")]:
         torch.cuda.synchronize()
         s = st.cpu().numpy().astype(np.float64).mean(axis=0)
         lp = float(res["pivots"].double().mean()) - n
-        print(f"n = m = {n}, {cnt} nodes: {s[:6].sum():.0f} clocks per node; {lp:.1f} Lemke pivots ({s[3] / max(lp, 1):.0f} clocks each)")
+        print(f"n = m = {n}, {cnt} nodes: {s[:8].sum():.0f} clocks per node; {lp:.1f} Lemke pivots ({(s[3] + s[6] + s[7]) / max(lp, 1):.0f} clocks each)")
         for k, nm in enumerate(names):
-            print(f"   {nm:28s} {s[k]:9.0f}  {100 * s[k] / s[:6].sum():5.1f} %")
+            print(f"   {nm:28s} {s[k]:9.0f}  {100 * s[k] / s[:8].sum():5.1f} %")
