@@ -196,3 +196,24 @@ def test_mid_nodes_full_batch_properties(engine, oracle):
     ref = _oracle(oracle, tuple(a[idx] for a in rec), w)
     assert np.array_equal(host["status"][idx], ref["status"]) and np.array_equal(host["active"][idx], ref["active"])
     assert np.max(np.abs(host["z"][idx] - ref["z"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["z"])))
+
+
+def test_one_wavefront_class_schedule_changes_nothing_in_the_results(engine, oracle):
+    """33 <= max(n, m) <= 48 through a resident handle beyond the 2 048 resident wavefronts: the handle installs its longest-first
+    schedule from the sweeps' own pivot counts (as in the 32-class); the rows it produces are bit for bit the per-call route's
+    (which has no schedule), sweep after sweep, with new parameters every sweep; a subset against the oracle."""
+    n, m, p, cnt = 40, 37, 5, 2600
+    rec, abi = _records(41, cnt, n, m, p)
+    nodes = engine.upload_nodes(*abi)
+    rng = np.random.default_rng(8)
+    for sweep in range(4):
+        w = rng.standard_normal(p)
+        a = nodes.solve(w)
+        b = engine.solve_nodes(*abi, w)
+        for k in ("z", "status", "resid", "pivots", "active"):
+            assert np.array_equal(a[k], b[k]), (sweep, k)
+    assert nodes.info()["scheduled"]
+    idx = np.sort(rng.choice(cnt, 60, replace=False))
+    ref = _oracle(oracle, tuple(x[idx] for x in rec), w)
+    _same({k: a[k][idx] for k in ("status", "active", "z")}, ref)
+    nodes.close()
