@@ -150,7 +150,9 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
 {
     constexpr int NW = NT > MT ? NT : MT;
 
-    const int b = blockIdx.x;
+    // schedule hint of a resident handle (longest first): this workgroup's node; a bad entry leaves the slot idle (uniform exit)
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)b >= (unsigned)a.batch) return;
     const int v = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int l = (int)threadIdx.x & 63, lc = l & 15, lq = l >> 4, tid = 64 * v + l;
     const int n = a.nd.n, m = a.nd.m, np_ = a.nd.p, N = n + m;
@@ -896,6 +898,7 @@ __global__ __launch_bounds__(64 * (NT > MT ? NT : MT), 4) void schur_wg_nodes(Av
         for (int k = 1; k < NW; ++k) rs = sRed[k] > rs ? sRed[k] : rs;
         if (re_) re_[b] = rs;
         if (pe_) pe_[b] = pivots;
+        if (int32_t *const sk = kp->sched_key) { const int k0 = sk[b]; sk[b] = k0 > 0 ? k0 - (k0 >> 5) + pivots : 32 * pivots; }      // smoothed pivot count
     }
     STAMP(0);   // (diagnostic builds: read-back + post-check are added to the load slot)
 #ifdef QPN_STAMPS

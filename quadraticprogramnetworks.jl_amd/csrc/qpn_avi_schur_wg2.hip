@@ -174,7 +174,9 @@ template <int NR>
 __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(AviBatchArgs a)
 {
     constexpr int pad = 16 * NR;
-    const int b = blockIdx.x;
+    // schedule hint of a resident handle (longest first): this workgroup's node; a bad entry leaves the slot idle (uniform exit)
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)b >= (unsigned)a.batch) return;
     // Which hardware wave plays which part: the wavefronts of a workgroup that has the CU to itself go to the SIMDs round-robin,
     // so the hardware waves 2, 6, 10, 14 share a SIMD.  For NR <= 6 they all become C waves -- the first of them the leader --, so
     // that no H wave's exchange runs on the SIMD on which the leader takes its turn: +3 % at 65 .. 80, +2 % at 96 (with 14 or 16
@@ -1105,6 +1107,7 @@ __global__ __launch_bounds__(128 * NR, (NR >= 7) ? 4 : 3) void schur_wg2_nodes(A
         for (int k = 1; k < 2 * NR; ++k) rs = sRed[k] > rs ? sRed[k] : rs;
         if (re_) re_[b] = rs;
         if (pe_) pe_[b] = pivots;
+        if (int32_t *const sk = kp->sched_key) { const int k0 = sk[b]; sk[b] = k0 > 0 ? k0 - (k0 >> 5) + pivots : 32 * pivots; }      // smoothed pivot count
     }
 }
 

@@ -837,23 +837,24 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                     for (int k = 0; k < ctx->mirror_count; ++k) a.mirror[k] = ctx->mirror_peer[k] + x_off;
                 }
             }
-            if (qpn_schur_wg2_shape(n, m)) HIPCHK(ctx, qpn_launch_schur_wg2_nodes(a, s));
-            else if (ctx->mid_route == 1 && qpn_schur48_shape(n, m)) {
-                // one wavefront per node: the handle's longest-first schedule as in the 32-class (launches beyond the 2 048
-                // resident wavefronts only): the kernel feeds the smoothed pivot counts, the order is re-sorted from them
-                const bool sched = h && h->period > 0 && batch > 2048;
-                if (sched) { a.sched_key = h->key; if (h->order_valid) a.order = h->order; }
-                HIPCHK(ctx, qpn_launch_avi_solve_schur48_nodes(a, s));
-                a.sched_key = nullptr; a.order = nullptr;
-                if (sched) {
-                    const int32_t per = h->calls < 8 * h->period ? h->period : 4 * h->period;
-                    if (h->calls % per == 0) {
-                        HIPCHK(ctx, qpn_launch_order_by_pivots(nullptr, batch, h->order, s, h->key));
-                        h->order_valid = true;
-                    }
-                    h->calls++;
+            // the handle's longest-first schedule as in the 32-class (launches beyond the resident set only: 2 048 wavefronts of the
+            // one-wavefront kernel, 1 024 workgroups of the 49-64 class, 256 of the 65-128 class): the kernel feeds the smoothed
+            // pivot counts, the order is re-sorted from them
+            const bool one_wave = ctx->mid_route == 1 && qpn_schur48_shape(n, m), two_role = qpn_schur_wg2_shape(n, m);
+            const bool sched = h && h->period > 0 && batch > (one_wave ? 2048 : (two_role ? 256 : 1024));
+            if (sched) { a.sched_key = h->key; if (h->order_valid) a.order = h->order; }
+            if (two_role) HIPCHK(ctx, qpn_launch_schur_wg2_nodes(a, s));
+            else if (one_wave) HIPCHK(ctx, qpn_launch_avi_solve_schur48_nodes(a, s));
+            else HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
+            a.sched_key = nullptr; a.order = nullptr;
+            if (sched) {
+                const int32_t per = h->calls < 8 * h->period ? h->period : 4 * h->period;
+                if (h->calls % per == 0) {
+                    HIPCHK(ctx, qpn_launch_order_by_pivots(nullptr, batch, h->order, s, h->key));
+                    h->order_valid = true;
                 }
-            } else HIPCHK(ctx, qpn_launch_schur_wg_nodes(a, s));
+                h->calls++;
+            }
             a.x = nullptr; a.n_mirror = 0;
         } else HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
         if (need_general) {

@@ -198,11 +198,13 @@ def test_mid_nodes_full_batch_properties(engine, oracle):
     assert np.max(np.abs(host["z"][idx] - ref["z"])) <= 1e-9 * max(1.0, np.max(np.abs(ref["z"])))
 
 
-def test_one_wavefront_class_schedule_changes_nothing_in_the_results(engine, oracle):
-    """33 <= max(n, m) <= 48 through a resident handle beyond the 2 048 resident wavefronts: the handle installs its longest-first
-    schedule from the sweeps' own pivot counts (as in the 32-class); the rows it produces are bit for bit the per-call route's
-    (which has no schedule), sweep after sweep, with new parameters every sweep; a subset against the oracle."""
-    n, m, p, cnt = 40, 37, 5, 2600
+@pytest.mark.parametrize("n,m,cnt", [(40, 37, 2600), (60, 52, 1150), (80, 70, 300)])
+def test_handle_schedule_changes_nothing_in_the_results(engine, oracle, n, m, cnt):
+    """The size classes above 32 through a resident handle beyond their resident sets (2 048 wavefronts of the one-wavefront kernel,
+    1 024 workgroups of the 49-64 class, 256 of the 65-128 class): the handle installs its longest-first schedule from the sweeps'
+    own pivot counts (as in the 32-class); the rows it produces are bit for bit the per-call route's (which has no schedule),
+    sweep after sweep, with new parameters every sweep; a subset against the oracle."""
+    p = 5
     rec, abi = _records(41, cnt, n, m, p)
     nodes = engine.upload_nodes(*abi)
     rng = np.random.default_rng(8)
