@@ -573,46 +573,38 @@ __global__ __launch_bounds__(64, 2) void avi_solve_schur48(AviBatchArgs a)
     auto check_row = [&](int k, double zk, double qk) {
         const bool isx = k < n;
         double rk = qk;
+        // a row's terms in ascending order on two alternating accumulators, 24 loads in flight together: the blocks are in L2 / the
+        // memory-side cache and a row is a chain of round trips, not bandwidth (8 in flight were 18 trips per node; 24 are 6:
+        // + 0.5 / 1.5 / 2.7 % on the class at 33 / 40 / 48)
+#define CHK_DOT(PB, PTR, STRIDE, CNT, ZOFF, ACC_E, ACC_O, SGN)                                                                      \
+        for (; j + PB <= (CNT); j += PB) {                                                                                          \
+            double mv[PB];                                                                                                          \
+            _Pragma("unroll") for (int q8 = 0; q8 < PB; ++q8) mv[q8] = (PTR)[(size_t)(j + q8) * (STRIDE)];                          \
+            _Pragma("unroll") for (int q8 = 0; q8 < PB; q8 += 2) {                                                                  \
+                ACC_E = fma(SGN mv[q8], SZ((ZOFF) + j + q8), ACC_E); ACC_O = fma(SGN mv[q8 + 1], SZ((ZOFF) + j + q8 + 1), ACC_O);    \
+            }                                                                                                                       \
+        }
+        double r2 = 0.0;
         if (isx) {
             const double *qcol = Q_ + k;
-            double r2 = 0.0;
             int j = 0;
-            for (; j + 8 <= n; j += 8) {
-                double mv[8];
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) mv[q8] = qcol[(size_t)(j + q8) * n];
-#pragma unroll
-                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(mv[q8], SZ(j + q8), rk); r2 = fma(mv[q8 + 1], SZ(j + q8 + 1), r2); }
-            }
+            CHK_DOT(24, qcol, n, n, 0, rk, r2, +)
+            CHK_DOT(8, qcol, n, n, 0, rk, r2, +)
             for (; j < n; ++j) rk = fma(qcol[(size_t)j * n], SZ(j), rk);
-            {                                                                          // columns of lambda: -A'
-                const double *arow = A_ + (size_t)k * m;                                  // column k of Ad: A[i][k], i contiguous
-                int i = 0;
-                for (; i + 8 <= m; i += 8) {
-                    double av[8];
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; ++q8) av[q8] = arow[i + q8];
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; q8 += 2) { r2 = fma(-av[q8], SZ(n + i + q8), r2); rk = fma(-av[q8 + 1], SZ(n + i + q8 + 1), rk); }
-                }
-                for (; i < m; ++i) r2 = fma(-arow[i], SZ(n + i), r2);
-            }
-            rk += r2;
+            const double *arow = A_ + (size_t)k * m;                                      // column k of Ad: A[i][k], i contiguous; columns of lambda: -A'
+            j = 0;
+            CHK_DOT(24, arow, 1, m, n, r2, rk, -)
+            CHK_DOT(8, arow, 1, m, n, r2, rk, -)
+            for (; j < m; ++j) r2 = fma(-arow[j], SZ(n + j), r2);
         } else {
-            const int r = k - n;
-            double r2 = 0.0;
+            const double *acol = A_ + (k - n);                                            // row r of Ad: A[r][j], lanes <-> r contiguous
             int j = 0;
-            const double *acol = A_ + r;                                                  // row r of Ad: A[r][j], lanes <-> r contiguous
-            for (; j + 8 <= n; j += 8) {
-                double av[8];
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) av[q8] = acol[(size_t)(j + q8) * m];
-#pragma unroll
-                for (int q8 = 0; q8 < 8; q8 += 2) { rk = fma(av[q8], SZ(j + q8), rk); r2 = fma(av[q8 + 1], SZ(j + q8 + 1), r2); }
-            }
+            CHK_DOT(24, acol, m, n, 0, rk, r2, +)
+            CHK_DOT(8, acol, m, n, 0, rk, r2, +)
             for (; j < n; ++j) rk = fma(acol[(size_t)j * m], SZ(j), rk);
-            rk += r2;
         }
+        rk += r2;
+#undef CHK_DOT
         const int gk = !isx;
         const double lk = gk ? a.nd.l[(size_t)b * m + (k - n)] : -QINF, uk = gk ? a.nd.u[(size_t)b * m + (k - n)] : QINF;
         const double pp = gk ? rk : zk, dv = gk ? zk : rk;
