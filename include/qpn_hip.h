@@ -247,7 +247,7 @@ int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period);
  *                      (default: ONE wavefront per node for max(n, m) <= 48, one workgroup per node beyond), 3 = the workgroup
  *                      kernel also for 33 .. 48, 2 = round 2's routes (three kernels with an HBM workspace up to 64, the route
  *                      of large nodes beyond), 0 = the route of large nodes.
- *                      The environment variable QPN_NODES_MID, read once by qpn_ctx_create, presets it.
+ *                      (The library reads no environment variable; diagnostic builds with -DQPN_DEV_SWITCHES accept a preset.)
  *   QPN_OPT_BIG_ROUTE  node records with 64 < n <= 256 and m <= 256 beyond the sizes above (BASELINE config 5): 1 = the blocked
  *                      matrix-core crash straight from the records (default), 0 = round 2's route over an assembled M.
  *   QPN_OPT_SYM_ROUTE  resident records (qpn_nodes_upload) whose Qd blocks are ALL bitwise symmetric: 1 = kernel variants that

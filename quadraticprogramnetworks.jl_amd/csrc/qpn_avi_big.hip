@@ -630,13 +630,13 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
 {
     if (a.batch <= 0) return hipSuccess;
     const int N = a.N;
-    static const bool no_schur = [] { const char *e = getenv("QPN_AVI_BIG_KERNEL"); return e && e[0] == 'g'; }();   // "general"
+    static const bool no_schur = [] { const char *e = QPN_DEV_ENV("QPN_AVI_BIG_KERNEL"); return e && e[0] == 'g'; }();   // "general"
     if (a.kind == nullptr || a.only_if != nullptr || a.n_items != nullptr || no_schur) return launch_big_kernel(a, workspace, stream);
     double *dict = workspace;
     void *sb = workspace + (size_t)a.batch * (size_t)N * (size_t)(N + 1);
     uint8_t *ones = reinterpret_cast<uint8_t *>(static_cast<char *>(sb) + qpn_schur_big_workspace_bytes(a.batch, N));
     SchurBigWs w{};
-    static const bool lemke_general = [] { const char *e = getenv("QPN_AVI_BIG_LEMKE"); return e && e[0] == 'g'; }();
+    static const bool lemke_general = [] { const char *e = QPN_DEV_ENV("QPN_AVI_BIG_LEMKE"); return e && e[0] == 'g'; }();
     // node path with m <= 64 (uniform, known here): the Schur problems go to the one-wavefront register kernel
     const bool lemke_reg = !lemke_general && a.nd.Qd && a.nd.m >= 1 && a.nd.m <= 64 && a.nd.n + a.nd.m == N &&
                            (a.max_pivots <= 0 || a.max_pivots - a.nd.n >= 1);

@@ -1257,7 +1257,7 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
     SchurDebug d{nullptr, nullptr, nullptr, nullptr};
 #ifdef QPN_DIAG
     // diagnostic builds only: extra dynamic LDS per block lowers the occupancy (occupancy-sensitivity experiments)
-    static const unsigned pad = [] { const char *e = getenv("QPN_DEBUG_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    static const unsigned pad = [] { const char *e = QPN_DEV_ENV("QPN_DEBUG_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
 #else
     const unsigned pad = 0;
 #endif
@@ -1271,7 +1271,7 @@ hipError_t qpn_launch_avi_solve_schur_nodes(const AviBatchArgs &a, hipStream_t s
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         resident[dev] = 16 * cus;
     }
-    static const bool no_stagger = [] { const char *e = getenv("QPN_NO_STAGGER"); return e && e[0] == '1'; }();   // A/B switch
+    static const bool no_stagger = [] { const char *e = QPN_DEV_ENV("QPN_NO_STAGGER"); return e && e[0] == '1'; }();   // A/B switch
     // a partial round has no burst to spread; other CU counts (partitioned modes) run without the stagger
     const bool stag = !no_stagger && resident[dev] == kResidentMI355X && a.batch > kResidentMI355X;
     const bool full = a.nd.n == 32 && a.nd.m == 32, half = a.nd.n == 16 && a.nd.m == 16;

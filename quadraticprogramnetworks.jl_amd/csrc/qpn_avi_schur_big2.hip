@@ -713,7 +713,7 @@ hipError_t qpn_launch_schur_big2_stage_a(const AviBatchArgs &a, void *ws, double
         attr_once.done[attr_dev] = true;
     }
     const dim3 grid((unsigned)batch);
-    static const bool force_convert = [] { const char *e = getenv("QPN_BIG2_CONVERT"); return e && e[0] == '1'; }();     // A/B switch
+    static const bool force_convert = [] { const char *e = QPN_DEV_ENV("QPN_BIG2_CONVERT"); return e && e[0] == '1'; }();     // A/B switch
     if (!force_convert && (a.nd.n & 15) == 0 && (a.nd.m & 15) == 0) {
         hipLaunchKernelGGL(schur_big2_eliminate<1>, grid, dim3(TPB2), LDS_DOUBLES * sizeof(double), stream, a, w);
         if (a.nd.n > 64) hipLaunchKernelGGL(schur_big2_eliminate<2>, grid, dim3(TPB2), LDS_DOUBLES * sizeof(double), stream, a, w);

@@ -569,7 +569,7 @@ hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream
     r.flags = a.flags | QPN_AVI_FLAG_COLD_START | (w.s_bs > 0 ? QPN_AVI_IFLAG_BLOCKED_M : 0);
     r.only_if = a.status; r.only_if_value = -2;
 #ifdef QPN_STAMPS
-    if (getenv("QPN_MID_STAMP_REG")) r.stamps = a.stamps;          // diagnostic builds: the Lemke kernel's phases instead
+    if (QPN_DEV_ENV("QPN_MID_STAMP_REG")) r.stamps = a.stamps;          // diagnostic builds: the Lemke kernel's phases instead
 #endif
     e = qpn_launch_avi_solve_reg(r, stream);
     if (e != hipSuccess) return e;

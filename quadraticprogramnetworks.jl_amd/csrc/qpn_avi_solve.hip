@@ -412,7 +412,7 @@ int qpn_avi_max_n() { return qpn_avi_big_max_n(); }   // N <= 64: one wavefront;
 hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream)
 {
     static const int use_lds1 = [] {
-        const char *e = getenv("QPN_AVI_KERNEL");
+        const char *e = QPN_DEV_ENV("QPN_AVI_KERNEL");
         return (e && strcmp(e, "lds1") == 0) ? 1 : 0;
     }();
     if (use_lds1) return qpn_launch_avi_solve_lds1(a, stream);
@@ -422,7 +422,7 @@ hipError_t qpn_launch_avi_solve(const AviBatchArgs &a, hipStream_t stream)
     // gated launch.  Pure box-MCP batches (kind == NULL) and already gated launches go straight to
     // the register kernel.  QPN_AVI_KERNEL=reg forces the general kernel for A/B runs.
     static const int force_reg = [] {
-        const char *e = getenv("QPN_AVI_KERNEL");
+        const char *e = QPN_DEV_ENV("QPN_AVI_KERNEL");
         return (e && strcmp(e, "reg") == 0) ? 1 : 0;
     }();
     if (force_reg || a.kind == nullptr || a.only_if != nullptr || a.N < 2) return qpn_launch_avi_solve_reg(a, stream);

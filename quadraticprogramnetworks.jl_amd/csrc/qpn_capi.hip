@@ -139,8 +139,8 @@ int qpn_ctx_create(int device_id, qpn_ctx **out)
         delete ctx; return QPN_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    // developer default of the mid-size route, read ONCE here (never per call); qpn_ctx_set_option overrides it
-    if (const char *e = getenv("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '3' && !e[1]) ctx->mid_route = e[0] - '0'; }
+    // diagnostic builds (-DQPN_DEV_SWITCHES) only: a preset of the mid-size route, read ONCE here; qpn_ctx_set_option overrides it
+    if (const char *e = QPN_DEV_ENV("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '3' && !e[1]) ctx->mid_route = e[0] - '0'; }
     *out = ctx;
     return QPN_OK;
 }

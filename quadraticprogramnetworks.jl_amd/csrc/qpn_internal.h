@@ -7,6 +7,16 @@
 
 #include "../../include/qpn_hip.h"
 
+// Developer switches on the environment (kernel A/B, diagnostic routes) exist in diagnostic builds only
+// (csrc/build.sh -DQPN_DEV_SWITCHES): the product library dispatches on its arguments and on qpn_ctx_set_option alone and
+// never reads the environment.
+#ifdef QPN_DEV_SWITCHES
+#include <stdlib.h>
+#define QPN_DEV_ENV(name) getenv(name)
+#else
+#define QPN_DEV_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 // per-node records (qpn_solve_nodes): the solve kernel assembles the KKT blocks on the fly
 struct NodeSrc {
     int32_t n, m, p;

@@ -56,3 +56,24 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower().replace("# oracle", "").replace("cpu oracle", "").replace("the oracle", ""), \
                     f"{f} mentions the oracle"
+
+
+def test_library_does_not_read_the_environment():
+    """Routes are chosen by arguments and qpn_ctx_set_option alone: the product build of the library does not import getenv
+    (the developer switches exist in -DQPN_DEV_SWITCHES builds only; QPN_HIP_LIB is the loaders' variable)."""
+    import shutil
+    import subprocess
+    import qpn_amd  # noqa: F401
+    from qpn_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    path = _lib.LIB_PATH
+    if os.environ.get("QPN_HIP_LIB"):
+        pytest.skip("a developer library is selected")
+    out = subprocess.run([nm, "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    undefined = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+    assert "getenv" not in undefined and "secure_getenv" not in undefined
+    src_dir = os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc")
+    for f in os.listdir(src_dir):
+        if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(src_dir, f)).read()
+            assert len(re.findall(r"\bgetenv\s*\(", txt)) == (1 if f == "qpn_internal.h" else 0), f

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: BASELINE config 5 item shape (n = m = 256, N_red = 512) on the large-item path -- time per
-batch and agreement between the blocked-MFMA-crash path and the general kernel (QPN_AVI_BIG_KERNEL=general)."""
+batch and agreement between the blocked-MFMA-crash path and the general kernel (QPN_AVI_BIG_KERNEL=general: honoured by a
+diagnostic build of the library only -- csrc/build.sh -DQPN_DEV_SWITCHES with QPN_OUT=..., loaded through QPN_HIP_LIB)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

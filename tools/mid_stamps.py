@@ -5,7 +5,7 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 out = "/tmp/libqpn_hip_stamps.so"
-subprocess.check_call(["bash", os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc", "build.sh"), "-DQPN_STAMPS"], env=dict(os.environ, QPN_OUT=out, QPN_OBJ="/tmp/qpn_obj_stamps"))
+subprocess.check_call(["bash", os.path.join(ROOT, "quadraticprogramnetworks.jl_amd", "csrc", "build.sh"), "-DQPN_STAMPS", "-DQPN_DEV_SWITCHES"], env=dict(os.environ, QPN_OUT=out, QPN_OBJ="/tmp/qpn_obj_stamps"))
 import numpy as np, torch
 import qpn_amd
 from qpn_amd import _lib
