@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Developer aid: node-solve rate across node sizes (where the kernel families hand over), per-call route (records passed every call,
-outputs allocated per call, wall clock).  n = m = 64 twice: 2 000 nodes are 1.95 rounds of the 1 024 workgroups resident at once (the
+"""Developer aid: node-solve rate across node sizes (where the kernel families hand over), wall clock, two columns: the per-call
+route (records passed every call, outputs allocated per call, the decline count read back every call) and the resident-records
+route of the bench (qpn_nodes_upload once, then one launch per sweep in the handle's longest-first order; 48 untimed sweeps first,
+so that the order has been re-sorted from the kernels' own pivot counts).  n = m = 64 twice: 2 000 nodes are 1.95 rounds of the 1 024 workgroups resident at once (the
 second round nearly empty at the end), 4 096 are four full rounds."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,4 +30,18 @@ for n, m, cnt in [(16, 16, 10000), (32, 32, 10000), (33, 33, 4000), (40, 40, 400
         dts.append((time.perf_counter() - t0) / reps)
     dt = sorted(dts)[1]
     st = res["status"].cpu().numpy()
-    print(f"n=m={n:4d} ({cnt:5d} nodes): {dt*1e3:8.3f} ms/batch = {cnt/dt/1e3:10.1f} K solves/s, solved {(st==1).mean()*100:.0f} %, mean pivots {res['pivots'].double().mean().item():.0f}", flush=True)
+    nodes = eng.upload_nodes(*args[:-1])
+    for _ in range(48):
+        rr = nodes.solve(args[-1])
+    torch.cuda.synchronize()
+    dth = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(4 * reps):
+            rr = nodes.solve(args[-1])
+        torch.cuda.synchronize()
+        dth.append((time.perf_counter() - t0) / (4 * reps))
+    dh = sorted(dth)[1]
+    assert (rr["status"].cpu().numpy() == st).all()
+    del nodes
+    print(f"n=m={n:4d} ({cnt:5d} nodes): {dt*1e3:8.3f} ms/batch = {cnt/dt/1e3:10.1f} K solves/s per call; resident records: {dh*1e3:8.3f} ms = {cnt/dh/1e3:10.1f} K solves/s; solved {(st==1).mean()*100:.0f} %, mean pivots {res['pivots'].double().mean().item():.0f}", flush=True)
