@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer aid: ten sweeps of ONE mid-size node class (NN, CNT; HANDLE=1: resident records) -- the program tools/midsize_trace.sh
+runs under rocprofv3."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
