@@ -321,6 +321,29 @@ int qpn_local_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int
 int qpn_recipes_from_masks(qpn_ctx *ctx, int32_t N, const uint8_t *mask, int64_t first, int32_t count, uint8_t *K,
                            int64_t *total, int mem);
 
+/* ---- (F1, batched over a level) the solution-graph pieces of MANY nodes with O(1) calls -------------------------------------
+ * The outer loop maps process_qp over the nodes of a level (src/algorithm.jl:44-52) and every optimal node below level 1
+ * makes its solution graph (src/qp_processing.jl:158, :193-198, :231 -> process_solution_graph, src/avi.jl:447-477).
+ * qpn_recipes_batch: all_Ks (src/avi_solutions.jl:200-215) for `nodes` solutions in one launch.  masks [nodes][N]; offsets
+ *   [nodes + 1] (ALWAYS a host array, like a pool shape: offsets[0] = 0, node b gets the recipes 0 .. offsets[b+1]-offsets[b]-1 of
+ *   its Cartesian product, at most as many as the product has); outputs K [offsets[nodes]][N] and node_of [offsets[nodes]] --
+ *   exactly what qpn_local_pieces / qpn_reduced_pieces take.
+ * qpn_reduced_pieces: local_piece (src/avi_solutions.jl:400-496, as qpn_local_pieces) followed by the elimination of the m
+ *   multiplier columns through the piece's own equality rows (eliminate_variables, src/sets.jl:731-800: one column at a time,
+ *   the alive equality row with the largest entry |a| > tol, the first of equal ones; that row then leaves) -- what
+ *   project_and_permute (src/avi_solutions.jl:79-91) comes to when the active rows pin the multipliers.  Output per piece, over
+ *   the columns [x_d (n); x_p (p)] and with room for cap = n + 2m rows: Ar = the cap x (n+p) matrix, column-major,
+ *   lr, ur [cap], rows = the number of rows that remain (in their original order), flags: bit 0 = a multiplier column was pinned
+ *   by no equality row while an alive row still holds it (degenerate active set: the projection needs Fourier-Motzkin / vertex
+ *   enumeration, which stays with the caller -- the piece's output is then incomplete), bit 1 = more than cap rows remained.
+ *   The local pieces themselves live in the context's workspace only.  n + m <= 512. */
+int qpn_recipes_batch(qpn_ctx *ctx, int32_t nodes, int32_t N, const uint8_t *masks, const int64_t *offsets, uint8_t *K,
+                      int32_t *node_of, int mem);
+int qpn_reduced_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd,
+                       const double *R, const double *qd, const double *Ad, const double *B, const double *l,
+                       const double *u, const int32_t *node_of, const uint8_t *K, double tol, double *Ar, double *lr, double *ur,
+                       int32_t *rows, int32_t *flags, int mem);
+
 /* ---- (A8) batched per-node KKT verification, src/qp_processing.jl:57-149 ------------
  *   xd [batch][n] current decision values, w as above.
  *   solution [batch] int32 (1 = optimal for the node), lambda [batch][m] (sign: + at the lower

@@ -21,6 +21,7 @@ ABI_SYMBOLS = (
     "qpn_sweep_status", "qpn_ctx_set_auto_schedule", "qpn_ctx_set_option",
     "qpn_nodes_upload", "qpn_nodes_update", "qpn_nodes_set_schedule", "qpn_nodes_free", "qpn_nodes_info", "qpn_solve_nodes_h",
     "qpn_verify_nodes_h", "qpn_pool_size", "qpn_assemble_pools", "qpn_local_pieces", "qpn_recipes_from_masks",
+    "qpn_recipes_batch", "qpn_reduced_pieces",
 )
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -125,6 +126,9 @@ def load_library():
     lib.qpn_local_pieces.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp, vp, C.c_int]
     lib.qpn_recipes_from_masks.argtypes = [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, C.POINTER(C.c_int64), C.c_int]
+    lib.qpn_recipes_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int]
+    lib.qpn_reduced_pieces.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                       C.c_double, vp, vp, vp, vp, vp, C.c_int]
     del dp, ip, bp
     _lib = lib
     return lib

@@ -6,7 +6,8 @@ from __future__ import annotations
 import numpy as np
 
 from .avi import AVISolveError, solve_qep
-from .qp_processing import process_qp
+from .level_batch import process_level
+from .polyhedra import remove_subsets_many
 
 
 class CyclingError(RuntimeError):
@@ -50,13 +51,14 @@ def solve_base(qpn, x_init, level=1, proj_vectors=None, rng=None, engine=None):
                 S = {}
             players = sorted(qpn.network_depth_map[level])                           # :44
             child_level = sorted(set().union(*[qpn.network_edges[i] for i in players]))
-            results = [process_qp(qpn, pid, x, S, engine=engine,
-                                  exploration_vertices=opts.exploration_vertices) for pid in players]   # :47-49
+            results = process_level(qpn, players, x, S, engine=engine,
+                                    exploration_vertices=opts.exploration_vertices)                    # :47-49, one batch
             equilibrium = True
             sub_assign = {i: S[i][0] for i in child_level}                           # :54
             sub_ids = {i: 0 for i in child_level}
             if any(r["failed"] for r in results):                                    # :57-66
                 return dict(solved=False, x_fail=x, x_opt=None)
+            graphs = {}
             for pid, r in zip(players, results):                                     # :68-90
                 if not r["solution"]:
                     equilibrium = False
@@ -64,7 +66,15 @@ def solve_base(qpn, x_init, level=1, proj_vectors=None, rng=None, engine=None):
                         for child, sp in r["subpiece_assignments"].items():
                             sub_assign[child] = S[child][sp]; sub_ids[child] = sp
                 else:
-                    S[pid] = r["S"]
+                    graphs[pid] = r["S"]
+            lv = opts.levels_to_remove_subsets                                       # None = NaturalNumbers(): every level
+            if graphs and (lv is None or level in lv):                               # :84, all nodes of the level in one batch
+                ids = [pid for pid in graphs if graphs[pid] is not None and len(graphs[pid]) > 1]
+                if ids:
+                    from .avi import _eng
+                    for pid, kept in zip(ids, remove_subsets_many([graphs[pid] for pid in ids], _eng(engine))):
+                        graphs[pid] = kept
+            S.update(graphs)
             if not equilibrium:                                                      # :91-109
                 try:
                     xnew = solve_qep(qpn, players, x, sub_assign, engine=engine)

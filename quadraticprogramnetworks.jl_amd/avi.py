@@ -236,38 +236,12 @@ def assemble_pool_batch(blocks, w, engine=None, form="reduced", qd=None, l=None,
 # ---- src/avi.jl:382-444 -------------------------------------------------------------------------
 def solve_qep(qp_net, player_pool, x, S: Optional[Dict[int, object]] = None, engine=None,
               reference_form=False):
-    """One AVI for the Nash game among `player_pool` at the current x; returns x_opt."""
-    S = S or {}
-    x = np.asarray(x, dtype=np.float64)
-    x_dim = len(x)
-    dec_inds = sorted(set().union(*[set(qp_net.decision_inds(i)) for i in player_pool]))
-    param_inds = [i for i in range(x_dim) if i not in set(dec_inds)]
-    labeled = {i: create_labeled_gavi_from_qp(qp_net, i, S) for i in player_pool}
-    disjoint = sum(len(labeled[i]["dvars"]) for i in player_pool) == len(dec_inds)
-    w = x[param_inds]
-    nd = len(dec_inds)
-    # combine_gavis (:399-400) ON THE DEVICE: one qpn_assemble_pools call stacks the players' blocks into the pool's AVI --
-    # the reference form (xi blocks, the sum-of-xi rows :356-367, convert :113-128) when asked for or when players share
-    # decision variables, else the reduced form (N = nd + sum m_i) -- and the batched solve takes it as it stands.  (The host
-    # mirrors combine_gavis / combine_gavis_reduced above remain as the checkers of that kernel, tests/test_gpu_pools.py.)
-    form = "reference" if (reference_form or not disjoint) else "reduced"
-    blocks = pool_blocks(x_dim, dec_inds, param_inds, labeled)
-    Mc, q, lo, hi, kind = assemble_pool_batch(blocks, w, engine=engine, form=form)
-    Nn = np.asarray(q).shape[-1]
-    z0 = np.zeros(Nn)
-    z0[:nd] = x[dec_inds]                                                            # duals cold, :404
-    if form == "reference":
-        # z0s = [z0; A z0 + B w] (:107-108): the slack block, the last sum m_i entries of the converted AVI
-        sm = len(blocks["l"])
-        if sm:
-            z0[Nn - sm:] = blocks["Ad"] @ x[dec_inds] + blocks["Bp"] @ w
-    res = _eng(engine).solve_avi_batch(np.asarray(Mc), np.asarray(q).reshape(1, Nn), np.asarray(lo).reshape(1, Nn),
-                                       np.asarray(hi).reshape(1, Nn), z0=z0[None], kind=np.asarray(kind).reshape(Nn))
-    z = np.asarray(res["z"][0]); status = StatusCode(int(res["status"][0]))
-    info = dict(resid=float(res["resid"][0]), pivots=int(res["pivots"][0]), active=np.asarray(res["active"][0]))
-    if status != StatusCode.SUCCESS:
-        raise AVISolveError(f"AVI solve error. This might be because one of the qps {list(player_pool)} "
-                            f"is unbounded or ill-conditioned. {info}")
-    x_opt = x.copy()
-    x_opt[dec_inds] = z[:len(dec_inds)]
-    return x_opt
+    """The AVI step of a level at the current x; returns x_opt.  The reference forms ONE AVI for the whole pool
+    (:399-400); that AVI is block diagonal over the connected components of the pool's coupling graph, so the components
+    are solved as batches (level_batch.solve_level): single-node components as node records (create_labeled_gavi_from_qp
+    fused into the solve kernel), multi-node components through qpn_assemble_pools (combine_gavis on the device; the
+    reference form with the xi blocks, the sum-of-xi rows :356-367 and convert :113-128 when asked for or when players
+    share decision variables, else the reduced form).  The host mirrors combine_gavis / combine_gavis_reduced above remain
+    as the checkers of that kernel (tests/test_gpu_pools.py)."""
+    from .level_batch import solve_level
+    return solve_level(qp_net, list(player_pool), x, S or {}, engine=engine, reference_form=reference_form)

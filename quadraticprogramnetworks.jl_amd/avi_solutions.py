@@ -154,17 +154,18 @@ def solution_graph_pieces(Q, q, A, l, u, dec_inds, x, lam, engine=None, tol=1e-2
 
 def _dedupe(P: Poly, digits=6):
     """Merge rows with equal normals (intersection of their intervals), drop all-zero rows:
-    the array part of simplify (src/sets.jl:255-311)."""
-    A, l, u = P.vectorize()
+    the array part of simplify (src/sets.jl:255-311).  Works on the local form (the columns the rows touch)."""
+    cols, A = P.local()
+    l, u = P.l.copy(), P.u.copy()
     keep = {}
     for i in range(A.shape[0]):
         if not np.any(A[i]):
             continue
-        key = tuple(np.round(A[i], digits))
+        key = np.round(A[i], digits).tobytes()
         if key in keep:
             j = keep[key]
             l[j] = max(l[j], l[i]); u[j] = min(u[j], u[i])
         else:
             keep[key] = i
     idx = sorted(keep.values())
-    return Poly(A[idx], l[idx], u[idx], normalise=False)
+    return Poly.from_local(P.ncols, cols, A[idx], l[idx], u[idx], normalise=False)

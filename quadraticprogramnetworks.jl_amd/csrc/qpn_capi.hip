@@ -498,6 +498,116 @@ int qpn_recipes_from_masks(qpn_ctx *ctx, int32_t N, const uint8_t *mask, int64_t
     return QPN_OK;
 }
 
+int qpn_recipes_batch(qpn_ctx *ctx, int32_t nodes, int32_t N, const uint8_t *masks, const int64_t *offsets, uint8_t *K,
+                      int32_t *node_of, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (nodes <= 0 || N <= 0 || !masks || !offsets) return fail_arg(ctx, "qpn_recipes_batch: bad argument");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_recipes_batch: bad mem kind");
+    if (offsets[0] != 0) return fail_arg(ctx, "qpn_recipes_batch: offsets[0] must be 0");
+    for (int b = 0; b < nodes; ++b)
+        if (offsets[b + 1] < offsets[b]) return fail_arg(ctx, "qpn_recipes_batch: offsets must not decrease");
+    const int64_t total = offsets[nodes];
+    if (total == 0) return QPN_OK;
+    if (!K || !node_of) return fail_arg(ctx, "qpn_recipes_batch: null output");
+    if (total > INT32_MAX) { ctx->last_error = "qpn_recipes_batch: more than 2^31 - 1 recipes in one call"; return QPN_ERR_SIZE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // a node may ask for at most the number of recipes its masks have (host masks are checked here; device masks are the
+    // caller's: a count beyond the product wraps around inside the product, it cannot leave the arrays)
+    if (mem == QPN_MEM_HOST)
+        for (int b = 0; b < nodes; ++b) {
+            int64_t tot = 1;
+            for (int i = 0; i < N; ++i) { const int r = __builtin_popcount(masks[(size_t)b * N + i]); if (r > 1) tot = (tot > INT64_MAX / r) ? INT64_MAX : tot * r; }
+            if (offsets[b + 1] - offsets[b] > tot) return fail_arg(ctx, "qpn_recipes_batch: a node asks for more recipes than its masks have");
+        }
+    long long *doff; uint8_t *dm = nullptr, *dK = nullptr; int32_t *dno = nullptr;
+    Carver cv(ctx);
+    cv.add((void **)&doff, (size_t)(nodes + 1) * 8);
+    if (mem == QPN_MEM_HOST) { cv.add((void **)&dm, (size_t)nodes * N); cv.add((void **)&dK, (size_t)total * N); cv.add((void **)&dno, (size_t)total * 4); }
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    // (the offsets go through a synchronous copy: the host array is the caller's and may be pageable)
+    HIPCHK(ctx, hipMemcpyAsync(doff, offsets, (size_t)(nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_recipes_batch(nodes, N, masks, doff, total, K, node_of, s));
+        return QPN_OK;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dm, masks, (size_t)nodes * N, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_recipes_batch(nodes, N, dm, doff, total, dK, dno, s));
+    HIPCHK(ctx, hipMemcpyAsync(K, dK, (size_t)total * N, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(node_of, dno, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
+int qpn_reduced_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd,
+                       const double *R, const double *qd, const double *Ad, const double *B, const double *l,
+                       const double *u, const int32_t *node_of, const uint8_t *K, double tol, double *Ar, double *lr, double *ur,
+                       int32_t *rows, int32_t *flags, int mem)
+{
+    if (!ctx) return QPN_ERR_ARG;
+    if (pieces < 0 || nodes <= 0 || n <= 0 || m < 0 || p < 0) return fail_arg(ctx, "qpn_reduced_pieces: bad sizes");
+    if (pieces == 0) return QPN_OK;
+    if (n + m > 512) { ctx->last_error = "qpn_reduced_pieces: n + m <= 512 in ABI v1"; return QPN_ERR_SIZE; }
+    if (!Qd || !qd || (m > 0 && (!Ad || !l || !u)) || (p > 0 && (!R || (m > 0 && !B))) || !K || !Ar || !lr || !ur || !rows || !flags)
+        return fail_arg(ctx, "qpn_reduced_pieces: null pointer");
+    if (!node_of && nodes < pieces) return fail_arg(ctx, "qpn_reduced_pieces: fewer record sets than pieces and no node_of");
+    if (mem != QPN_MEM_HOST && mem != QPN_MEM_DEVICE) return fail_arg(ctx, "qpn_reduced_pieces: bad mem kind");
+    if (!(tol >= 0.0)) return fail_arg(ctx, "qpn_reduced_pieces: bad tolerance");
+    if (qpn_reduce_pieces_lds(n, m, p) > 60 * 1024) { ctx->last_error = "qpn_reduced_pieces: too many parameters for one workgroup's LDS"; return QPN_ERR_SIZE; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int N = n + m;
+    const size_t rws = 2 * (size_t)N, cols = (size_t)N + p, cap = (size_t)n + 2 * (size_t)m, oc = (size_t)n + p;
+    const NodeSizes sz = node_sizes(nodes, n, m, p, 0);
+    if (mem == QPN_MEM_HOST && node_of)
+        for (int t = 0; t < pieces; ++t)
+            if (node_of[t] < 0 || node_of[t] >= nodes) return fail_arg(ctx, "qpn_reduced_pieces: node_of outside 0..nodes-1");
+    double *dAp, *dlp, *dup; uint8_t *dkeep;
+    double *dQ = nullptr, *dR = nullptr, *dq = nullptr, *dA = nullptr, *dB = nullptr, *dl = nullptr, *du = nullptr, *dAr = nullptr, *dlr = nullptr,
+           *dur = nullptr;
+    int32_t *dno = nullptr, *drows = nullptr, *dflags = nullptr; uint8_t *dK = nullptr;
+    Carver cv(ctx);
+    cv.add((void **)&dAp, (size_t)pieces * rws * cols * 8); cv.add((void **)&dlp, (size_t)pieces * rws * 8);
+    cv.add((void **)&dup, (size_t)pieces * rws * 8); cv.add((void **)&dkeep, (size_t)pieces * rws);
+    if (mem == QPN_MEM_HOST) {
+        cv.add((void **)&dQ, sz.Q); cv.add((void **)&dR, sz.R + 8); cv.add((void **)&dq, sz.q); cv.add((void **)&dA, sz.A + 8);
+        cv.add((void **)&dB, sz.B + 8); cv.add((void **)&dl, sz.lu + 8); cv.add((void **)&du, sz.lu + 8);
+        if (node_of) cv.add((void **)&dno, (size_t)pieces * 4);
+        cv.add((void **)&dK, (size_t)pieces * N); cv.add((void **)&dAr, (size_t)pieces * oc * cap * 8);
+        cv.add((void **)&dlr, (size_t)pieces * cap * 8 + 8); cv.add((void **)&dur, (size_t)pieces * cap * 8 + 8);
+        cv.add((void **)&drows, (size_t)pieces * 4); cv.add((void **)&dflags, (size_t)pieces * 4);
+    }
+    int rc = cv.commit();
+    if (rc != QPN_OK) return rc;
+    if (mem == QPN_MEM_DEVICE) {
+        HIPCHK(ctx, qpn_launch_local_pieces(pieces, nodes, n, m, p, Qd, R, qd, Ad, B, l, u, node_of, K, dAp, dlp, dup, dkeep, s));
+        HIPCHK(ctx, qpn_launch_reduce_pieces(pieces, n, m, p, tol, dAp, dlp, dup, dkeep, Ar, lr, ur, rows, flags, s));
+        return QPN_OK;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dQ, Qd, sz.Q, hipMemcpyHostToDevice, s));
+    if (sz.R) HIPCHK(ctx, hipMemcpyAsync(dR, R, sz.R, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dq, qd, sz.q, hipMemcpyHostToDevice, s));
+    if (sz.A) HIPCHK(ctx, hipMemcpyAsync(dA, Ad, sz.A, hipMemcpyHostToDevice, s));
+    if (sz.B) HIPCHK(ctx, hipMemcpyAsync(dB, B, sz.B, hipMemcpyHostToDevice, s));
+    if (sz.lu) { HIPCHK(ctx, hipMemcpyAsync(dl, l, sz.lu, hipMemcpyHostToDevice, s)); HIPCHK(ctx, hipMemcpyAsync(du, u, sz.lu, hipMemcpyHostToDevice, s)); }
+    if (node_of) HIPCHK(ctx, hipMemcpyAsync(dno, node_of, (size_t)pieces * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dK, K, (size_t)pieces * N, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, qpn_launch_local_pieces(pieces, nodes, n, m, p, dQ, dR, dq, dA, dB, dl, du, dno, dK, dAp, dlp, dup, dkeep, s));
+    HIPCHK(ctx, qpn_launch_reduce_pieces(pieces, n, m, p, tol, dAp, dlp, dup, dkeep, dAr, dlr, dur, drows, dflags, s));
+    HIPCHK(ctx, hipMemcpyAsync(Ar, dAr, (size_t)pieces * oc * cap * 8, hipMemcpyDeviceToHost, s));
+    if (cap) {
+        HIPCHK(ctx, hipMemcpyAsync(lr, dlr, (size_t)pieces * cap * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(ur, dur, (size_t)pieces * cap * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(rows, drows, (size_t)pieces * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(flags, dflags, (size_t)pieces * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return QPN_OK;
+}
+
 int qpn_local_pieces(qpn_ctx *ctx, int32_t pieces, int32_t nodes, int32_t n, int32_t m, int32_t p, const double *Qd,
                      const double *R, const double *qd, const double *Ad, const double *B, const double *l,
                      const double *u, const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up,

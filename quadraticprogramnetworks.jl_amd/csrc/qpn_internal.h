@@ -168,6 +168,13 @@ hipError_t qpn_launch_local_pieces(int32_t batch, int32_t nodes, int32_t n, int3
                                    const int32_t *node_of, const uint8_t *K, double *Ap, double *lp, double *up, uint8_t *keep,
                                    hipStream_t stream);
 hipError_t qpn_launch_recipes(int32_t N, const uint8_t *mask, long long first, int32_t count, uint8_t *K, hipStream_t stream);
+// qpn_pieces.hip: a level's recipes / pieces with the multipliers eliminated, one call each
+hipError_t qpn_launch_recipes_batch(int32_t nodes, int32_t N, const uint8_t *masks, const long long *offsets, long long total, uint8_t *K,
+                                    int32_t *node_of, hipStream_t stream);
+size_t qpn_reduce_pieces_lds(int32_t n, int32_t m, int32_t p);
+hipError_t qpn_launch_reduce_pieces(int32_t pieces, int32_t n, int32_t m, int32_t p, double tol, double *Ap, const double *lp,
+                                    const double *up, const uint8_t *keep, double *Ar, double *lr, double *ur, int32_t *rows_out,
+                                    int32_t *flags_out, hipStream_t stream);
 // pool assembly (combine_gavis): all pointers device
 struct QpnPoolLaunch {
     int32_t batch, form, nd, sn, sm, p;

@@ -9,6 +9,7 @@ There is no CPU path here: every method ends in a HIP kernel launch or raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 
 import numpy as np
@@ -61,6 +62,7 @@ class Engine:
             raise QpnError(f"qpn_ctx_create({device}) failed: {self.lib.qpn_strerror(rc).decode()}")
         self.ctx = h
         self.use_torch_stream = use_torch_stream
+        self.calls = collections.Counter()       # C-ABI calls per entry point (the tests assert O(1) calls per level with it)
         self._bound = "own"                      # which stream the context launches on (a new context: its own)
 
     def close(self):
@@ -76,6 +78,7 @@ class Engine:
 
     # -- helpers ---------------------------------------------------------------------------
     def _chk(self, rc, what):
+        self.calls[what] += 1
         if rc != 0:
             msg = self.lib.qpn_ctx_last_error(self.ctx).decode()
             raise QpnError(f"{what}: {self.lib.qpn_strerror(rc).decode()} ({msg})")
@@ -322,6 +325,56 @@ class Engine:
                                        MEM_DEVICE if dev else MEM_HOST)
         self._chk(rc, "qpn_local_pieces")
         return Ap, lp, up, keep
+
+    # -- (F1, a level at a time) --------------------------------------------------------------------
+    def recipes_batch(self, masks, offsets):
+        """all_Ks (src/avi_solutions.jl:200-215) for MANY solutions in one launch (qpn_recipes_batch): masks [nodes, N] uint8,
+        offsets [nodes + 1] int64 (host; node b gets the first offsets[b+1] - offsets[b] recipes of its product).
+        Returns (K [total, N] uint8, node_of [total] int32)."""
+        dev = self._mode(masks)
+        self._bind_stream(dev)
+        if not dev:
+            masks = self._host(masks, np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        nodes, N = int(masks.shape[0]), int(masks.shape[1])
+        if offsets.shape != (nodes + 1,):
+            raise ValueError("recipes_batch: offsets must have nodes + 1 entries")
+        total = int(offsets[-1])
+        K = self._alloc(dev, (total, N), np.uint8)
+        node_of = self._alloc(dev, (total,), np.int32)
+        rc = self.lib.qpn_recipes_batch(self.ctx, nodes, N, _ptr(masks), _ptr(offsets), _ptr(K), _ptr(node_of),
+                                        MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_recipes_batch")
+        return K, node_of
+
+    def reduced_pieces(self, Qc, Rc, qd, Ac, Bc, l, u, K, node_of=None, tol=1e-9):
+        """local_piece (src/avi_solutions.jl:400-496) for recipes K over node records, with the m multiplier columns eliminated
+        through each piece's own equality rows (qpn_reduced_pieces).  Returns (Ar [pieces, n+p, cap] column-major per piece --
+        Ar[t].T is the cap x (n+p) row matrix over [x_d; x_p] --, lr, ur [pieces, cap], rows [pieces], flags [pieces]),
+        cap = n + 2m."""
+        dev = self._mode(Qc, Rc, qd, Ac, Bc, l, u, K, node_of)
+        self._bind_stream(dev)
+        if not dev:
+            Qc, Rc, qd, Ac, Bc, l, u = (self._host(a, np.float64) for a in (Qc, Rc, qd, Ac, Bc, l, u))
+            K = self._host(K, np.uint8)
+            node_of = self._host(node_of, np.int32)
+        else:
+            self._require_dev64(Qc, Rc, qd, Ac, Bc, l, u)
+        nodes, n = qd.shape
+        m = l.shape[1]
+        p = Rc.shape[1]
+        pieces = int(K.shape[0])
+        cap = n + 2 * m
+        Ar = self._alloc(dev, (pieces, n + p, cap), np.float64)
+        lr = self._alloc(dev, (pieces, cap), np.float64)
+        ur = self._alloc(dev, (pieces, cap), np.float64)
+        rows = self._alloc(dev, (pieces,), np.int32)
+        flags = self._alloc(dev, (pieces,), np.int32)
+        rc = self.lib.qpn_reduced_pieces(self.ctx, pieces, nodes, n, m, p, _ptr(Qc), _ptr(Rc), _ptr(qd), _ptr(Ac), _ptr(Bc), _ptr(l),
+                                         _ptr(u), _ptr(node_of), _ptr(K), float(tol), _ptr(Ar), _ptr(lr), _ptr(ur), _ptr(rows),
+                                         _ptr(flags), MEM_DEVICE if dev else MEM_HOST)
+        self._chk(rc, "qpn_reduced_pieces")
+        return Ar, lr, ur, rows, flags
 
     # -- (A6) pool assembly ----------------------------------------------------------------------
     def assemble_pools(self, n_i, m_i, dpos, nd, Qd, Qp, qd, Ad, Bp, l, u, w, form="reduced", share_M=None):

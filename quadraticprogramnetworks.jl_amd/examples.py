@@ -137,29 +137,33 @@ def _robust_avoid_simple(num_obj=2, num_poly_faces=5, seed=1, max_ego_delta=15.0
     return net
 
 
-def _synthetic_pairs(pairs=4, n=4, m=4, seed=20240422, **kwargs):
+def _synthetic_pairs(pairs=4, n=4, m=4, seed=20240422, first=0, **kwargs):
     """`pairs` independent leader-follower pairs in one two-level net (config 4's structure,
     SURVEY.md section 8(d)): leader k owns n variables and has box rows; follower k owns n variables,
-    is coupled to its leader's variables through its cost, and has m two-sided rows."""
+    is coupled to its leader's variables through its cost, and has m two-sided rows.  Costs and rows are given in
+    LOCAL form (the 2n variables of the pair), so the net is as large as one likes: 5 000 pairs x (32, 32) are
+    10 000 nodes over 320 000 variables.  Pair k draws from Philox(seed, 1000 + first + k): a net of one pair with
+    first = k is pair k of the large net on its own."""
     nv = 2 * n * pairs
     net = QPNet(nv)
     leaders, followers = [], []
     for k in range(pairs):
-        g = np.random.Generator(np.random.Philox(key=[seed, 1000 + k]))
+        g = np.random.Generator(np.random.Philox(key=[seed, 1000 + first + k]))
         lv = list(range(2 * n * k, 2 * n * k + n)); fv = list(range(2 * n * k + n, 2 * n * (k + 1)))
+        pv = lv + fv                                             # the pair's variables: local positions 0..n-1 leader, n..2n-1 follower
+        L, F = slice(0, n), slice(n, 2 * n)
         G = g.standard_normal((n, n)); Qf = G.T @ G / n + 0.1 * np.eye(n)
         Rf = 0.3 * g.standard_normal((n, n))
-        Q = np.zeros((nv, nv)); Q[np.ix_(fv, fv)] = Qf; Q[np.ix_(fv, lv)] = Rf; Q[np.ix_(lv, fv)] = Rf.T
-        q = np.zeros(nv); q[fv] = g.standard_normal(n)
-        A = np.zeros((m, nv)); A[:, fv] = g.standard_normal((m, n)) / np.sqrt(n)
-        cid = net.add_constraint(A, -1 - np.abs(g.standard_normal(m)), 1 + np.abs(g.standard_normal(m)))
-        followers.append(net.add_qp(Q, q, [cid], fv))
+        Q = np.zeros((2 * n, 2 * n)); Q[F, F] = Qf; Q[F, L] = Rf; Q[L, F] = Rf.T
+        q = np.zeros(2 * n); q[F] = g.standard_normal(n)
+        A = g.standard_normal((m, n)) / np.sqrt(n)
+        cid = net.add_constraint(A, -1 - np.abs(g.standard_normal(m)), 1 + np.abs(g.standard_normal(m)), cols=fv)
+        followers.append(net.add_qp(Q, q, [cid], fv, idx=pv))
         G2 = g.standard_normal((n, n)); Ql = G2.T @ G2 / n + 0.5 * np.eye(n)
-        Q2 = np.zeros((nv, nv)); Q2[np.ix_(lv, lv)] = Ql; Q2[np.ix_(fv, fv)] = 0.1 * np.eye(n)
-        q2 = np.zeros(nv); q2[lv] = g.standard_normal(n)
-        Bx = np.zeros((n, nv)); Bx[:, lv] = np.eye(n)
-        cid2 = net.add_constraint(Bx, -2 * np.ones(n), 2 * np.ones(n))
-        leaders.append(net.add_qp(Q2, q2, [cid2], lv))
+        Q2 = np.zeros((2 * n, 2 * n)); Q2[L, L] = Ql; Q2[F, F] = 0.1 * np.eye(n)
+        q2 = np.zeros(2 * n); q2[L] = g.standard_normal(n)
+        cid2 = net.add_constraint(np.eye(n), -2 * np.ones(n), 2 * np.ones(n), cols=lv)
+        leaders.append(net.add_qp(Q2, q2, [cid2], lv, idx=pv))
     net.add_edges([(leaders[k], followers[k]) for k in range(pairs)])
     net.assign_constraint_groups()
     net.set_options(**kwargs)

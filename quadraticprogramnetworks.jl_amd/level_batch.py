@@ -1,0 +1,512 @@
+"""A whole LEVEL of a QPNet as batches: the per-node map of process_qp (src/algorithm.jl:44-52), the sub-piece combinations
+of src/qp_processing.jl:162-205 and the level's AVI step (solve_qep, src/avi.jl:382-444) served by O(1) device calls per
+level and outer iteration, whatever the number of nodes.
+
+The reference maps process_qp over the nodes of a level one by one and then forms ONE AVI for all of them
+(src/avi.jl:399-400).  That AVI is block diagonal whenever the level's coupling graph is disconnected -- 5 000 followers
+that read only their own leader are 5 000 independent node-AVIs, not one AVI of 320 000 unknowns -- so here
+
+  * `components` splits the level's pool by the coupling graph (shared decision variables, or a player's KKT rows reading
+    another player's decision variables: src/avi.jl:335-340 puts exactly those columns into M instead of N);
+  * single-node components of equal shape are ONE batch of node records (qpn_solve_nodes / a resident qpn_nodes handle for
+    nodes without children, whose records never change between outer iterations);
+  * multi-node components of equal pool shape are ONE batch of pool AVIs (qpn_assemble_pools + qpn_solve_avi_batch);
+  * `process_level` verifies every node of the level under every combination of its children's pieces in one
+    qpn_verify_nodes call per record shape, and makes the solution-graph pieces of all optimal nodes with one
+    comp_indices / recipes / pieces call each (src/avi.jl:447-477, src/avi_solutions.jl:200-215, :400-496).
+
+A node's parameters are LOCAL here: only the variables its rows actually read (R, B have one column per such variable),
+gathered from the iterate per sweep -- the reference's N = M[:, param_inds] over all n_total - n other variables
+(src/avi.jl:340) is structurally zero outside them.
+
+Everything numeric goes through the engine (the HIP library; the tests' CPU twin serves the same interface).
+"""
+from __future__ import annotations
+
+import itertools
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .programs import Poly
+
+INF = np.inf
+ROW_PAD = 16            # constraint rows of a record batch are padded with inert rows to a multiple of this (one MFMA tile)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# node records
+# ---------------------------------------------------------------------------------------------------------------------
+def _static(qpn, pid: int) -> dict:
+    """What a node's records owe to the net alone: decision indices, Q blocks, the base constraint rows."""
+    cache = qpn.__dict__.setdefault("_node_static", {})
+    st = cache.get(pid)
+    if st is not None:
+        return st
+    qp = qpn.qps[pid]
+    dec = np.asarray(qpn.decision_inds(pid), dtype=np.int64)
+    base = [qpn.constraints[c].poly for c in qp.constraint_indices]
+    f = qp.f
+    supp = [f.row_support(dec)] + [P.support() for P in base]
+    supp = np.unique(np.concatenate(supp)) if supp else np.zeros(0, np.int64)
+    par = np.setdiff1d(supp, dec, assume_unique=True)
+    st = dict(dec=dec, base=base, par=par, Qd=f.block(dec, dec), qd=f.q_at(dec),
+              Ad=(np.vstack([P.block(dec) for P in base]) if base else np.zeros((0, dec.size))),
+              l=(np.concatenate([P.l for P in base]) if base else np.zeros(0)),
+              u=(np.concatenate([P.u for P in base]) if base else np.zeros(0)))
+    cache[pid] = st
+    return st
+
+
+def node_record(qpn, pid: int, child_polys: Sequence[Poly] = ()) -> dict:
+    """Dense record of one node under one choice of its children's pieces (src/qp_processing.jl:62-66: the constraint
+    stack is [base; child pieces]) with LOCAL parameters: dict(pid, dec, par, Qd, R, qd, Ad, B, l, u) in math layout."""
+    st = _static(qpn, pid)
+    dec = st["dec"]
+    f = qpn.qps[pid].f
+    if child_polys:
+        extra = np.unique(np.concatenate([P.support() for P in child_polys]))
+        par = np.union1d(st["par"], np.setdiff1d(extra, dec, assume_unique=True))
+        Ad = np.vstack([st["Ad"]] + [P.block(dec) for P in child_polys])
+        l = np.concatenate([st["l"]] + [P.l for P in child_polys])
+        u = np.concatenate([st["u"]] + [P.u for P in child_polys])
+        cons = list(st["base"]) + list(child_polys)
+    else:
+        par, Ad, l, u, cons = st["par"], st["Ad"], st["l"], st["u"], st["base"]
+    R = f.block(dec, par)
+    B = np.vstack([P.block(par) for P in cons]) if cons else np.zeros((0, par.size))
+    return dict(pid=pid, dec=dec, par=par, Qd=st["Qd"], R=R, qd=st["qd"], Ad=Ad, B=B, l=l, u=u)
+
+
+class RecordBatch:
+    """Records of equal shape (n, padded m, padded p) stacked in the ABI layout (column-major per item)."""
+
+    def __init__(self, recs: List[dict], where: List[int], n: int, m: int, p: int):
+        nb = len(recs)
+        self.where = list(where)                     # positions of these records in the caller's list
+        self.n, self.m, self.p = n, m, p
+        self.m_true = np.array([len(r["l"]) for r in recs], dtype=np.int64)
+        self.Qc = np.zeros((nb, n, n)); self.Rc = np.zeros((nb, p, n)); self.qd = np.zeros((nb, n))
+        self.Ac = np.zeros((nb, n, m)); self.Bc = np.zeros((nb, p, m))
+        self.l = np.full((nb, m), -INF); self.u = np.full((nb, m), INF)      # missing rows: 0'x in (-inf, inf) -- inert
+        self.dec = np.zeros((nb, n), dtype=np.int64)
+        self.par = np.full((nb, p), -1, dtype=np.int64)                      # missing parameters: a zero column, w = 0
+        for b, r in enumerate(recs):
+            mi, pi = len(r["l"]), r["par"].size
+            self.Qc[b] = r["Qd"].T
+            self.Rc[b, :pi] = r["R"].T
+            self.qd[b] = r["qd"]
+            self.Ac[b, :, :mi] = r["Ad"].T
+            self.Bc[b, :pi, :mi] = r["B"].T
+            self.l[b, :mi] = r["l"]; self.u[b, :mi] = r["u"]
+            self.dec[b] = r["dec"]; self.par[b, :pi] = r["par"]
+        self.handle = None                           # resident copy (engine.upload_nodes), when the records are static
+        self.handle_engine = None
+
+    def __len__(self):
+        return len(self.where)
+
+    def gather(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        xd = x[self.dec]
+        w = np.where(self.par >= 0, x[np.maximum(self.par, 0)], 0.0)
+        return xd, w
+
+    def resident(self, engine):
+        """The records as a resident handle of `engine` (made once), or None when the engine has no such thing."""
+        if not hasattr(engine, "upload_nodes"):
+            return None
+        if self.handle is None or self.handle_engine is not engine:
+            self.handle = engine.upload_nodes(self.Qc, self.Rc, self.qd, self.Ac, self.Bc, self.l, self.u)
+            self.handle_engine = engine
+        return self.handle
+
+
+def batch_records(recs: List[dict], row_pad: int = ROW_PAD) -> List[RecordBatch]:
+    """Group records by (n, m rounded up to a multiple of row_pad); p is padded to the group's widest record (>= 1)."""
+    groups: Dict[tuple, List[int]] = {}
+    for i, r in enumerate(recs):
+        m = len(r["l"])
+        mp = max(row_pad, -(-m // row_pad) * row_pad) if m else 0
+        groups.setdefault((r["dec"].size, mp), []).append(i)
+    out = []
+    for (n, mp), idx in sorted(groups.items()):
+        p = max(1, max(recs[i]["par"].size for i in idx))
+        out.append(RecordBatch([recs[i] for i in idx], idx, n, mp, p))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the level's pool split into connected components
+# ---------------------------------------------------------------------------------------------------------------------
+def components(qpn, players: Sequence[int], assign: Optional[Dict[int, Poly]] = None) -> List[List[int]]:
+    """Connected components of the level's coupling graph.  Players i and j are coupled when they share a decision
+    variable or when the KKT rows of one (Q_i[dvars_i, :], its base rows, its children's chosen pieces) read a decision
+    variable of the other: those are the columns src/avi.jl:335-340 keeps in M.  Components come back as sorted id lists,
+    ordered by their smallest id."""
+    assign = assign or {}
+    players = sorted(players)
+    owner: Dict[int, int] = {}
+    parent = {i: i for i in players}
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    decs = {}
+    for i in players:
+        st = _static(qpn, i)
+        decs[i] = st["dec"]
+        for v in st["dec"].tolist():
+            o = owner.get(v)
+            if o is None:
+                owner[v] = i
+            else:
+                ra, rb = find(o), find(i)
+                if ra != rb:
+                    parent[max(ra, rb)] = min(ra, rb)
+    for i in players:
+        reads = [_static(qpn, i)["par"]]
+        for j in sorted(qpn.network_edges[i]):
+            if j in assign:
+                reads.append(assign[j].support())
+        for v in np.unique(np.concatenate(reads)).tolist():
+            o = owner.get(v)
+            if o is not None:
+                ra, rb = find(o), find(i)
+                if ra != rb:
+                    parent[max(ra, rb)] = min(ra, rb)
+    comps: Dict[int, List[int]] = {}
+    for i in players:
+        comps.setdefault(find(i), []).append(i)
+    return [sorted(c) for _, c in sorted(comps.items())]
+
+
+def _pool_blocks_local(qpn, pool: List[int], assign: Dict[int, Poly]):
+    """The numeric blocks of ONE multi-node component as qpn_assemble_pools takes them (avi.pool_blocks), with the
+    component's own decision set and local parameters."""
+    stat = {i: _static(qpn, i) for i in pool}
+    dec = np.unique(np.concatenate([stat[i]["dec"] for i in pool]))
+    cons = {i: list(stat[i]["base"]) + [assign[j] for j in sorted(qpn.network_edges[i]) if j in assign] for i in pool}
+    reads = [stat[i]["par"] for i in pool] + [P.support() for i in pool for P in cons[i][len(stat[i]["base"]):]]
+    par = np.setdiff1d(np.unique(np.concatenate(reads)), dec, assume_unique=True)
+    pos = {int(d): k for k, d in enumerate(dec.tolist())}
+    n_i = [stat[i]["dec"].size for i in pool]
+    m_i = [sum(len(P) for P in cons[i]) for i in pool]
+    dpos = [pos[int(d)] for i in pool for d in stat[i]["dec"].tolist()]
+    f = {i: qpn.qps[i].f for i in pool}
+    zero_d = np.zeros((0, dec.size)); zero_p = np.zeros((0, par.size))
+    Qd = np.vstack([f[i].block(stat[i]["dec"], dec) for i in pool])
+    Qp = np.vstack([f[i].block(stat[i]["dec"], par) for i in pool])
+    qd = np.concatenate([stat[i]["qd"] for i in pool])
+    Ad = np.vstack([zero_d] + [P.block(dec) for i in pool for P in cons[i]])
+    Bp = np.vstack([zero_p] + [P.block(par) for i in pool for P in cons[i]])
+    l = np.concatenate([np.zeros(0)] + [P.l for i in pool for P in cons[i]])
+    u = np.concatenate([np.zeros(0)] + [P.u for i in pool for P in cons[i]])
+    return dict(n_i=n_i, m_i=m_i, dpos=dpos, nd=int(dec.size), Qd=Qd, Qp=Qp, qd=qd, Ad=Ad, Bp=Bp, l=l, u=u, dec=dec, par=par)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# solve_qep for a level: src/avi.jl:382-444 over the components
+# ---------------------------------------------------------------------------------------------------------------------
+def _leaf_batches(qpn, players, engine):
+    """Record batches of the childless nodes among `players`: they depend on the net alone, so they are built once per
+    (net, player set) and keep a resident handle."""
+    cache = qpn.__dict__.setdefault("_leaf_batches", {})
+    key = tuple(players)
+    got = cache.get(key)
+    if got is None:
+        recs = [node_record(qpn, i) for i in players]
+        got = cache[key] = (recs, batch_records(recs))
+    return got
+
+
+def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]] = None, engine=None, reference_form=False):
+    """solve_qep (src/avi.jl:382-444) for a whole level: x_opt with every component's decision block replaced by the
+    solution of its AVI.  Raises avi.AVISolveError when any component's solve does not end in SUCCESS (:426)."""
+    from .avi import AVISolveError, StatusCode, _eng
+    from .engine import colmajor
+    eng = _eng(engine)
+    assign = assign or {}
+    x = np.asarray(x, dtype=np.float64)
+    x_opt = x.copy()
+    comps = components(qpn, players, assign)
+    singles = [c[0] for c in comps if len(c) == 1]
+    multis = [c for c in comps if len(c) > 1]
+    bad = []
+    # ---- single-node components: node records, one call per record shape
+    leaf = [i for i in singles if not qpn.network_edges[i]]
+    inner = [i for i in singles if qpn.network_edges[i]]
+    work = []
+    if leaf and not reference_form:
+        work += [(b, True) for b in _leaf_batches(qpn, leaf, eng)[1]]
+    elif leaf:
+        inner = sorted(inner + leaf)
+    if inner:
+        recs = [node_record(qpn, i, [assign[j] for j in sorted(qpn.network_edges[i]) if j in assign]) for i in inner]
+        if reference_form:
+            work += [(r, None) for r in recs]
+        else:
+            work += [(b, False) for b in batch_records(recs)]
+    for item, static in work:
+        if static is None:
+            _solve_single_reference_form(item, x, x_opt, eng, bad)
+            continue
+        b = item
+        xd, w = b.gather(x)
+        z0 = np.zeros((len(b), b.n + b.m)); z0[:, :b.n] = xd                        # duals cold, :404
+        h = b.resident(eng) if static else None
+        if h is not None:
+            res = h.solve(w, want=("z", "resid", "pivots"))
+        else:
+            res = eng.solve_nodes(b.Qc, b.Rc, b.qd, b.Ac, b.Bc, b.l, b.u, w, z0=z0)
+        st = np.asarray(res["status"])
+        z = np.asarray(res["z"])
+        if np.any(st != StatusCode.SUCCESS):
+            k = int(np.nonzero(st != StatusCode.SUCCESS)[0][0])
+            bad.append((int(b.dec[k][0]), int(st[k])))
+        x_opt[b.dec.ravel()] = z[:, :b.n].ravel()                                    # :440-443
+    # ---- multi-node components: pool AVIs, one assemble + one solve per pool shape
+    if multis:
+        blocks = [_pool_blocks_local(qpn, c, assign) for c in multis]
+        sig: Dict[tuple, List[int]] = {}
+        for k, bl in enumerate(blocks):
+            disjoint = sum(bl["n_i"]) == bl["nd"]
+            form = "reference" if (reference_form or not disjoint) else "reduced"
+            sig.setdefault((tuple(bl["n_i"]), tuple(bl["m_i"]), tuple(bl["dpos"]), bl["nd"], bl["par"].size, form), []).append(k)
+        for key, ks in sorted(sig.items()):
+            form = key[-1]
+            b0 = blocks[ks[0]]
+            p = max(1, b0["par"].size)
+            pad = lambda M: np.hstack([M, np.zeros((M.shape[0], p - M.shape[1]))]) if M.shape[1] < p else M
+            stack = lambda name: np.stack([colmajor(pad(blocks[k][name]) if name in ("Qp", "Bp") else blocks[k][name]) for k in ks])
+            w = np.stack([np.concatenate([x[blocks[k]["par"]], np.zeros(p - blocks[k]["par"].size)]) for k in ks])
+            Mc, q, lo, hi, kind = eng.assemble_pools(b0["n_i"], b0["m_i"], b0["dpos"], b0["nd"], stack("Qd"), stack("Qp"),
+                                                     np.stack([blocks[k]["qd"] for k in ks]), stack("Ad"), stack("Bp"),
+                                                     np.stack([blocks[k]["l"] for k in ks]), np.stack([blocks[k]["u"] for k in ks]),
+                                                     w, form=form, share_M=False)
+            q = np.asarray(q); Nn = q.shape[-1]
+            nd = b0["nd"]
+            z0 = np.zeros((len(ks), Nn))
+            for t, k in enumerate(ks):
+                z0[t, :nd] = x[blocks[k]["dec"]]
+                if form == "reference":
+                    sm = len(blocks[k]["l"])
+                    if sm:                                                          # z0s = [z0; A z0 + B w], :107-108
+                        z0[t, Nn - sm:] = blocks[k]["Ad"] @ x[blocks[k]["dec"]] + blocks[k]["Bp"] @ x[blocks[k]["par"]]
+            res = eng.solve_avi_batch(np.asarray(Mc).reshape(len(ks), Nn, Nn), q.reshape(len(ks), Nn), np.asarray(lo).reshape(len(ks), Nn),
+                                      np.asarray(hi).reshape(len(ks), Nn), z0=z0, kind=np.asarray(kind).reshape(len(ks), Nn))
+            st = np.asarray(res["status"]); z = np.asarray(res["z"])
+            for t, k in enumerate(ks):
+                if int(st[t]) != StatusCode.SUCCESS:
+                    bad.append((multis[k], int(st[t])))
+                x_opt[blocks[k]["dec"]] = z[t, :nd]
+    if bad:
+        raise AVISolveError(f"AVI solve error. This might be because one of the qps {list(players)} is unbounded or "
+                            f"ill-conditioned. (first failures: {bad[:4]})")
+    return x_opt
+
+
+def _solve_single_reference_form(rec, x, x_opt, eng, bad):
+    """One single-node component through the reference's own AVI (xi and slack blocks, convert(): src/avi.jl:113-128) --
+    the parity route of solve_qep(reference_form=True)."""
+    from .avi import GAVI, StatusCode, solve_gavi
+    n, m = rec["dec"].size, len(rec["l"])
+    # z = [x_d; xi; lambda], rows [sum xi = 0 ; KKT rows], A = [Ad 0 0]
+    M = np.block([[np.zeros((n, n)), np.eye(n), np.zeros((n, m))], [rec["Qd"], np.zeros((n, n)), -rec["Ad"].T]])
+    Nn = np.vstack([np.zeros((n, rec["par"].size)), rec["R"]])
+    o = np.concatenate([np.zeros(n), rec["qd"]])
+    A = np.hstack([rec["Ad"], np.zeros((m, n + m))])
+    g = GAVI(M, Nn, o, np.full(2 * n, -INF), np.full(2 * n, INF), A, rec["B"], rec["l"], rec["u"])
+    z0 = np.zeros(2 * n + m); z0[:n] = x[rec["dec"]]
+    z, status, _ = solve_gavi(g, z0, x[rec["par"]], engine=eng, reference_form=True)
+    if status != StatusCode.SUCCESS:
+        bad.append((rec["pid"], int(status)))
+    x_opt[rec["dec"]] = z[:n]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# process_qp for a level: src/algorithm.jl:44-52 over src/qp_processing.jl:151-241
+# ---------------------------------------------------------------------------------------------------------------------
+_VERIFY_MSGS = {0: "Current point is infeasible when using tolerance {tol}.", 1: "Current point is suboptimal",
+                4: "Current point is suboptimal (via QP).", 5: "Solving for duals failed."}
+
+
+def verify_items(qpn, items, x, engine, tol=1e-4):
+    """verify_solution (src/qp_processing.jl:57-149) for MANY (node, child pieces) items: one qpn_verify_nodes call per
+    record shape.  items: list of (pid, [child Poly, ...]).  Returns (records, batches, one result dict per item)."""
+    eng = engine
+    leaf_ids = tuple(pid for pid, ch in items if not ch)
+    all_leaf = len(leaf_ids) == len(items)
+    if all_leaf:
+        recs, batches = _leaf_batches(qpn, list(leaf_ids), eng)
+    else:
+        recs = [node_record(qpn, pid, ch) for pid, ch in items]
+        batches = batch_records(recs)
+    out = [None] * len(items)
+    for b in batches:
+        xd, w = b.gather(x)
+        h = b.resident(eng) if all_leaf else None
+        if h is not None:
+            sol, lam, path = h.verify(xd, w, tol=tol)
+        else:
+            sol, lam, path = eng.verify_nodes(b.Qc, b.Rc, b.qd, b.Ac, b.Bc, b.l, b.u, xd, w, tol=tol)
+        sol = np.asarray(sol); lam = np.asarray(lam); path = np.asarray(path)
+        for k, i in enumerate(b.where):
+            pth = int(path[k]); ok = bool(sol[k]); mi = int(b.m_true[k])
+            out[i] = dict(solution=ok, lam=(lam[k, :mi].copy() if pth in (1, 2, 3, 4) else None),
+                          e=None if ok else _VERIFY_MSGS.get(pth, "").format(tol=tol), path=pth)
+        b.last = dict(xd=xd, w=w, lam=lam)
+    return recs, batches, out
+
+
+def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], tol=1e-2, max_pieces=64):
+    """The solution-graph pieces of MANY nodes around (x, lambda) (process_solution_graph, src/avi.jl:447-477 ->
+    comp_indices -> all_Ks, src/avi_solutions.jl:200-215 -> local_piece, :400-496 -> the multipliers eliminated, the
+    columns permuted back, :86-87), batched: per record shape one comp_indices pair, one recipes call, one pieces call.
+    Returns a list (per item; None where `want` is False) of lists of Poly in global coordinates."""
+    from .avi_solutions import _dedupe
+    eng = engine
+    x = np.asarray(x, dtype=np.float64)
+    out: List[Optional[list]] = [None] * len(recs)
+    for b in batches:
+        sel = [k for k, i in enumerate(b.where) if want[i]]
+        if not sel:
+            continue
+        n, m, p = b.n, b.m, b.p
+        xd, w = b.last["xd"], b.last["w"]
+        lam = np.zeros((len(b), m))
+        for k, i in enumerate(b.where):
+            if want[i]:
+                lam[k, :b.m_true[k]] = rets[i]["lam"]
+        # the node's own GAVI at z = [x_d; lambda], w = x_p (src/avi.jl:447-477): r1 = Qd x + R w + qd - Ad' lambda, s = Ad x + B w
+        r1 = np.einsum("bji,bj->bi", b.Qc, xd) + np.einsum("bji,bj->bi", b.Rc, w) + b.qd - np.einsum("bij,bj->bi", b.Ac, lam)
+        s = np.einsum("bji,bj->bi", b.Ac, xd) + np.einsum("bji,bj->bi", b.Bc, w)
+        free_lo = np.full((len(sel), n), -INF); free_hi = np.full((len(sel), n), INF)
+        m1 = np.asarray(eng.comp_indices(xd[sel], r1[sel], free_lo, free_hi, tol=tol, shift=0))
+        m2 = np.asarray(eng.comp_indices(s[sel], lam[sel], b.l[sel], b.u[sel], tol=tol, shift=4)) if m else np.zeros((len(sel), 0), np.uint8)
+        for t, k in enumerate(sel):                          # inert padding rows: l = -inf, u = inf, lambda = 0 -> code 6 only
+            m2[t, b.m_true[k]:] = 1 << 5
+        masks = np.concatenate([m1, m2], axis=1).astype(np.uint8)
+        ok = ~np.any(masks == 0, axis=1)                     # a zero mask: (x, lambda) is no solution of the GAVI at this tolerance
+        pop = np.array([[bin(int(v)).count("1") for v in row] for row in masks], dtype=np.float64)
+        total = np.where(ok, np.prod(np.maximum(pop, 1.0), axis=1), 0.0)
+        counts = np.minimum(total, max_pieces).astype(np.int64)
+        for t, k in enumerate(sel):
+            if total[t] > max_pieces:
+                warnings.warn(f"node {recs[b.where[k]]['pid']}: {int(total[t])} local recipes, only the first {max_pieces} "
+                              "are expanded (max_pieces)")
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        if offsets[-1] == 0:
+            for k in sel:
+                out[b.where[k]] = []
+            continue
+        K, node_of = eng.recipes_batch(masks, offsets)
+        node_of = np.asarray(node_of)
+        rec_of = np.asarray(sel, dtype=np.int32)[node_of]    # recipe -> record inside the batch
+        Ar, lr, ur, rows, flags = eng.reduced_pieces(b.Qc, b.Rc, b.qd, b.Ac, b.Bc, b.l, b.u, np.asarray(K), rec_of)
+        Ar = np.asarray(Ar); lr = np.asarray(lr); ur = np.asarray(ur); rows = np.asarray(rows); flags = np.asarray(flags)
+        for k in sel:
+            out[b.where[k]] = []
+        for t in range(len(node_of)):
+            k = int(rec_of[t]); i = b.where[k]
+            if flags[t]:
+                P = _reduce_on_host(b, k, np.asarray(K)[t], eng)
+            else:
+                r = int(rows[t])
+                P = (Ar[t, :, :r].T, lr[t, :r], ur[t, :r])             # [rows, n + p] over [x_d; x_p]
+            if P is None:
+                continue
+            Al, ll, ul = P
+            pk = b.par[k] >= 0
+            cols = np.concatenate([b.dec[k], b.par[k][pk]])
+            Pg = _dedupe(Poly.from_local(qpn.num_vars, cols, np.hstack([Al[:, :n], Al[:, n:][:, pk]]), ll, ul))
+            if Pg.contains(x, tol=10 * tol):
+                out[i].append(Pg)
+    return out
+
+
+def _reduce_on_host(b, k, Krow, eng):
+    """A piece the device elimination flagged (a multiplier no equality row pins: Fourier-Motzkin, polyhedral) goes
+    through the host restatement (avi_solutions.eliminate_multipliers)."""
+    from .avi_solutions import eliminate_multipliers
+    Ap, lp, up, keep = eng.local_pieces(b.Qc[k:k + 1], b.Rc[k:k + 1], b.qd[k:k + 1], b.Ac[k:k + 1], b.Bc[k:k + 1], b.l[k:k + 1],
+                                        b.u[k:k + 1], np.asarray(Krow, dtype=np.uint8)[None], node_of=np.zeros(1, np.int32))
+    rows = np.asarray(keep[0]).astype(bool)
+    P = Poly(np.asarray(Ap[0]).T[rows], np.asarray(lp[0])[rows], np.asarray(up[0])[rows], normalise=False)
+    try:
+        Pl = eliminate_multipliers(P, b.n, b.m)
+    except RuntimeError:
+        return None
+    return Pl.vectorize()
+
+
+def process_level(qpn, players: Sequence[int], x, S: Dict[int, list], engine=None, exploration_vertices=0):
+    """results = map(process_qp(qpn, id, x, S) for id in players) (src/algorithm.jl:44-52) as batches: every node under
+    every combination of its children's pieces (src/qp_processing.jl:162-205) in one verify call per record shape, the
+    solution graphs of the optimal ones in one call chain per record shape.  Returns one process_qp result per player."""
+    from .avi import _eng
+    from .qp_processing import combine_many
+    eng = _eng(engine)
+    x = np.asarray(x, dtype=np.float64)
+    items, owner = [], []
+    combos_of = {}
+    for pid in players:
+        children = sorted(qpn.network_edges[pid])
+        if children:
+            cards = [range(len(S[j])) for j in children]
+            if any(len(c) < 1 for c in cards):
+                raise RuntimeError("Solution graphs were not properly populated.")
+            combos = list(itertools.product(*cards))
+        else:
+            combos = [()]
+        combos_of[pid] = (children, combos)
+        for combo in combos:
+            items.append((pid, [S[j][ji] for j, ji in zip(children, combo)]))
+            owner.append(pid)
+    recs, batches, rets = verify_items(qpn, items, x, eng)
+    results = {}
+    first = {}
+    for i, (pid, _) in enumerate(items):
+        first.setdefault(pid, i)
+    want = [False] * len(items)
+    for pid in players:
+        children, combos = combos_of[pid]
+        i0 = first[pid]
+        fail = next((t for t in range(len(combos)) if not rets[i0 + t]["solution"]), None)
+        if fail is not None:                                                        # the first failure in product order, :206-216
+            results[pid] = dict(solution=False, e=rets[i0 + fail]["e"], failed=False,
+                                subpiece_assignments={j: ji for j, ji in zip(children, combos[fail])} if children else {})
+            continue
+        gen = (pid not in qpn.network_depth_map[1]) or qpn.options.gen_solution_map
+        results[pid] = dict(solution=True, S=None, failed=False)
+        if gen:
+            for t in range(len(combos)):
+                want[i0 + t] = True
+    if any(want):
+        pieces = solution_pieces(qpn, recs, batches, rets, x, eng, want)
+        jobs, job_pid = [], []
+        for pid in players:
+            children, combos = combos_of[pid]
+            i0 = first[pid]
+            if not want[i0]:
+                continue
+            per_combo = [pieces[i0 + t] for t in range(len(combos))]
+            if len(combos) == 1:
+                results[pid]["S"] = per_combo[0]                                    # combine(...) with one solution set, :271-272
+            else:
+                jobs.append(([[S[j][ji] for j, ji in zip(children, combo)] for combo in combos], per_combo))
+                job_pid.append(pid)
+        if jobs:                                                                    # all kinks of the level: one batch of LPs
+            for pid, got in zip(job_pid, combine_many(jobs, x, eng)):
+                if isinstance(got, RuntimeError):
+                    results[pid] = dict(solution=False, failed=True, S=None)        # :219-223
+                else:
+                    results[pid]["S"] = got
+        for pid in players:
+            if results[pid].get("solution") and want[first[pid]] and len(results[pid]["S"]) == 0:
+                raise RuntimeError("This shouldn't happen. Solution graph is empty.")
+    return [results[pid] for pid in players]

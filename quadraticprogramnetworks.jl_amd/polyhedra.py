@@ -92,9 +92,11 @@ def issubset_batch(pairs, engine, tol=1e-6):
                 queries.append((np.vstack([A1, A2[i:i + 1]]), np.append(l1, u2[i] + tol), np.append(u1, INF))); owner.append(k)
     out = np.ones(len(pairs), bool)
     if queries:
-        empty = isempty_batch(queries, engine)
-        for e, k in zip(empty, owner):
-            if not e:
+        # a query the solver neither answers with a point (SUCCESS) nor with a ray (RAY_TERM: empty) counts against the subset
+        # claim, as the reference's `ret.info.status_val != 1 -> return false` does (src/sets.jl:397-398): the piece is kept
+        _, _, status = exemplar_batch(queries, engine)
+        for st, k in zip(status, owner):
+            if st != 2:
                 out[k] = False
     return out
 
@@ -115,6 +117,42 @@ def remove_subsets(polys, engine, tol=1e-6):
         if any(j != i and not is_subset[j] and sub[i, j] for j in range(k)):
             is_subset[i] = True
     return [p for p, s in zip(polys, is_subset) if not s], is_subset
+
+
+def remove_subsets_many(lists, engine, tol=1e-6):
+    """`remove_subsets` (src/sets.jl:889-902) for the solution graphs of ALL nodes of a level at once (src/algorithm.jl:84
+    applies it to every node's S): the k (k - 1) subset tests of every list go out as ONE `issubset_batch` call.  Every list is
+    first brought down to the columns its pieces touch (a large net's pieces are local).  -> list of kept lists."""
+    jobs, where = [], []
+    comp = []
+    for a, polys in enumerate(lists):
+        k = len(polys) if polys is not None else 0
+        if k < 2:
+            comp.append(None)
+            continue
+        cols = np.unique(np.concatenate([P.support() for P in polys]))
+        trips = [(P.block(cols), P.l, P.u) for P in polys]
+        comp.append(trips)
+        for i in range(k):
+            for j in range(k):
+                if i != j:
+                    jobs.append((trips[i], trips[j])); where.append((a, i, j))
+    res = issubset_batch(jobs, engine, tol=tol) if jobs else []
+    sub = {}
+    for (a, i, j), r in zip(where, res):
+        sub[(a, i, j)] = bool(r)
+    out = []
+    for a, polys in enumerate(lists):
+        if comp[a] is None:
+            out.append(polys)
+            continue
+        k = len(polys)
+        is_subset = np.zeros(k, bool)
+        for i in range(k):
+            if any(j != i and not is_subset[j] and sub[(a, i, j)] for j in range(k)):
+                is_subset[i] = True
+        out.append([P for P, s_ in zip(polys, is_subset) if not s_])
+    return out
 
 
 # ---- the reference's own rules on the same solver: LPs as node-AVIs with Q = 0 --------------------------------------------

@@ -102,59 +102,108 @@ def solve_qp(Q, q, A, l, u, solver="PATH", engine=None):
 
 
 def process_qp(qpn, pid: int, x, S: Dict[int, list], engine=None, exploration_vertices=0):
-    """src/qp_processing.jl:151-241.  S maps child id -> list of Poly pieces.  For every combination of the children's
-    pieces (:162-169) the node is verified (:187, one batched call).  Solution-graph generation (:193-198, :231): the pieces
-    come from the device kernels (avi_solutions.solution_graph_pieces: masks -> qpn_recipes_from_masks -> qpn_local_pieces)
-    for leaves and for every sub-piece combination of an inner node; an inner node returns each combination's pieces
-    intersected with the child pieces they were derived under -- the first generation of what combine(...) (:219,
-    IntersectionRoot, polyhedral: out of scope) would enumerate, without its exploration."""
-    qp = qpn.qps[pid]
-    base = [qpn.constraints[c].poly for c in qp.constraint_indices]
-    dec_inds = qpn.decision_inds(pid)
-    gen = (pid not in qpn.network_depth_map[1]) or qpn.options.gen_solution_map
-    children = sorted(qpn.network_edges[pid])
-    if children:
-        cards = [range(len(S[j])) for j in children]
-        if any(len(c) < 1 for c in cards):
-            raise RuntimeError("Solution graphs were not properly populated.")
-        # every combination is verified (the reference maps over all of them, :171-205, and then reports the
-        # first failure in product order, :206-216): ONE batched call instead of one call per combination
-        combos = list(itertools.product(*cards))
-        rets = verify_solutions_batched(qp, pid, [base + [S[j][ji] for j, ji in zip(children, combo)] for combo in combos],
-                                        dec_inds, x, engine=engine)
-        for combo, ret in zip(combos, rets):
-            if not ret["solution"]:
-                return dict(solution=False, e=ret["e"], failed=False,
-                            subpiece_assignments={j: ji for j, ji in zip(children, combo)})
-        S_out = None
-        if gen:
-            # :193-198 per combination: the node's GAVI under this combination's child pieces -> device pieces
-            S_out = []
-            for combo, ret in zip(combos, rets):
-                cons = base + [S[j][ji] for j, ji in zip(children, combo)]
-                rec = node_record(qp, cons, dec_inds, x)
-                pieces = solution_graph_pieces(qp.f.Q, qp.f.q, rec["A"], rec["l"], rec["u"], dec_inds, np.asarray(x), ret["lam"],
-                                               engine=engine)
-                child = [S[j][ji] for j, ji in zip(children, combo)]
-                for P in pieces:
-                    Ap, lp, up = P.vectorize()
-                    rows = [c.vectorize() for c in child]
-                    S_out.append(Poly(np.vstack([Ap] + [r[0] for r in rows]), np.concatenate([lp] + [r[1] for r in rows]),
-                                      np.concatenate([up] + [r[2] for r in rows])))
-            if len(S_out) == 0:
-                raise RuntimeError("This shouldn't happen. Solution graph is empty.")
-        return dict(solution=True, S=S_out, failed=False)
-    ret = verify_solution(qp, pid, base, dec_inds, x, engine=engine)
-    if not ret["solution"]:
-        return dict(solution=False, e=ret["e"], failed=False, subpiece_assignments={})
-    S_out = None
-    if gen:
-        rec = node_record(qp, base, dec_inds, x)
-        S_out = solution_graph_pieces(qp.f.Q, qp.f.q, rec["A"], rec["l"], rec["u"], dec_inds, np.asarray(x), ret["lam"],
-                                      engine=engine)
-        if len(S_out) == 0:
-            raise RuntimeError("This shouldn't happen. Solution graph is empty.")
-    return dict(solution=True, S=S_out, failed=False)
+    """src/qp_processing.jl:151-241 for ONE node.  S maps child id -> list of Poly pieces.  For every combination of the
+    children's pieces (:162-169) the node is verified (:187, one batched call); if it is optimal under all of them and a
+    solution graph is wanted (:158), each combination's pieces come from the device kernels (masks -> recipes -> local pieces
+    with the multipliers eliminated) and are put together by `combine_at` (:219, :260-291).  The outer loop does not call this
+    per node: level_batch.process_level serves all nodes of a level with the same calls (src/algorithm.jl:44-52)."""
+    from .level_batch import process_level
+    return process_level(qpn, [pid], x, S, engine=engine, exploration_vertices=exploration_vertices)[0]
+
+
+def _halfspace_complements(P: Poly, cols, x, tol=1e-6):
+    """complement(p::Poly) (src/sets.jl:918-930) over the compressed columns `cols`: one open half-space per finite bound of
+    every row.  Returns (all of them, the ones whose closure contains x)."""
+    A = P.block(cols)
+    xs = np.asarray(x, dtype=np.float64)[cols]
+    every, near = [], []
+    for i in range(A.shape[0]):
+        ax = float(A[i] @ xs)
+        if np.isfinite(P.l[i]):                             # a'x < l (the relation complemented: closed -> open)
+            H = Poly(A[i:i + 1], [-INF], [P.l[i]], normalise=False, open_hi=[not P.open_lo[i]])
+            every.append(H)
+            if ax <= P.l[i] + tol:
+                near.append(H)
+        if np.isfinite(P.u[i]):                             # a'x > u
+            H = Poly(A[i:i + 1], [P.u[i]], [INF], normalise=False, open_lo=[not P.open_hi[i]])
+            every.append(H)
+            if ax >= P.u[i] - tol:
+                near.append(H)
+    return every, near
+
+
+def _combine_products(regions: List[List[Poly]], solutions: List[List[Poly]], x):
+    """The candidate products of combine(...) for one node: (cols, ncols, products), every product a Poly over the compressed
+    columns `cols` whose closure contains x; raises RuntimeError on the reference's size guard (src/qp_processing.jl:281-285)."""
+    x = np.asarray(x, dtype=np.float64)
+    polys = [P for R in regions for P in R] + [P for Sg in solutions for P in Sg]
+    cols = np.unique(np.concatenate([P.support() for P in polys])) if polys else np.zeros(0, np.int64)
+    ncols = polys[0].ncols if polys else len(x)
+    widths, cands = [], []
+    for R, Sg in zip(regions, solutions):
+        every, near = [], []
+        for P in R:
+            e, nr = _halfspace_complements(P, cols, x)
+            every += e; near += nr
+        widths.append(len(Sg) + len(every))
+        mine = [(False, Poly(P.block(cols), P.l, P.u, normalise=False, open_lo=P.open_lo, open_hi=P.open_hi)) for P in Sg]
+        cands.append(mine + [(True, H) for H in near])
+    if len(widths) > 3 and sum(widths) > 20:                # :281-285
+        raise RuntimeError("Too many solutions to combine.")
+    xs = x[cols]
+    prods = []
+    for choice in itertools.product(*cands):
+        if all(c[0] for c in choice):                       # complement pieces only: the redzone (src/intersection.jl:124)
+            continue
+        A = np.vstack([c[1].A for c in choice]); l = np.concatenate([c[1].l for c in choice]); u = np.concatenate([c[1].u for c in choice])
+        olo = np.concatenate([c[1].open_lo for c in choice]); ohi = np.concatenate([c[1].open_hi for c in choice])
+        if not Poly(A, l, u, normalise=False).contains(xs):                         # central_point in closure(...), src/intersection.jl:74
+            continue
+        prods.append(Poly(A, l, u, normalise=False, open_lo=olo, open_hi=ohi))
+    return cols, ncols, prods
+
+
+def combine_many(jobs, x, engine, tol=1e-4):
+    """combine(regions, solutions, x) (src/qp_processing.jl:260-291) for ALL nodes of a level that are optimal under SEVERAL
+    combinations of their children's pieces (x sits on a kink of a child's solution graph).  Per node
+
+        S = intersection over the combinations i of ( S_i  union  complement(R_i) ),
+
+    R_i = the intersection of combination i's child pieces, S_i = the node's solution pieces under it.  The reference
+    enumerates the products lazily (IntersectionRoot, src/intersection.jl:55-138) and keeps a product when the current point
+    lies in its closure and it is not empty (:74, :83), skipping products made of complement pieces only (the "redzone",
+    :124).  Only candidates whose closure contains x can survive, so they alone are expanded; the emptiness questions of all
+    nodes go to the engine as ONE batch of LPs (polyhedra.isempty_slack_batch: `isempty`, src/sets.jl:647-655 -> `exemplar`,
+    :591-642, open bounds included).  jobs: list of (regions, solutions); returns per job the list of pieces (global
+    coordinates) or the RuntimeError of the reference's size guard (:281-285) for the caller to turn into failed = true."""
+    from .polyhedra import isempty_slack_batch
+    prep, flat, owner = [], [], []
+    for k, (regions, solutions) in enumerate(jobs):
+        try:
+            cols, ncols, prods = _combine_products(regions, solutions, x)
+        except RuntimeError as err:
+            prep.append(err)
+            continue
+        prep.append((cols, ncols, prods))
+        flat += prods; owner += [k] * len(prods)
+    empty = isempty_slack_batch(flat, engine, tol=tol) if flat else []
+    out = []
+    for k, pr in enumerate(prep):
+        if isinstance(pr, RuntimeError):
+            out.append(pr)
+            continue
+        cols, ncols, _ = pr
+        out.append([Poly.from_local(ncols, cols, P.A, P.l, P.u, normalise=False, open_lo=P.open_lo, open_hi=P.open_hi)
+                    for P, e, o in zip(flat, empty, owner) if o == k and not e])
+    return out
+
+
+def combine_at(regions: List[List[Poly]], solutions: List[List[Poly]], x, engine, tol=1e-4):
+    """combine_many for one node; raises the size guard's RuntimeError."""
+    got = combine_many([(regions, solutions)], x, engine, tol=tol)[0]
+    if isinstance(got, RuntimeError):
+        raise got
+    return got
 
 
 def local_recipe_count(qpn, pid: int, x, S: Dict[int, list], engine=None):

@@ -19,7 +19,9 @@ def test_reference_end_to_end_cases_on_gpu(engine):
         ret = algorithm.solve(net, np.array(list(w) + c["x0"], float), engine=engine)
         assert ret["solved"], ret
         assert any(np.allclose(ret["x_opt"], list(w) + list(xy), atol=c["atol"]) for xy in xs), (w, ret["x_opt"])
-        # the path's counterpart of test/simple_bilevel.jl:20 (see tests/test_oracle_golden.py): local pieces of the root
+        # test/simple_bilevel.jl:20 itself: the root's solution graph (combine + remove_subsets over the device-made pieces)
+        assert len(ret["Sol"][2]) >= min_pieces, (w, len(ret["Sol"][2]))
+        # and the path's own count (see tests/test_oracle_golden.py): local pieces of the root at the equilibrium
         assert local_recipe_count(net, 2, ret["x_opt"], ret["Sol"], engine=engine) >= min_pieces, w
 
 

@@ -38,11 +38,13 @@ def test_reference_end_to_end_cases(oracle):
         assert any(np.allclose(ret["x_opt"], list(w) + list(xy), atol=c["atol"]) for xy in xs), (w, ret["x_opt"])
         # follower's solution graph has the local pieces the reference derives
         assert 1 <= len(ret["Sol"][1]) <= 2
-        # The reference's second assertion, test/simple_bilevel.jl:20: length(collect(ret.Sol[2])) >= s -- the number of
-        # pieces its enumeration of the ROOT's solution graph collects.  That enumeration (vertex exploration + polyhedral
-        # projection, src/avi_solutions.jl rest) is outside the hot path; what the path itself yields is the number of
-        # local pieces of the root AT the equilibrium (one per recipe compatible with its active-set masks, over the child
-        # pieces for which it is optimal), which the reference's graph contains: it must reach the same lower bound.
+        # The reference's second assertion, test/simple_bilevel.jl:20: length(collect(ret.Sol[2])) >= s -- the ROOT's solution
+        # graph as process_qp leaves it: each sub-piece combination's local pieces (device kernels, multipliers eliminated),
+        # put together by combine (src/qp_processing.jl:260-291 -> qp_processing.combine_at) and remove_subsets
+        # (src/algorithm.jl:84).  The reference's graph additionally grows by vertex exploration, so its count can only be larger.
+        assert len(ret["Sol"][2]) >= min_pieces, (w, len(ret["Sol"][2]))
+        # ... and the count the hot path alone yields at the equilibrium (one local piece per recipe compatible with the
+        # root's active-set masks, over the child pieces for which it is optimal) reaches the same lower bound
         assert local_recipe_count(net, 2, ret["x_opt"], ret["Sol"], engine=OracleEngine()) >= min_pieces, w
 
 
