@@ -32,6 +32,15 @@ import numpy as np
 from .programs import Poly
 
 INF = np.inf
+# A local piece enters a node's solution graph only when it contains the current point within verify_solution's own feasibility
+# tolerance (src/qp_processing.jl:86).  comp_indices classifies with 1e-2 (src/avi_solutions.jl:511), so a row up to 1e-2 away
+# from its bound still spawns the recipe "at the bound"; the reference keeps every such piece that is non-empty
+# (src/avi_solutions.jl:247-249).  A piece the point misses by more than 1e-3 fails the PARENT's verify by construction (:86-89:
+# infeasible), the parent's solve_qep then moves onto it, the next sweep finds the mirror image, and the loop ends in the
+# reference's own "Cycling detected" (observed: one pair in 60 at n = m = 16).  Such pieces say nothing about optimality AT the
+# point, so they are left out.
+MEMBER_TOL = 1e-3
+CODE_TOL = 1e-4          # _refine_row_codes: a row keeps a code whose own condition the point meets within verify's tolerance (:57)
 ROW_PAD = 16            # constraint rows of a record batch are padded with inert rows to a multiple of this (one MFMA tile)
 
 
@@ -363,7 +372,7 @@ def verify_items(qpn, items, x, engine, tol=1e-4):
     return recs, batches, out
 
 
-def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], tol=1e-2, max_pieces=64):
+def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], tol=1e-2, max_pieces=64, member_tol=MEMBER_TOL):
     """The solution-graph pieces of MANY nodes around (x, lambda) (process_solution_graph, src/avi.jl:447-477 ->
     comp_indices -> all_Ks, src/avi_solutions.jl:200-215 -> local_piece, :400-496 -> the multipliers eliminated, the
     columns permuted back, :86-87), batched: per record shape one comp_indices pair, one recipes call, one pieces call.
@@ -390,6 +399,8 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         m2 = np.asarray(eng.comp_indices(s[sel], lam[sel], b.l[sel], b.u[sel], tol=tol, shift=4)) if m else np.zeros((len(sel), 0), np.uint8)
         for t, k in enumerate(sel):                          # inert padding rows: l = -inf, u = inf, lambda = 0 -> code 6 only
             m2[t, b.m_true[k]:] = 1 << 5
+        if m:
+            m2 = _refine_row_codes(m2, s[sel], lam[sel], b.l[sel], b.u[sel], CODE_TOL)
         masks = np.concatenate([m1, m2], axis=1).astype(np.uint8)
         ok = ~np.any(masks == 0, axis=1)                     # a zero mask: (x, lambda) is no solution of the GAVI at this tolerance
         pop = np.array([[bin(int(v)).count("1") for v in row] for row in masks], dtype=np.float64)
@@ -411,6 +422,10 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         Ar = np.asarray(Ar); lr = np.asarray(lr); ur = np.asarray(ur); rows = np.asarray(rows); flags = np.asarray(flags)
         for k in sel:
             out[b.where[k]] = []
+        first_of = {}                                        # a node's FIRST recipe is kept whatever the membership test says (every
+        for t in range(len(node_of) - 1, -1, -1):            # code left by _refine_row_codes is met within CODE_TOL or is its row's best):
+                                                             # a solution graph is never empty (src/qp_processing.jl:233)
+            first_of[int(rec_of[t])] = t
         for t in range(len(node_of)):
             k = int(rec_of[t]); i = b.where[k]
             if flags[t]:
@@ -424,8 +439,35 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
             pk = b.par[k] >= 0
             cols = np.concatenate([b.dec[k], b.par[k][pk]])
             Pg = _dedupe(Poly.from_local(qpn.num_vars, cols, np.hstack([Al[:, :n], Al[:, n:][:, pk]]), ll, ul))
-            if Pg.contains(x, tol=10 * tol):
+            # the parent's verify_solution tests feasibility on exactly these normalised rows with 1e-3 (src/qp_processing.jl:86):
+            # a piece the point fails here would be "infeasible" there by construction (MEMBER_TOL)
+            if Pg.contains(x, tol=member_tol) or first_of.get(k) == t:
                 out[i].append(Pg)
+    return out
+
+
+def _refine_row_codes(m2, s, lam, l, u, mt):
+    """Of the codes comp_indices allows on a constraint row (tolerance 1e-2), keep those whose OWN condition the point meets
+    within `mt`: code 5 (s = l, lambda >= 0), 6 (lambda = 0, l <= s <= u), 7 (s = u, lambda <= 0), 8 (l = s = u).  A recipe's piece
+    contains the point exactly when every row's condition holds (the lifted piece is a product of per-row conditions, src/
+    avi_solutions.jl:413-432), so after this every enumerated recipe's piece contains the point -- see MEMBER_TOL.  A row left
+    without any code keeps the allowed code it violates least."""
+    viol = np.full(m2.shape + (4,), np.inf)
+    with np.errstate(invalid="ignore"):
+        viol[..., 0] = np.maximum(np.abs(s - l), np.maximum(-lam, 0.0))
+        viol[..., 1] = np.maximum(np.abs(lam), np.maximum(np.maximum(l - s, s - u), 0.0))
+        viol[..., 2] = np.maximum(np.abs(s - u), np.maximum(lam, 0.0))
+        viol[..., 3] = np.maximum(np.abs(s - l), np.abs(s - u))
+    viol = np.where(np.isnan(viol), np.inf, viol)
+    bits = (m2[..., None] >> np.arange(4, 8)) & 1
+    viol = np.where(bits == 1, viol, np.inf)
+    keep = viol <= mt
+    best = np.argmin(viol, axis=-1)
+    none = ~keep.any(axis=-1) & (m2 != 0)
+    keep[none, best[none]] = True
+    out = np.zeros_like(m2)
+    for c in range(4):
+        out |= (keep[..., c].astype(np.uint8) << (4 + c)).astype(np.uint8)
     return out
 
 

@@ -119,12 +119,68 @@ def remove_subsets(polys, engine, tol=1e-6):
     return [p for p, s in zip(polys, is_subset) if not s], is_subset
 
 
-def remove_subsets_many(lists, engine, tol=1e-6):
+LP_CHUNK_BYTES = 1 << 30          # padded input of one batched LP call (host arrays; the device copy is as large again)
+
+
+def issubset_batch_chunked(pairs, engine, tol=1e-6, chunk_bytes=None):
+    """issubset_batch with the batch cut into calls whose padded host arrays stay below chunk_bytes (a level of a large net
+    asks millions of subset questions; one call for all of them would need their padded copies all at once)."""
+    chunk_bytes = chunk_bytes or LP_CHUNK_BYTES
+    out = np.ones(len(pairs), bool)
+    start = 0
+    while start < len(pairs):
+        cost, stop = 0, start
+        while stop < len(pairs):
+            (A1, l1, _), (A2, l2, u2) = [(_trip(P)) for P in pairs[stop]]
+            rows1, d = np.atleast_2d(A1).shape
+            nq = int(np.isfinite(l2).sum() + np.isfinite(u2).sum())
+            c = nq * ((rows1 + 1) * d + d * d + 4 * (rows1 + 1 + d)) * 8
+            if stop > start and cost + c > chunk_bytes:
+                break
+            cost += c; stop += 1
+        out[start:stop] = issubset_batch(pairs[start:stop], engine, tol=tol)
+        start = stop
+    return out
+
+
+def interior_members_batch(trips, engine, slack_cap=1.0, chunk=20000):
+    """One member per polyhedron (A, l, u), as far inside as its INEQUALITY rows allow: the slack LP of `exemplar`
+    (src/sets.jl:608-619) with the equality rows (l == u) kept as equalities, so that a lower-dimensional piece gets a point of its
+    relative interior instead of eps = 0 at an arbitrary feasible point.  -> list of x or None (empty / no answer)."""
+    out = [None] * len(trips)
+    for c0 in range(0, len(trips), chunk):
+        part = trips[c0:c0 + chunk]
+        dmax = max(np.atleast_2d(t[0]).shape[1] for t in part) + 1
+        mmax = max(2 * np.atleast_2d(t[0]).shape[0] for t in part) + 1
+        B = len(part)
+        A2 = np.zeros((B, mmax, dmax)); l2 = np.full((B, mmax), -INF); u2 = np.full((B, mmax), INF)
+        cost = np.zeros((B, dmax)); cost[:, dmax - 1] = 1.0
+        for k, (A, l, u) in enumerate(part):
+            A = np.atleast_2d(A); n, d = A.shape
+            eq = (l == u)
+            A2[k, :n, :d] = A; A2[k, n:2 * n, :d] = -A
+            A2[k, :n, dmax - 1] = np.where(eq, 0.0, 1.0); A2[k, n:2 * n, dmax - 1] = np.where(eq, 0.0, 1.0)
+            l2[k, :n] = l; l2[k, n:2 * n] = -u                     # A x + eps >= l, -A x + eps >= -u  (eps off on equality rows)
+            A2[k, mmax - 1, dmax - 1] = 1.0; l2[k, mmax - 1] = -slack_cap
+        st, x, _ = _solve_lps(cost, A2, l2, u2, engine)
+        for k, (A, l, u) in enumerate(part):
+            if st[k] == 1 and x[k, dmax - 1] <= 1e-6:
+                out[c0 + k] = x[k, :np.atleast_2d(A).shape[1]].copy()
+    return out
+
+
+def remove_subsets_many(lists, engine, tol=1e-6, prefilter=True):
     """`remove_subsets` (src/sets.jl:889-902) for the solution graphs of ALL nodes of a level at once (src/algorithm.jl:84
-    applies it to every node's S): the k (k - 1) subset tests of every list go out as ONE `issubset_batch` call.  Every list is
-    first brought down to the columns its pieces touch (a large net's pieces are local).  -> list of kept lists."""
-    jobs, where = [], []
-    comp = []
+    applies it to every node's S).  Every list is first brought down to the columns its pieces touch (a large net's pieces are
+    local).  The reference asks k (k - 1) subset questions per list, each one LP per finite bound of the second polyhedron
+    (src/sets.jl:376-407) -- 100 000 LPs for a node with 32 pieces.  Here a question is first put to ONE point: P1 ⊆ P2 needs
+    every point of P1 in P2, so a member of P1 that violates a row of P2 by more than 10 tol settles "not a subset" without
+    an LP (the reference's LP over P1 would come out below the bound by the same amount).  The member is a point of P1's
+    relative interior (interior_members_batch: the slack LP of `exemplar`, src/sets.jl:591-642, over the inequality rows; one LP
+    per piece, all pieces of the level in one batch) -- cells of a piecewise-affine solution map that merely touch are told
+    apart by it -- and only the pairs it does not settle go to the LPs (issubset_batch, chunked).  -> list of kept lists."""
+    comp, jobs, where = [], [], []
+    flat, flat_of = [], []
     for a, polys in enumerate(lists):
         k = len(polys) if polys is not None else 0
         if k < 2:
@@ -133,14 +189,32 @@ def remove_subsets_many(lists, engine, tol=1e-6):
         cols = np.unique(np.concatenate([P.support() for P in polys]))
         trips = [(P.block(cols), P.l, P.u) for P in polys]
         comp.append(trips)
-        for i in range(k):
-            for j in range(k):
-                if i != j:
-                    jobs.append((trips[i], trips[j])); where.append((a, i, j))
-    res = issubset_batch(jobs, engine, tol=tol) if jobs else []
+        if prefilter:
+            flat += trips; flat_of += [(a, i) for i in range(k)]
+    member = {}
+    if flat:
+        for key, pt in zip(flat_of, interior_members_batch(flat, engine)):      # (no answer for a piece: its pairs go to the LPs)
+            member[key] = pt
     sub = {}
-    for (a, i, j), r in zip(where, res):
-        sub[(a, i, j)] = bool(r)
+    for a, trips in enumerate(comp):
+        if trips is None:
+            continue
+        k = len(trips)
+        for i in range(k):
+            pt = member.get((a, i))
+            for j in range(k):
+                if i == j:
+                    continue
+                if pt is not None:
+                    A2, l2, u2 = trips[j]
+                    ax = A2 @ pt[:A2.shape[1]]
+                    if np.any(ax < l2 - 10 * tol) or np.any(ax > u2 + 10 * tol):
+                        sub[(a, i, j)] = False
+                        continue
+                jobs.append((trips[i], trips[j])); where.append((a, i, j))
+    res = issubset_batch_chunked(jobs, engine, tol=tol) if jobs else []
+    for key, r in zip(where, res):
+        sub[key] = bool(r)
     out = []
     for a, polys in enumerate(lists):
         if comp[a] is None:
@@ -198,7 +272,7 @@ def _isapprox(x, y, atol, rtol):
         return bool(np.all((x == y) | (fin & close)))
 
 
-def exemplar_slack_batch(polys, engine, tol=1e-2, slack_cap=1.0):
+def exemplar_slack_batch(polys, engine, tol=1e-2, slack_cap=1.0, strict=True):
     """`exemplar(poly; tol)` (src/sets.jl:591-642), the reference's own emptiness rule, for a batch:
         min eps  s.t.  A x + eps >= l,  -A x + eps >= -u                       (:608-619)
         eps > tol -> empty;  eps > -tol -> empty iff an OPEN bound is active (|dual| > tol), else a member;
@@ -243,7 +317,9 @@ def exemplar_slack_batch(polys, engine, tol=1e-2, slack_cap=1.0):
         st, x, lam = _solve_lps(cost, A2, l2, u2, engine)
         for k, b in enumerate(todo):
             if st[k] != 1:
-                raise RuntimeError(f"exemplar_slack_batch: solver status {st[k]} on item {b}")
+                if strict:
+                    raise RuntimeError(f"exemplar_slack_batch: solver status {st[k]} on item {b}")
+                continue                                    # (not strict: no answer for this item -- empty False, no example, eps nan)
             n, d = trips[b][0].shape
             eps = x[k, dmax - 1]; eps_out[b] = eps
             ol, oh = opens[b]
