@@ -422,10 +422,8 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         Ar = np.asarray(Ar); lr = np.asarray(lr); ur = np.asarray(ur); rows = np.asarray(rows); flags = np.asarray(flags)
         for k in sel:
             out[b.where[k]] = []
-        first_of = {}                                        # a node's FIRST recipe is kept whatever the membership test says (every
-        for t in range(len(node_of) - 1, -1, -1):            # code left by _refine_row_codes is met within CODE_TOL or is its row's best):
-                                                             # a solution graph is never empty (src/qp_processing.jl:233)
-            first_of[int(rec_of[t])] = t
+        fallback = {}                                        # per node: the piece the point misses least, for a node none of whose
+                                                             # pieces passes (a solution graph is never empty, src/qp_processing.jl:233)
         for t in range(len(node_of)):
             k = int(rec_of[t]); i = b.where[k]
             if flags[t]:
@@ -441,7 +439,15 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
             Pg = _dedupe(Poly.from_local(qpn.num_vars, cols, np.hstack([Al[:, :n], Al[:, n:][:, pk]]), ll, ul))
             # the parent's verify_solution tests feasibility on exactly these normalised rows with 1e-3 (src/qp_processing.jl:86):
             # a piece the point fails here would be "infeasible" there by construction (MEMBER_TOL)
-            if Pg.contains(x, tol=member_tol) or first_of.get(k) == t:
+            cl, Al_ = Pg.local()
+            ax = Al_ @ x[cl]
+            miss = float(np.max(np.maximum(Pg.l - ax, ax - Pg.u), initial=0.0))
+            if miss <= member_tol:
+                out[i].append(Pg)
+            elif i not in fallback or miss < fallback[i][0]:
+                fallback[i] = (miss, Pg)
+        for i, (miss, Pg) in fallback.items():
+            if not out[i]:
                 out[i].append(Pg)
     return out
 
