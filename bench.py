@@ -72,6 +72,8 @@ def parse_args():
                     help=f"skip the {PREWARM_STEPS} untimed steps (~0.1 s) that bring the GPU out of its idle power state")
     ap.add_argument("--no-scaling-proxy", action="store_true",
                     help="N = 1: skip the strong_scaling_proxy object (per-sweep time at 10 000 / 5 000 / 2 500 / 1 250 nodes)")
+    ap.add_argument("--outer-loop-pairs", type=int, default=250,
+                    help="N = 1: leader-follower pairs (n = m = 32) of the net the outer_loop object runs through solve(); 0 skips it")
     ap.add_argument("--no-schedule", action="store_true",
                     help="natural node order (default: longest-first schedule refreshed from the pivot counts every 16 steps)")
     return ap.parse_args()
@@ -390,11 +392,72 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
         out["cpu_baseline"] = cpu_baseline(np, Q, R, qd, A, B, l, u, w_host)
     if world == 1 and not use_dist and handle is not None and not args.no_scaling_proxy and total == NODES:
         out["strong_scaling_proxy"] = strong_scaling_proxy(env, drec, ring, n, m, kern_ms_all)
+    if world == 1 and not use_dist and args.outer_loop_pairs > 0 and total == NODES:
+        try:
+            out["outer_loop"] = outer_loop(env, args.outer_loop_pairs, n, m)
+        except Exception as e:      # the extra object must never cost the run its line
+            out["outer_loop"] = {"error": f"{type(e).__name__}: {e}"}
     if handle is not None:
         handle.close()
     if shared is not None:
         shared.close()
     return out
+
+
+def outer_loop(env, pairs, n, m):
+    """BASELINE configs[3]'s NET through the kept API: `pairs` independent leader-follower pairs (n = m per node: 2 x pairs nodes
+    on two levels, 2 n pairs variables) through algorithm.solve itself -- solve_base!'s sweeps (src/algorithm.jl:13-117) with the
+    per-node map of process_qp (:44-52) and the level's AVI step (:95) served as level-wide batches (level_batch.py).  Reported:
+    wall time per outer iteration (one process_level or solve_level sweep over a level), split into the C-ABI calls' own time
+    (verify / solve / solution-graph pieces / the LP batches of remove_subsets and combine: staging + kernels + read-back, the
+    calls are synchronous) and the host's (record assembly, polyhedral bookkeeping: Python), and the calls per sweep."""
+    import warnings
+    from qpn_amd import algorithm, examples, level_batch
+    eng = env["eng"]
+    sweeps = {"process": 0, "solve": 0}
+    t_sweep = {"process": 0.0, "solve": 0.0}
+    orig_p, orig_s = level_batch.process_level, level_batch.solve_level
+
+    def proc(*a, **k):
+        t = time.perf_counter(); r = orig_p(*a, **k); t_sweep["process"] += time.perf_counter() - t; sweeps["process"] += 1
+        return r
+
+    def solv(*a, **k):
+        t = time.perf_counter(); r = orig_s(*a, **k); t_sweep["solve"] += time.perf_counter() - t; sweeps["solve"] += 1
+        return r
+
+    t0 = time.perf_counter()
+    net = examples.setup("synthetic_pairs", pairs=pairs, n=n, m=m)
+    t_setup = time.perf_counter() - t0
+    eng.calls.clear(); eng.seconds.clear()
+    algorithm.process_level = proc; level_batch.solve_level = solv
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            ret = algorithm.solve(net, engine=eng)
+            wall = time.perf_counter() - t0
+    finally:
+        algorithm.process_level = orig_p; level_batch.solve_level = orig_s
+    sec, calls = dict(eng.seconds), dict(eng.calls)
+    grp = {"verify": ("qpn_verify_nodes", "qpn_verify_nodes_h"),
+           "solve": ("qpn_solve_nodes_into", "qpn_solve_nodes_h", "qpn_solve_avi_batch", "qpn_assemble_pools"),
+           "pieces": ("qpn_comp_indices", "qpn_recipes_batch", "qpn_reduced_pieces", "qpn_local_pieces"),
+           "upload": ("qpn_nodes_upload",)}
+    n_sweeps = max(1, sweeps["process"] + sweeps["solve"])
+    dev_s = sum(sec.values())
+    return {"net": f"synthetic_pairs: {pairs} leader-follower pairs, n = m = {n} per node ({2 * pairs} nodes on 2 levels, "
+                   f"{2 * n * pairs} variables), through algorithm.solve on the HIP engine",
+            "solved": bool(ret["solved"]), "error": ret.get("error"),
+            "wall_s": wall, "setup_s": t_setup,
+            "sweeps": sweeps, "ms_per_outer_iteration": wall / n_sweeps * 1e3,
+            "ms_per_process_level_sweep": t_sweep["process"] / max(1, sweeps["process"]) * 1e3,
+            "ms_per_solve_level_sweep": t_sweep["solve"] / max(1, sweeps["solve"]) * 1e3,
+            "abi_ms_per_outer_iteration": {k: sum(sec.get(f, 0.0) for f in fs) / n_sweeps * 1e3 for k, fs in grp.items()},
+            "abi_calls_per_outer_iteration": {k: sum(calls.get(f, 0) for f in fs) / n_sweeps for k, fs in grp.items()},
+            "abi_share_of_wall": dev_s / wall if wall > 0 else None,
+            "note": "solve also counts the node-solver calls behind the LP batches of remove_subsets / combine; the host share is "
+                    "Python (record assembly, polyhedral bookkeeping)"}
 
 
 def strong_scaling_proxy(env, drec, ring, n, m, full_ms):

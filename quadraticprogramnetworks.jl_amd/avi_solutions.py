@@ -152,20 +152,33 @@ def solution_graph_pieces(Q, q, A, l, u, dec_inds, x, lam, engine=None, tol=1e-2
     return out
 
 
+_PROBES = {}
+
+
+def _probe_vector(c):
+    v = _PROBES.get(c)
+    if v is None:
+        v = _PROBES[c] = np.random.Generator(np.random.Philox(key=[97, c])).standard_normal(c)
+    return v
+
+
 def _dedupe(P: Poly, digits=6):
     """Merge rows with equal normals (intersection of their intervals), drop all-zero rows:
     the array part of simplify (src/sets.jl:255-311).  Works on the local form (the columns the rows touch)."""
     cols, A = P.local()
-    l, u = P.l.copy(), P.u.copy()
-    keep = {}
-    for i in range(A.shape[0]):
-        if not np.any(A[i]):
-            continue
-        key = np.round(A[i], digits).tobytes()
-        if key in keep:
-            j = keep[key]
-            l[j] = max(l[j], l[i]); u[j] = min(u[j], u[i])
-        else:
-            keep[key] = i
-    idx = sorted(keep.values())
-    return Poly.from_local(P.ncols, cols, A[idx], l[idx], u[idx], normalise=False)
+    if A.shape[0] == 0:
+        return P
+    # most pieces have neither: one random projection of the rows tells (equal normals project equally)
+    h = A @ _probe_vector(A.shape[1])
+    hs = np.sort(h)
+    if A.any(axis=1).all() and not np.any(np.diff(hs) <= 1e-7 * (1.0 + np.abs(hs[1:]))):
+        return P
+    nz = np.nonzero(A.any(axis=1))[0]
+    R = np.round(A[nz], digits) + 0.0                           # (+ 0.0: no negative zeros in the keys)
+    _, first, inv = np.unique(R, axis=0, return_index=True, return_inverse=True)
+    inv = np.asarray(inv).ravel()
+    l = np.full(first.size, -INF); u = np.full(first.size, INF)
+    np.maximum.at(l, inv, P.l[nz]); np.minimum.at(u, inv, P.u[nz])
+    order = np.argsort(first)                                   # rows keep the order of their first appearance
+    idx = nz[first[order]]
+    return Poly.from_local(P.ncols, cols, A[idx], l[order], u[order], normalise=False)

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -63,6 +64,8 @@ class Engine:
         self.ctx = h
         self.use_torch_stream = use_torch_stream
         self.calls = collections.Counter()       # C-ABI calls per entry point (the tests assert O(1) calls per level with it)
+        self.seconds = collections.Counter()     # wall time per entry point, method entry to the library's return (host-pointer
+        self._t0 = None                          # calls are synchronous, so this is staging + kernels + read-back)
         self._bound = "own"                      # which stream the context launches on (a new context: its own)
 
     def close(self):
@@ -79,6 +82,9 @@ class Engine:
     # -- helpers ---------------------------------------------------------------------------
     def _chk(self, rc, what):
         self.calls[what] += 1
+        if self._t0 is not None:
+            self.seconds[what] += time.perf_counter() - self._t0
+            self._t0 = None
         if rc != 0:
             msg = self.lib.qpn_ctx_last_error(self.ctx).decode()
             raise QpnError(f"{what}: {self.lib.qpn_strerror(rc).decode()} ({msg})")
@@ -98,6 +104,7 @@ class Engine:
                 self._bound = None
                 self._chk(self.lib.qpn_ctx_use_own_stream(self.ctx), "qpn_ctx_use_own_stream")
                 self._bound = "own"
+        self._t0 = time.perf_counter()
 
     def synchronize(self):
         self._chk(self.lib.qpn_ctx_synchronize(self.ctx), "qpn_ctx_synchronize")

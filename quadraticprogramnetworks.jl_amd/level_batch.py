@@ -422,6 +422,7 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         Ar = np.asarray(Ar); lr = np.asarray(lr); ur = np.asarray(ur); rows = np.asarray(rows); flags = np.asarray(flags)
         for k in sel:
             out[b.where[k]] = []
+        seen = {b.where[k]: set() for k in sel}
         fallback = {}                                        # per node: the piece the point misses least, for a node none of whose
                                                              # pieces passes (a solution graph is never empty, src/qp_processing.jl:233)
         for t in range(len(node_of)):
@@ -443,7 +444,10 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
             ax = Al_ @ x[cl]
             miss = float(np.max(np.maximum(Pg.l - ax, ax - Pg.u), initial=0.0))
             if miss <= member_tol:
-                out[i].append(Pg)
+                key = (cl.tobytes(), (np.round(Al_, 6) + 0.0).tobytes(), np.round(Pg.l, 6).tobytes(), np.round(Pg.u, 6).tobytes())
+                if key not in seen[i]:                       # the reference collects the pieces in a Set (src/avi_solutions.jl:104)
+                    seen[i].add(key)
+                    out[i].append(Pg)
             elif i not in fallback or miss < fallback[i][0]:
                 fallback[i] = (miss, Pg)
         for i, (miss, Pg) in fallback.items():

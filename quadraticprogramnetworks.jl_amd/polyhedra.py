@@ -85,10 +85,16 @@ def issubset_batch(pairs, engine, tol=1e-6):
         A1, l1, u1 = (P1.vectorize() if hasattr(P1, "vectorize") else P1)
         A2, l2, u2 = (P2.vectorize() if hasattr(P2, "vectorize") else P2)
         A1 = np.atleast_2d(np.asarray(A1, dtype=np.float64)); A2 = np.atleast_2d(np.asarray(A2, dtype=np.float64))
+        # a bound of P2 that P1 carries itself -- the same normal (to 1e-9) with a bound at least as tight -- holds on all of P1: no LP
+        own = {}
+        for r in range(A1.shape[0]):
+            own.setdefault((np.round(A1[r], 9) + 0.0).tobytes(), []).append(r)
         for i in range(A2.shape[0]):
-            if np.isfinite(l2[i]):          # a violation is a point of P1 with a'x <= l2 - tol
+            mine = own.get((np.round(A2[i], 9) + 0.0).tobytes(), ())
+            lo1 = max((l1[r] for r in mine), default=-INF); hi1 = min((u1[r] for r in mine), default=INF)
+            if np.isfinite(l2[i]) and not lo1 >= l2[i] - tol:          # a violation is a point of P1 with a'x <= l2 - tol
                 queries.append((np.vstack([A1, A2[i:i + 1]]), np.append(l1, -INF), np.append(u1, l2[i] - tol))); owner.append(k)
-            if np.isfinite(u2[i]):          # ... or with a'x >= u2 + tol
+            if np.isfinite(u2[i]) and not hi1 <= u2[i] + tol:          # ... or with a'x >= u2 + tol
                 queries.append((np.vstack([A1, A2[i:i + 1]]), np.append(l1, u2[i] + tol), np.append(u1, INF))); owner.append(k)
     out = np.ones(len(pairs), bool)
     if queries:
@@ -200,18 +206,23 @@ def remove_subsets_many(lists, engine, tol=1e-6, prefilter=True):
         if trips is None:
             continue
         k = len(trips)
+        have = [i for i in range(k) if member.get((a, i)) is not None]
+        refuted = np.zeros((k, k), bool)                    # refuted[i, j]: P1 = piece i has a member outside P2 = piece j
+        if have:
+            pts = np.stack([member[(a, i)] for i in have], axis=1)          # [d, members]
+            for j in range(k):
+                A2, l2, u2 = trips[j]
+                ax = A2 @ pts[:A2.shape[1]]
+                out = np.any(ax < (l2 - 10 * tol)[:, None], axis=0) | np.any(ax > (u2 + 10 * tol)[:, None], axis=0)
+                refuted[have, j] = out
         for i in range(k):
-            pt = member.get((a, i))
             for j in range(k):
                 if i == j:
                     continue
-                if pt is not None:
-                    A2, l2, u2 = trips[j]
-                    ax = A2 @ pt[:A2.shape[1]]
-                    if np.any(ax < l2 - 10 * tol) or np.any(ax > u2 + 10 * tol):
-                        sub[(a, i, j)] = False
-                        continue
-                jobs.append((trips[i], trips[j])); where.append((a, i, j))
+                if refuted[i, j]:
+                    sub[(a, i, j)] = False
+                else:
+                    jobs.append((trips[i], trips[j])); where.append((a, i, j))
     res = issubset_batch_chunked(jobs, engine, tol=tol) if jobs else []
     for key, r in zip(where, res):
         sub[key] = bool(r)
