@@ -198,6 +198,324 @@ __global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
     if (lane == 0) { a.solution[b] = 0; a.path[b] = -1; }
 }
 
+// ---- verify_node32: the n, m <= 32 class rebuilt (round 4) ---------------------------------------------------------------
+// One wavefront per node, ALL 64 lanes at work, 9.9 KB of LDS (four waves per SIMD), the Gram block on the matrix cores:
+//   * Qd and Ad arrive with fully coalesced loads, two columns of 32 rows per instruction (512 contiguous bytes at n = m = 32),
+//     all 32 + the vector loads in flight at once; they STAY in registers (lane (r, h) holds row r, columns of parity h);
+//   * q~ = Qd x + R w + qd and ax = Ad x + B w are two 16-term chains per lane over both halves of the wavefront, x read from
+//     LDS de-interleaved by parity (8 ds_read_b128), the halves added with one v_permlane32_swap pair;
+//   * the signed active rows go to LDS compacted (row c of A_bar', leading dimension 34: conflict-free as MFMA operands),
+//     G = A_bar' A_bar is 8 (k <= 16) or 24 v_mfma_f64_16x16x4_f64 -- an operand register is A AND B operand of a diagonal
+//     tile -- and lands in the same LDS region (leading dimension 33), which the factor then takes over column by column;
+//   * the diagonally pivoted Cholesky is LEFT-looking: step s forms column pv of the Schur complement from the factor's
+//     earlier columns (2 s independent LDS reads, one chain of s fma) instead of updating k columns of G through LDS
+//     round trips; same pivots, same arithmetic per entry as the right-looking form of verify_stage1;
+//   * the back substitution is column-oriented (no wave reduction per step), the residual reads the re-staged active rows.
+// Decisions (feasibility, classes, pivot order, sign and residual tests) are verify_stage1's; q~, ax and the Gram entries differ
+// from its ascending chains by summation order only.
+typedef double vd4 __attribute__((ext_vector_type(4)));
+typedef double vd2 __attribute__((ext_vector_type(2)));
+#define VMFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+
+__device__ __forceinline__ void vwave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double vsum_halves(double v)      // v[l] + v[l ^ 32] in every lane
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+__device__ __forceinline__ double vadd2(double a, double b) { return a + b; }
+__device__ __forceinline__ double wave_sum32_f64(double v)   // sum over lanes 0..31 (lanes 32..63 ignored), wave-uniform
+{
+    QPN_ROW_REDUCE(v, vadd2);
+    return readlane_f64(v, 0) + readlane_f64(v, 16);
+}
+
+constexpr int V32_LDA = 34;      // compacted active rows / all rows: entry (row c, column t) at c * 34 + t
+constexpr int V32_LDG = 33;      // Gram block / factor: entry (i, j) at j * 33 + i
+
+template <bool FULL>
+__global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
+{
+    const int n = FULL ? 32 : a.n, m = FULL ? 32 : a.m, p = a.p;
+    const int l = threadIdx.x;
+    const int b = blockIdx.x;
+    const int r5 = l & 31, ch = l >> 5;
+    __shared__ __attribute__((aligned(16))) double sM[32 * V32_LDA];
+    __shared__ __attribute__((aligned(16))) double sx[32];       // x, then q~: [parity][16]
+    __shared__ __attribute__((aligned(16))) double sv[32];       // broadcast vector (rhs, y)
+    __shared__ int srow[32];
+    __shared__ double ssg[32];
+
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *B_ = a.B + (size_t)b * m * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double *lam = a.lambda + (size_t)b * m;
+
+    // ---- every load of the node in flight at once
+    double vq[16], va[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int cj = 2 * t + ch;
+        const bool okq = FULL || (cj < n && r5 < n), oka = FULL || (cj < n && r5 < m);
+        vq[t] = Q_[okq ? (size_t)cj * n + r5 : 0];
+        va[t] = A_[oka ? (size_t)cj * m + r5 : 0];
+    }
+    const double xv = (l < n) ? a.xd[(size_t)b * n + l] : 0.0;
+    const double qdv = (FULL || r5 < n) ? a.qd[(size_t)b * n + r5] : 0.0;
+    double lr = 0.0, ur = 0.0;
+    if (FULL || r5 < m) { lr = a.l[(size_t)b * m + r5]; ur = a.u[(size_t)b * m + r5]; }
+    double accr = 0.0, accb = 0.0;                            // (R w)_r and (B w)_r: columns of parity ch
+    for (int k0 = ch; k0 < p; k0 += 8) {
+        double rv[4], bv[4], wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = k0 + 2 * k;
+            const bool ok = kk < p;
+            wv[k] = ok ? w_[kk] : 0.0;
+            rv[k] = (ok && (FULL || r5 < n)) ? R_[(size_t)kk * n + r5] : 0.0;
+            bv[k] = (ok && (FULL || r5 < m)) ? B_[(size_t)kk * m + r5] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { accr = fma(rv[k], wv[k], accr); accb = fma(bv[k], wv[k], accb); }
+    }
+    if (l < 32) sx[(l & 1) * 16 + (l >> 1)] = xv;
+    vwave_sync();
+    if (!FULL) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int cj = 2 * t + ch;
+            if (!(cj < n && r5 < n)) vq[t] = 0.0;
+            if (!(cj < n && r5 < m)) va[t] = 0.0;
+        }
+    }
+    // ---- :58-60 q~, :84 ax: 16 terms per lane, both halves of the wavefront
+    double q0 = accr, q1 = 0.0, a0 = accb, a1 = 0.0;
+    {
+        const vd2 *xh = reinterpret_cast<const vd2 *>(sx + ch * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const vd2 xx = xh[j];
+            q0 = fma(vq[2 * j], xx[0], q0); q1 = fma(vq[2 * j + 1], xx[1], q1);
+            a0 = fma(va[2 * j], xx[0], a0); a1 = fma(va[2 * j + 1], xx[1], a1);
+        }
+    }
+    const double qt = vsum_halves(q0 + q1) + qdv;             // q~ of row r5, in both halves
+    const double ax = vsum_halves(a0 + a1);                   // (Ad x + B w) of row r5, in both halves
+    const bool isrow = FULL || r5 < m;
+
+    // :86  feasibility, tol 1e-3 (Slice membership, src/sets.jl:851-854)
+    const bool infeas = isrow && !(lr - 1e-3 <= ax && ax - 1e-3 <= ur);
+    if (qpn_ballot(infeas)) {
+        if (l < m) lam[l] = 0.0;
+        if (l == 0) { a.solution[b] = 0; a.path[b] = 0; }
+        return;
+    }
+    if (!FULL && m == 0) {   // :91-96
+        const double s = wave_sum32_f64((l < n) ? qt * qt : 0.0);
+        if (l == 0) { a.solution[b] = sqrt(s) <= a.tol ? 1 : 0; a.path[b] = 1; }
+        return;
+    }
+    // :98-103  active-row classes (same in both halves)
+    const bool pos0 = isrow && ax < lr + 1e-2, neg0 = isrow && ax > ur - 1e-2;
+    const int cls = (pos0 ? 1 : 0) | (neg0 ? 2 : 0);
+    const unsigned bp = (unsigned)qpn_ballot(cls == 1), bn = (unsigned)qpn_ballot(cls == 2), bb = (unsigned)qpn_ballot(cls == 3);
+    const int np = __popc(bp), nn = __popc(bn), nb = __popc(bb);
+    const int k = np + nn + nb;
+    const unsigned below = (1u << r5) - 1u;
+    int mycol = -1;
+    if (cls == 1) mycol = __popc(bp & below);
+    else if (cls == 2) mycol = np + __popc(bn & below);
+    else if (cls == 3) mycol = np + nn + __popc(bb & below);
+    const double mysgr = (cls == 2) ? -1.0 : 1.0;             // sign of row r5 as a column of A_bar
+    // ---- A_bar' (signed active rows, compacted) and q~ to LDS
+    vwave_sync();                                             // (the x reads are done)
+    if (mycol >= 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = mysgr * va[t];
+        if (ch == 0) { srow[mycol] = r5; ssg[mycol] = mysgr; }
+    }
+    if (l < 32) sx[(l & 1) * 16 + (l >> 1)] = (FULL || l < n) ? qt : 0.0;
+    vwave_sync();
+    // (Ad q~)_r for every row (the fallback's -Ad q~ too), then the right-hand side A_bar' q~ by column
+    double g0 = 0.0, g1 = 0.0;
+    {
+        const vd2 *qh = reinterpret_cast<const vd2 *>(sx + ch * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const vd2 qq = qh[j];
+            g0 = fma(va[2 * j], qq[0], g0); g1 = fma(va[2 * j + 1], qq[1], g1);
+        }
+    }
+    const double aq = vsum_halves(g0 + g1);                   // (Ad q~)_r5
+    if (mycol >= 0 && ch == 0) sv[mycol] = mysgr * aq;
+    // ---- Gram block on the matrix cores: operand lane (lc, lq) <-> A_bar'(row lc [+16], column 4 s + lq)
+    const int lc = l & 15, lq = l >> 4;
+    double x0[8], x1[8];
+    const bool two = k > 16;                                  // (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int t = 4 * s + lq;
+        const double v0 = sM[lc * V32_LDA + t];
+        x0[s] = (lc < k && (FULL || t < n)) ? v0 : 0.0;
+    }
+    if (two) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int t = 4 * s + lq;
+            const double v1 = sM[(16 + lc) * V32_LDA + t];
+            x1[s] = (16 + lc < k && (FULL || t < n)) ? v1 : 0.0;
+        }
+    }
+    vwave_sync();                                             // operands and sv are in; the region changes hands
+    const double rhs = (l < k) ? sv[l] : 0.0;
+    {
+        vd4 g00 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) g00 = VMFMA(x0[s], x0[s], g00);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = lq + 4 * g, j = lc;
+            if (i < k && j < k) sM[j * V32_LDG + i] = g00[g];
+        }
+        if (two) {
+            vd4 g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { g01 = VMFMA(x0[s], x1[s], g01); g11 = VMFMA(x1[s], x1[s], g11); }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = lq + 4 * g, j = 16 + lc;
+                if (j < k) { sM[j * V32_LDG + i] = g01[g]; sM[i * V32_LDG + j] = g01[g]; }
+                if (16 + i < k && j < k) sM[j * V32_LDG + 16 + i] = g11[g];
+            }
+        }
+    }
+    vwave_sync();
+    // ---- diagonally pivoted Cholesky, left-looking; lane i < k <-> row i.  Column ord[s] of the region becomes column s of
+    // the factor (the freed column), exactly as in verify_stage1.
+    const bool mine = l < k;
+    bool done = !mine;
+    int mystep = -1;
+    double diag = mine ? sM[l * V32_LDG + l] : 0.0;
+    const double dscale = wave_max_f64(mine ? diag : 0.0);
+    const double dfloor = 1e-12 * (dscale > 1.0 ? dscale : 1.0);
+    int rank = 0;
+    int ordv = 0;                                             // lane s holds the pivot column of step s
+    double bvec = rhs, myinv = 0.0;
+    for (int s = 0; s < k; ++s) {
+        const double dmax = wave_max_f64(done ? -1.0 : diag);
+        if (!(dmax > dfloor)) break;
+        const int pv = wave_first(!done && diag == dmax);
+        const double lpp = sqrt(dmax), inv = 1.0 / lpp;
+        double acc = done ? 0.0 : sM[pv * V32_LDG + l];       // G(i, pv)
+        for (int t0 = 0; t0 < s; t0 += 4) {
+            double av[4], bw[4];
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) {
+                const int t = t0 + u_;
+                const int o = readlane_i32(ordv, t < s ? t : s - 1);
+                av[u_] = sM[o * V32_LDG + (mine ? l : 0)];
+                bw[u_] = (t < s) ? sM[o * V32_LDG + pv] : 0.0;
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) acc = fma(-av[u_], bw[u_], acc);
+        }
+        const double lis = (l == pv) ? lpp : acc * inv;
+        if (!done) sM[pv * V32_LDG + l] = lis;                // L(:, s) into the freed column
+        const double ws = readlane_f64(bvec, pv) * inv;       // forward substitution: w_s = b_pv / lpp ; b_i -= L(i, s) w_s
+        if (!done && l != pv) { diag = fma(-lis, lis, diag); bvec = fma(-lis, ws, bvec); }
+        if (l == pv) { done = true; mystep = s; bvec = ws; myinv = inv; }
+        if (l == s) ordv = pv;
+        rank++;
+        vwave_sync();
+    }
+    // ---- back substitution L' y = w, column-oriented: y of the last pivot first; a lane pivoted at step a < s' takes
+    // L(ord[s'], a) -- row ord[s'] of its own (freed) column -- times y_{ord[s']} off its right-hand side
+    double y = 0.0;
+    for (int s = rank - 1; s >= 0; --s) {
+        const int pvs = readlane_i32(ordv, s);
+        const double ys = readlane_f64(bvec * myinv, pvs);
+        if (mystep >= 0 && mystep < s) bvec = fma(-sM[l * V32_LDG + pvs], ys, bvec);
+        if (l == pvs) y = ys;
+    }
+    // :119  sign test; then the residual A_bar y - q~ on the re-staged active rows
+    const bool badsign = l < np + nn && !(y > -a.tol);
+    vwave_sync();                                             // (the factor's reads are done)
+    if (mycol >= 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = mysgr * va[t];
+    }
+    if (l < k) sv[l] = y;
+    vwave_sync();
+    double res = 0.0;
+    {
+        double s0 = (l < 32) ? -qt : 0.0;
+        const int tcol = (l < 32 && (FULL || l < n)) ? l : 0;
+        for (int c0 = 0; c0 < k; c0 += 4) {
+            double av[4], yv[4];
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) {
+                const int c = c0 + u_;
+                av[u_] = sM[(c < k ? c : k - 1) * V32_LDA + tcol];
+                yv[u_] = (c < k) ? sv[c] : 0.0;
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) s0 = fma(av[u_], yv[u_], s0);
+        }
+        res = wave_sum32_f64((l < 32 && (FULL || l < n)) ? s0 * s0 : 0.0);
+    }
+    const bool ok = !qpn_ballot(badsign) && sqrt(res) <= a.tol;
+    if (ok) {
+        if (l < m) lam[l] = (mycol >= 0) ? mysgr * sv[mycol] : 0.0;        // :120-123
+        if (l == 0) { a.solution[b] = 1; a.path[b] = 2; }
+        return;
+    }
+    // ---- :129-137  bounded least squares as a box-AVI in lambda, handed to the AVI kernel: G = Ad Ad' by the ascending
+    // fma chains of verify_stage1 (bit for bit its Gram block), all rows re-staged unsigned
+    vwave_sync();
+    if (isrow) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sM[r5 * V32_LDA + 2 * t + ch] = va[t];
+    }
+    vwave_sync();
+    {
+        double *G = a.sG + (size_t)b * m * m;
+        double arow[32];
+        const int ri = isrow ? r5 : 0;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) arow[t] = sM[ri * V32_LDA + t];
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 2 * jj + ch;
+            if (!FULL && !(j < m)) continue;                  // (the two halves' j differ by one: at most one idle round)
+            const vd2 *rj = reinterpret_cast<const vd2 *>(sM + j * V32_LDA);
+            double s = 0.0;
+#pragma unroll
+            for (int t2 = 0; t2 < 16; ++t2) {
+                const vd2 bb2 = rj[t2];
+                if (FULL || 2 * t2 < n) s = fma(arow[2 * t2], bb2[0], s);
+                if (FULL || 2 * t2 + 1 < n) s = fma(arow[2 * t2 + 1], bb2[1], s);
+            }
+            if (isrow) G[(size_t)j * m + r5] = s;
+        }
+    }
+    if (l < m) {
+        a.sq[(size_t)b * m + l] = -aq;
+        a.slb[(size_t)b * m + l] = (cls & 2) ? -QINF : 0.0;   // :129-131
+        a.sub[(size_t)b * m + l] = (cls & 1) ? QINF : 0.0;    // :132-134
+        a.sz[(size_t)b * m + l] = 0.0;
+        lam[l] = 0.0;
+    }
+    if (l == 0) { a.solution[b] = 0; a.path[b] = -1; }
+}
+
 __global__ __launch_bounds__(WAVE) void verify_stage2(VerifyArgs a, const int32_t *avi_status)
 {
     const int n = a.n, m = a.m, p = a.p;
@@ -492,7 +810,8 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
         hipLaunchKernelGGL(verify_wide_stage2, dim3((unsigned)batch), dim3(WTPB), 0, stream, a, (const int32_t *)sst);
         return hipGetLastError();
     }
-    if (n <= 32 && m <= 32) hipLaunchKernelGGL(verify_stage1<33>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+    if (n == 32 && m == 32) hipLaunchKernelGGL(verify_node32<true>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+    else if (n <= 32 && m <= 32) hipLaunchKernelGGL(verify_node32<false>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     else hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || m == 0) return e;

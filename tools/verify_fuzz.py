@@ -13,10 +13,11 @@ from qpn_amd.engine import colmajor
 from oracle import binding
 eng = qpn_amd.Engine(0)
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+MAXDIM = int(os.environ.get("MAXDIM", "96"))       # MAXDIM=32: the one-wavefront class of verify_node32 only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 nodes = flag_diff = path_diff = 0
 for t in range(trials):
-    n = int(rng.integers(1, 97)); m = int(rng.integers(0, 97)); cnt = int(rng.integers(1, 7)); p = int(rng.integers(1, 9))
+    n = int(rng.integers(1, MAXDIM + 1)); m = int(rng.integers(0, MAXDIM + 1)); cnt = int(rng.integers(1, 7)); p = int(rng.integers(1, 9))
     Q, Rm, qd, A, B, l, u = P.synth_nodes(50_000 + t, cnt, n, max(m, 1), p)
     if m == 0:
         A = A[:, :0, :]; B = B[:, :0, :]; l = l[:, :0]; u = u[:, :0]
