@@ -357,106 +357,114 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
     }
     const double aq = vsum_halves(g0 + g1);                   // (Ad q~)_r5
     if (mycol >= 0 && ch == 0) sv[mycol] = mysgr * aq;
-    // ---- Gram block on the matrix cores: operand lane (lc, lq) <-> A_bar'(row lc [+16], column 4 s + lq)
+    vwave_sync();
+    const double rhs = (l < k) ? sv[l] : 0.0;                 // A_bar' q~ by column (lane c < k <-> column c)
     const int lc = l & 15, lq = l >> 4;
-    double x0[8], x1[8];
     const bool two = k > 16;                                  // (wave-uniform)
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int t = 4 * s + lq;
-        const double v0 = sM[lc * V32_LDA + t];
-        x0[s] = (lc < k && (FULL || t < n)) ? v0 : 0.0;
-    }
-    if (two) {
+    const bool mine = l < k;
+
+    // Least squares  A_bar(:, P) y ~ q~  for a column set P (lane c: inP): the Gram block on the matrix cores (operand lane
+    // (lc, lq) <-> A_bar'(row lc [+16], column 4 s + lq), read from the staged active rows), then the diagonally pivoted
+    // Cholesky, left-looking, on the same LDS region, forward and back substitution.  Returns y (0 outside P and on the
+    // columns the factorisation drops as dependent) and whether this lane's column was pivoted.  On entry the region holds
+    // the active rows (leading dimension 34); on exit the factor.
+    auto lsq_on = [&](bool inP, double &y_out, bool &pivoted) {
+        double x0[8], x1[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int t = 4 * s + lq;
-            const double v1 = sM[(16 + lc) * V32_LDA + t];
-            x1[s] = (16 + lc < k && (FULL || t < n)) ? v1 : 0.0;
-        }
-    }
-    vwave_sync();                                             // operands and sv are in; the region changes hands
-    const double rhs = (l < k) ? sv[l] : 0.0;
-    {
-        vd4 g00 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 8; ++s) g00 = VMFMA(x0[s], x0[s], g00);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i = lq + 4 * g, j = lc;
-            if (i < k && j < k) sM[j * V32_LDG + i] = g00[g];
+            const double v0 = sM[lc * V32_LDA + t];
+            x0[s] = (lc < k && (FULL || t < n)) ? v0 : 0.0;
         }
         if (two) {
-            vd4 g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) { g01 = VMFMA(x0[s], x1[s], g01); g11 = VMFMA(x1[s], x1[s], g11); }
+            for (int s = 0; s < 8; ++s) {
+                const int t = 4 * s + lq;
+                const double v1 = sM[(16 + lc) * V32_LDA + t];
+                x1[s] = (16 + lc < k && (FULL || t < n)) ? v1 : 0.0;
+            }
+        }
+        vwave_sync();                                         // operands are in; the region changes hands
+        {
+            vd4 g00 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) g00 = VMFMA(x0[s], x0[s], g00);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int i = lq + 4 * g, j = 16 + lc;
-                if (j < k) { sM[j * V32_LDG + i] = g01[g]; sM[i * V32_LDG + j] = g01[g]; }
-                if (16 + i < k && j < k) sM[j * V32_LDG + 16 + i] = g11[g];
+                const int i = lq + 4 * g, j = lc;
+                if (i < k && j < k) sM[j * V32_LDG + i] = g00[g];
+            }
+            if (two) {
+                vd4 g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { g01 = VMFMA(x0[s], x1[s], g01); g11 = VMFMA(x1[s], x1[s], g11); }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int i = lq + 4 * g, j = 16 + lc;
+                    if (j < k) { sM[j * V32_LDG + i] = g01[g]; sM[i * V32_LDG + j] = g01[g]; }
+                    if (16 + i < k && j < k) sM[j * V32_LDG + 16 + i] = g11[g];
+                }
             }
         }
-    }
-    vwave_sync();
-    // ---- diagonally pivoted Cholesky, left-looking; lane i < k <-> row i.  Column ord[s] of the region becomes column s of
-    // the factor (the freed column), exactly as in verify_stage1.
-    const bool mine = l < k;
-    bool done = !mine;
-    int mystep = -1;
-    double diag = mine ? sM[l * V32_LDG + l] : 0.0;
-    const double dscale = wave_max_f64(mine ? diag : 0.0);
-    const double dfloor = 1e-12 * (dscale > 1.0 ? dscale : 1.0);
-    int rank = 0;
-    int ordv = 0;                                             // lane s holds the pivot column of step s
-    double bvec = rhs, myinv = 0.0;
-    for (int s = 0; s < k; ++s) {
-        const double dmax = wave_max_f64(done ? -1.0 : diag);
-        if (!(dmax > dfloor)) break;
-        const int pv = wave_first(!done && diag == dmax);
-        const double lpp = sqrt(dmax), inv = 1.0 / lpp;
-        double acc = done ? 0.0 : sM[pv * V32_LDG + l];       // G(i, pv)
-        for (int t0 = 0; t0 < s; t0 += 4) {
-            double av[4], bw[4];
-#pragma unroll
-            for (int u_ = 0; u_ < 4; ++u_) {
-                const int t = t0 + u_;
-                const int o = readlane_i32(ordv, t < s ? t : s - 1);
-                av[u_] = sM[o * V32_LDG + (mine ? l : 0)];
-                bw[u_] = (t < s) ? sM[o * V32_LDG + pv] : 0.0;
-            }
-#pragma unroll
-            for (int u_ = 0; u_ < 4; ++u_) acc = fma(-av[u_], bw[u_], acc);
-        }
-        const double lis = (l == pv) ? lpp : acc * inv;
-        if (!done) sM[pv * V32_LDG + l] = lis;                // L(:, s) into the freed column
-        const double ws = readlane_f64(bvec, pv) * inv;       // forward substitution: w_s = b_pv / lpp ; b_i -= L(i, s) w_s
-        if (!done && l != pv) { diag = fma(-lis, lis, diag); bvec = fma(-lis, ws, bvec); }
-        if (l == pv) { done = true; mystep = s; bvec = ws; myinv = inv; }
-        if (l == s) ordv = pv;
-        rank++;
         vwave_sync();
-    }
-    // ---- back substitution L' y = w, column-oriented: y of the last pivot first; a lane pivoted at step a < s' takes
-    // L(ord[s'], a) -- row ord[s'] of its own (freed) column -- times y_{ord[s']} off its right-hand side
-    double y = 0.0;
-    for (int s = rank - 1; s >= 0; --s) {
-        const int pvs = readlane_i32(ordv, s);
-        const double ys = readlane_f64(bvec * myinv, pvs);
-        if (mystep >= 0 && mystep < s) bvec = fma(-sM[l * V32_LDG + pvs], ys, bvec);
-        if (l == pvs) y = ys;
-    }
-    // :119  sign test; then the residual A_bar y - q~ on the re-staged active rows
-    const bool badsign = l < np + nn && !(y > -a.tol);
-    vwave_sync();                                             // (the factor's reads are done)
-    if (mycol >= 0) {
+        // lane i < k <-> row i.  Column ord[s] of the region becomes column s of the factor (the freed column), as in verify_stage1.
+        bool done = !inP;
+        int mystep = -1;
+        double diag = inP ? sM[l * V32_LDG + l] : 0.0;
+        const double dscale = wave_max_f64(inP ? diag : 0.0);
+        const double dfloor = 1e-12 * (dscale > 1.0 ? dscale : 1.0);
+        int rank = 0;
+        int ordv = 0;                                         // lane s holds the pivot column of step s
+        double bvec = inP ? rhs : 0.0, myinv = 0.0;
+        for (int s = 0; s < k; ++s) {
+            const double dmax = wave_max_f64(done ? -1.0 : diag);
+            if (!(dmax > dfloor)) break;
+            const int pv = wave_first(!done && diag == dmax);
+            const double lpp = sqrt(dmax), inv = 1.0 / lpp;
+            double acc = done ? 0.0 : sM[pv * V32_LDG + l];   // G(i, pv)
+            for (int t0 = 0; t0 < s; t0 += 4) {
+                double av[4], bw[4];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = mysgr * va[t];
-    }
-    if (l < k) sv[l] = y;
-    vwave_sync();
-    double res = 0.0;
-    {
+                for (int u_ = 0; u_ < 4; ++u_) {
+                    const int t = t0 + u_;
+                    const int o = readlane_i32(ordv, t < s ? t : s - 1);
+                    av[u_] = sM[o * V32_LDG + (mine ? l : 0)];
+                    bw[u_] = (t < s) ? sM[o * V32_LDG + pv] : 0.0;
+                }
+#pragma unroll
+                for (int u_ = 0; u_ < 4; ++u_) acc = fma(-av[u_], bw[u_], acc);
+            }
+            const double lis = (l == pv) ? lpp : acc * inv;
+            if (!done) sM[pv * V32_LDG + l] = lis;            // L(:, s) into the freed column
+            const double ws = readlane_f64(bvec, pv) * inv;   // forward substitution: w_s = b_pv / lpp ; b_i -= L(i, s) w_s
+            if (!done && l != pv) { diag = fma(-lis, lis, diag); bvec = fma(-lis, ws, bvec); }
+            if (l == pv) { done = true; mystep = s; bvec = ws; myinv = inv; }
+            if (l == s) ordv = pv;
+            rank++;
+            vwave_sync();
+        }
+        // back substitution L' y = w, column-oriented: y of the last pivot first; a lane pivoted at step a < s' takes
+        // L(ord[s'], a) -- row ord[s'] of its own (freed) column -- times y_{ord[s']} off its right-hand side
+        double y = 0.0;
+        for (int s = rank - 1; s >= 0; --s) {
+            const int pvs = readlane_i32(ordv, s);
+            const double ys = readlane_f64(bvec * myinv, pvs);
+            if (mystep >= 0 && mystep < s) bvec = fma(-sM[l * V32_LDG + pvs], ys, bvec);
+            if (l == pvs) y = ys;
+        }
+        y_out = y; pivoted = mystep >= 0;
+        vwave_sync();                                         // (the factor's reads are done)
+    };
+    auto stage_active_rows = [&]() {
+        if (mycol >= 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = mysgr * va[t];
+        }
+    };
+    // r = A_bar y - q~ by lane t < n (y handed over through sv), on the staged active rows; returns this lane's entry
+    auto residual_entry = [&](double y) -> double {
+        if (l < k) sv[l] = y;
+        vwave_sync();
         double s0 = (l < 32) ? -qt : 0.0;
         const int tcol = (l < 32 && (FULL || l < n)) ? l : 0;
         for (int c0 = 0; c0 < k; c0 += 4) {
@@ -470,50 +478,107 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
 #pragma unroll
             for (int u_ = 0; u_ < 4; ++u_) s0 = fma(av[u_], yv[u_], s0);
         }
-        res = wave_sum32_f64((l < 32 && (FULL || l < n)) ? s0 * s0 : 0.0);
-    }
-    const bool ok = !qpn_ballot(badsign) && sqrt(res) <= a.tol;
-    if (ok) {
-        if (l < m) lam[l] = (mycol >= 0) ? mysgr * sv[mycol] : 0.0;        // :120-123
-        if (l == 0) { a.solution[b] = 1; a.path[b] = 2; }
-        return;
-    }
-    // ---- :129-137  bounded least squares as a box-AVI in lambda, handed to the AVI kernel: G = Ad Ad' by the ascending
-    // fma chains of verify_stage1 (bit for bit its Gram block), all rows re-staged unsigned
-    vwave_sync();
-    if (isrow) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) sM[r5 * V32_LDA + 2 * t + ch] = va[t];
-    }
-    vwave_sync();
+        return (l < 32 && (FULL || l < n)) ? s0 : 0.0;
+    };
+
+    // ---- :114-115  least squares on ALL active columns
+    double y; bool piv;
+    lsq_on(mine, y, piv);
+    // :119  sign test; then the residual A_bar y - q~ on the re-staged active rows
+    const bool badsign = l < np + nn && !(y > -a.tol);
+    stage_active_rows();
+    double rt = residual_entry(y);
     {
-        double *G = a.sG + (size_t)b * m * m;
-        double arow[32];
-        const int ri = isrow ? r5 : 0;
-#pragma unroll
-        for (int t = 0; t < 32; ++t) arow[t] = sM[ri * V32_LDA + t];
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = 2 * jj + ch;
-            if (!FULL && !(j < m)) continue;                  // (the two halves' j differ by one: at most one idle round)
-            const vd2 *rj = reinterpret_cast<const vd2 *>(sM + j * V32_LDA);
-            double s = 0.0;
-#pragma unroll
-            for (int t2 = 0; t2 < 16; ++t2) {
-                const vd2 bb2 = rj[t2];
-                if (FULL || 2 * t2 < n) s = fma(arow[2 * t2], bb2[0], s);
-                if (FULL || 2 * t2 + 1 < n) s = fma(arow[2 * t2 + 1], bb2[1], s);
-            }
-            if (isrow) G[(size_t)j * m + r5] = s;
+        const double res = wave_sum32_f64(rt * rt);
+        const bool ok = !qpn_ballot(badsign) && sqrt(res) <= a.tol;
+        if (ok) {
+            if (l < m) lam[l] = (mycol >= 0) ? mysgr * sv[mycol] : 0.0;    // :120-123
+            if (l == 0) { a.solution[b] = 1; a.path[b] = 2; }
+            return;
         }
     }
-    if (l < m) {
-        a.sq[(size_t)b * m + l] = -aq;
-        a.slb[(size_t)b * m + l] = (cls & 2) ? -QINF : 0.0;   // :129-131
-        a.sub[(size_t)b * m + l] = (cls & 1) ? QINF : 0.0;    // :132-134
-        a.sz[(size_t)b * m + l] = 0.0;
-        lam[l] = 0.0;
+    // ---- :129-137  bounded least squares  min |Ad' lambda - q~|  with the sign bounds of :129-134, in the signed columns:
+    // y_c >= 0 on the pos / neg columns (c < np + nn), y_c free on the equality columns, lambda = 0 on the inactive rows.  The
+    // reference hands this QP to PATH (solve_qp, :12-33); its minimiser's image Ad' lambda is unique, so the accept test of
+    // :138 does not depend on the method.  Here: Lawson-Hanson's active-set iteration started from the full column set --
+    // the least-squares solution just computed -- every re-solve a fresh Gram block on the matrix cores and the same
+    // Cholesky: the node never leaves the wavefront (no scratch block, no second and third launch).
+    {
+        const bool cons = l < np + nn;                        // sign-constrained column
+        bool inP = mine && piv;                               // passive set: the columns the factorisation kept
+        bool blocked = false;                                 // a column that came back non-positive after entering (LH's guard)
+        double ycur = 0.0, sl = y;                            // feasible iterate (starts at 0), least-squares solution on P
+        int iters = 0;
+        const int cap = 3 * k + 12;
+        bool failed = false;
+        for (;;) {
+            // inner loop: bring the least-squares solution on P into the feasible set
+            for (;;) {
+                const bool bad = inP && cons && !(sl > 0.0);
+                if (!qpn_ballot(bad)) { ycur = inP ? sl : 0.0; break; }
+                const double ratio = bad ? ycur / (ycur - sl) : QINF;          // ycur >= 0 >= sl: in [0, 1]; 0/0 -> NaN -> leaves
+                const double alpha = wave_min_f64((bad && ratio == ratio) ? ratio : (bad ? 0.0 : QINF));
+                if (inP) ycur = fma(alpha, sl - ycur, ycur);
+                const bool leave = bad && (!(ratio == ratio) || ratio <= alpha);      // the blocking column(s) go to zero
+                if (leave) { inP = false; ycur = 0.0; }
+                if (++iters > cap) { failed = true; break; }
+                stage_active_rows();
+                vwave_sync();
+                bool pv2;
+                lsq_on(inP, sl, pv2);
+                if (inP && !pv2) { inP = false; ycur = 0.0; }                       // dependent on the others: out, at zero
+            }
+            if (failed) break;
+            // outer test: the gradient  w = A_bar' (q~ - A_bar y)  on the zero set
+            stage_active_rows();
+            rt = residual_entry(ycur);
+            if (l < 32) sx[l] = rt;                           // (sx is free: q~ lives in registers by now)
+            vwave_sync();
+            double wgr = 0.0;
+            if (mine) {
+                const vd2 *rowc = reinterpret_cast<const vd2 *>(sM + l * V32_LDA);
+                const vd2 *rr = reinterpret_cast<const vd2 *>(sx);
+                double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+                for (int t2 = 0; t2 < 16; ++t2) {
+                    const vd2 aa = rowc[t2], r2 = rr[t2];
+                    w0 = fma(aa[0], r2[0], w0); w1 = fma(aa[1], r2[1], w1);
+                }
+                wgr = -(w0 + w1);                             // A_bar_c . (q~ - A_bar y)
+            }
+            const double gscale = wave_max_f64(mine ? fabs(rhs) : 0.0);
+            const bool cand = mine && cons && !inP && !blocked && wgr > 1e-11 * (gscale > 1.0 ? gscale : 1.0);
+            if (!qpn_ballot(cand)) break;                     // optimal
+            const double wmax = wave_max_f64(cand ? wgr : -1.0);
+            const int enter = wave_first(cand && wgr == wmax);
+            if (l == enter) inP = true;
+            if (++iters > cap) { failed = true; break; }
+            vwave_sync();
+            bool pv2;
+            lsq_on(inP, sl, pv2);
+            if (inP && !pv2) { inP = false; if (l == enter) blocked = true; }
+            const double s_enter = readlane_f64(sl, enter);
+            if (!(s_enter > 0.0)) {                           // numerically it should be: leave it out for good and carry on
+                if (l == enter) { inP = false; blocked = true; }
+                stage_active_rows();
+                vwave_sync();
+                lsq_on(inP, sl, pv2);
+                if (inP && !pv2) inP = false;
+            }
+        }
+        if (failed) {                                         // :143-145
+            if (l < m) lam[l] = 0.0;
+            if (l == 0) { a.solution[b] = 0; a.path[b] = 5; }
+            return;
+        }
+        // :138  accept iff | Ad' lambda - q~ |_2 <= 1e-4  (rt is the residual at ycur, from the last outer test)
+        const double res = wave_sum32_f64(rt * rt);
+        const bool ok = sqrt(res) <= 1e-4;
+        if (l < k) sv[l] = ycur;
+        vwave_sync();
+        if (l < m) lam[l] = (mycol >= 0) ? mysgr * sv[mycol] : 0.0;
+        if (l == 0) { a.solution[b] = ok ? 1 : 0; a.path[b] = ok ? 3 : 4; }
     }
-    if (l == 0) { a.solution[b] = 0; a.path[b] = -1; }
 }
 
 __global__ __launch_bounds__(WAVE) void verify_stage2(VerifyArgs a, const int32_t *avi_status)
@@ -810,9 +875,13 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
         hipLaunchKernelGGL(verify_wide_stage2, dim3((unsigned)batch), dim3(WTPB), 0, stream, a, (const int32_t *)sst);
         return hipGetLastError();
     }
-    if (n == 32 && m == 32) hipLaunchKernelGGL(verify_node32<true>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
-    else if (n <= 32 && m <= 32) hipLaunchKernelGGL(verify_node32<false>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
-    else hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+    if (n <= 32 && m <= 32) {
+        // ONE launch: the bounded least-squares fallback runs inside the node's wavefront (verify_node32)
+        if (n == 32 && m == 32) hipLaunchKernelGGL(verify_node32<true>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+        else hipLaunchKernelGGL(verify_node32<false>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || m == 0) return e;
     AviBatchArgs s{};
