@@ -535,7 +535,7 @@ def committed_counters():
     """HBM traffic and fp64-pipe occupancy of the dominant kernel come from rocprofv3 --pmc passes (own runs: counters cannot
     be collected inside a timed run) -- the committed summary of the latest one, tagged with where it came from.  They
     describe the build they were measured on, not necessarily this run's."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         pj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pj):
             continue
@@ -672,6 +672,19 @@ def run_config5(env, args):
     # the 2 N^2 term is per complementary (Lemke) pivot after it
     flops = N ** 3 / 3.0 + 2.0 * N * N * max(mean_piv - n, 0.0)
     achieved = flops * cnt / (ms * 1e-3) / 1e12
+    # what the Lemke phase EXECUTES: an exchange on the m x (m + 1) Schur dictionary is 2 m (m + 1) flops, not the 2 N^2 of the
+    # N x N formula (the crash took the n free variables out first); the factorisation term is left as the formula has it
+    flops_exec = N ** 3 / 3.0 + 2.0 * m * (m + 1) * max(mean_piv - n, 0.0)
+    traffic = None; traffic_src = None
+    try:
+        pj = os.path.join(ROOT, "profiles", "r04_c5_pmc_summary.json")
+        d5 = json.load(open(pj))
+        if total == 512 and world == 1:
+            traffic = d5.get("hbm_bytes_per_sweep")
+            traffic_src = ("profiles/r04_c5_pmc_summary.json (committed rocprofv3 --pmc summary, sum over the sweep's five kernels"
+                           + (f", measured at commit {d5['commit']}" if d5.get("commit") else "") + "; not measured by this run)")
+    except Exception:
+        pass
     res = {
         "metric": baseline_metric(), "value": solved * steps / dt, "unit": "solves/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "prewarm_steps": prewarm_steps, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -683,8 +696,12 @@ def run_config5(env, args):
                    "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p, "mean_pivots": mean_piv, "mean_lemke_pivots": mean_piv - n,
                    "max_resid": float(out["resid"].max().item()), "solved": solved},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "schur_big2_convert + schur_big2_eliminate + schur_big2_sprod + schur_big_lemke + schur_big2_finish (per step)", "kernel_ms": ms,
-                     "flops_per_solve": flops, "solves_per_launch": cnt},
+                     "traffic": traffic, "counters_source": traffic_src,
+                     "algorithmic_bytes_per_step": synthetic.algorithmic_bytes(n, m) * cnt,
+                     "kernel": "schur_big2_convert + schur_big2_eliminate + schur_big2_sprod + schur_big_lemke + schur_big2_finish (per step)", "kernel_ms": ms,
+                     "flops_per_solve": flops, "solves_per_launch": cnt,
+                     "flops_per_solve_executed_in_lemke_phase": flops_exec,
+                     "frac_with_executed_lemke_flops": flops_exec * cnt / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
     }
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         k = min(cnt, 16)

@@ -101,10 +101,16 @@ if latest("bench_fetch/*/*counter_collection.csv"):
         s["avi_solve_schur_sq_per_launch"] = s["sq_per_launch"]
     json.dump(s, open(os.path.join(dst, "r04_pmc_summary.json"), "w"), indent=1)
 if latest("c5_fetch/*/*counter_collection.csv"):
-    out = {"calibration_factor_known_over_reported": cal, "commit": commit, "kernels": {}}
-    names = sorted({r["Kernel_Name"] for r in rows("c5_fetch/*/*counter_collection.csv") if "schur_big" in r["Kernel_Name"]})
-    for kn in names:
-        short = kn.split("(")[0].replace("void (anonymous namespace)::", "")
-        out["kernels"][short] = {k: v for k, v in family("c5", kn.split("(")[0]).items() if k in ("hbm", "sq_per_launch")}
+    import re
+    out = {"calibration_factor_known_over_reported": cal, "commit": commit,
+           "workload": "bench.py --config 5: 512 nodes, n = m = 256, one sweep = the launches below", "kernels": {}}
+    shorts = sorted({re.search(r"(schur_big\w*(?:<\d+>)?)", r["Kernel_Name"]).group(1)
+                     for r in rows("c5_fetch/*/*counter_collection.csv") if "schur_big" in r["Kernel_Name"]})
+    total = 0.0
+    for kn in shorts:
+        fam = family("c5", kn + "(")
+        out["kernels"][kn] = {k: v for k, v in fam.items() if k in ("hbm", "sq_per_launch")}
+        total += fam.get("hbm", {}).get("hbm_bytes_per_launch", 0.0)
+    out["hbm_bytes_per_sweep"] = total
     json.dump(out, open(os.path.join(dst, "r04_c5_pmc_summary.json"), "w"), indent=1)
-    print(json.dumps(out, indent=1)[:1500])
+    print(json.dumps({k: v.get("hbm", {}).get("hbm_bytes_per_launch") for k, v in out["kernels"].items()}, indent=1), total)
