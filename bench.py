@@ -53,8 +53,6 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", type=int, choices=(4, 5), default=4,
                     help="4: 10 000 nodes x 32 variables (BASELINE configs[3], the metric's config); 5: 512 nodes x 256 variables")
-    ap.add_argument("--big-route", type=int, choices=(0, 1), default=1,
-                    help="--config 5, A/B: 1 = blocked crash straight from the records (default), 0 = round 2's route over an assembled M")
     ap.add_argument("--sym-route", type=int, choices=(0, 1), default=1,
                     help="A/B: 1 (default) = resident records whose Qd blocks are all symmetric take the kernel variants that use it, 0 = never")
     ap.add_argument("--nodes", type=int, default=None, help="nodes in the whole net (strong) / per GPU (weak)")
@@ -71,7 +69,7 @@ def parse_args():
     ap.add_argument("--no-prewarm", action="store_true",
                     help=f"skip the {PREWARM_STEPS} untimed steps (~0.1 s) that bring the GPU out of its idle power state")
     ap.add_argument("--no-scaling-proxy", action="store_true",
-                    help="N = 1: skip the strong_scaling_proxy object (per-sweep time at 10 000 / 5 000 / 2 500 / 1 250 nodes)")
+                    help="N = 1: skip the modelled_strong_scaling object (per-sweep time at 10 000 / 5 000 / 2 500 / 1 250 nodes on ONE GPU)")
     ap.add_argument("--outer-loop-pairs", type=int, default=250,
                     help="N = 1: leader-follower pairs (n = m = 32) of the net the outer_loop object runs through solve(); 0 skips it")
     ap.add_argument("--no-schedule", action="store_true",
@@ -391,7 +389,7 @@ def run_case(env, args, nodes, scaling, steps, warmup, prewarm, with_cpu):
     if with_cpu and rank == 0:
         out["cpu_baseline"] = cpu_baseline(np, Q, R, qd, A, B, l, u, w_host)
     if world == 1 and not use_dist and handle is not None and not args.no_scaling_proxy and total == NODES:
-        out["strong_scaling_proxy"] = strong_scaling_proxy(env, drec, ring, n, m, kern_ms_all)
+        out["modelled_strong_scaling"] = strong_scaling_proxy(env, drec, ring, n, m, kern_ms_all)
     if world == 1 and not use_dist and args.outer_loop_pairs > 0 and total == NODES:
         try:
             out["outer_loop"] = outer_loop(env, args.outer_loop_pairs, n, m)
@@ -521,14 +519,44 @@ def strong_scaling_proxy(env, drec, ring, n, m, full_ms):
     except Exception as e:          # the proxy must never cost the run its line
         gather_us = None
         print(f"[bench] strong_scaling_proxy: one-rank RCCL all-gather not measured ({e})", file=sys.stderr, flush=True)
+    # a 64-byte all-reduce on the one-rank group: what the status-only exchange of a net sharded BY CLUSTER costs per sweep
+    # (sharding.solve_sharded: no cluster reads another's variables, so the iterate stays where it is until the end)
+    allred_us = None
+    try:
+        import torch.distributed as dist
+        own = not dist.is_initialized()
+        if own:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        tiny = torch.zeros(8, dtype=torch.float64, device=dev)
+        for i in range(20):
+            dist.all_reduce(tiny)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(200):
+            dist.all_reduce(tiny)
+        e1.record(); torch.cuda.synchronize()
+        allred_us = e0.elapsed_time(e1) / 200 * 1e3
+        if own:
+            dist.destroy_process_group()
+    except Exception as e:
+        print(f"[bench] scaling model: one-rank all-reduce not measured ({e})", file=sys.stderr, flush=True)
     exch_ms = (status_us + (gather_us or 0.0)) * 1e-3
+    stat_ms = (status_us + (allred_us or 0.0)) * 1e-3
     t1 = per[10_000]
-    return {"route": "resident node records, one fused launch per sweep (the bench step), HIP-event time over 400 back-to-back sweeps",
+    return {"what": "a MODEL from single-GPU timings, NOT a measurement on N GPUs (no multi-GPU node was available to this run): "
+                    "t(10 000 nodes) / (t(10 000 / G nodes) + exchange), every term measured on this one GPU",
+            "route": "resident node records, one fused launch per sweep (the bench step), HIP-event time over 400 back-to-back sweeps",
             "ms_per_sweep": {str(k): v for k, v in per.items()},
-            "exchange_us": {"sweep_status_kernel": status_us, "rccl_all_gather_one_rank_lower_bound": gather_us},
-            "implied_speedup": {str(g): t1 / (per[10_000 // g] + (exch_ms if g > 1 else 0.0)) for g in (1, 2, 4, 8)},
+            "exchange_us": {"sweep_status_kernel": status_us, "rccl_all_gather_one_rank_lower_bound": gather_us,
+                            "rccl_all_reduce_64B_one_rank_lower_bound": allred_us},
+            "modelled_speedup_all_gather_per_sweep": {str(g): t1 / (per[10_000 // g] + (exch_ms if g > 1 else 0.0)) for g in (1, 2, 4, 8)},
+            "modelled_speedup_status_only_per_sweep": {str(g): t1 / (per[10_000 // g] + (stat_ms if g > 1 else 0.0)) for g in (1, 2, 4, 8)},
             "note": "strong scaling of this net is bound by the per-node dependent chain (one wavefront per node, ~30 us), "
-                    "not by the exchange: 1 250 nodes do not fill one GPU's 4 096 resident wavefronts"}
+                    "not by the exchange: 1 250 nodes do not fill one GPU's 4 096 resident wavefronts.  status-only: the net sharded "
+                    "by cluster (whole leader-follower pairs per rank, sharding.solve_sharded) exchanges the 8-double status per "
+                    "sweep and the iterate once at the end; all-gather: node-range sharding, the whole iterate every sweep"}
 
 
 def committed_counters():
@@ -639,7 +667,6 @@ def run_config5(env, args):
         ring_host = ring_host + 0.25 * np.random.Generator(np.random.Philox(key=[synthetic.SEED, 2 ** 41])).standard_normal((RING, p))
     ring = t(ring_host)
     from qpn_amd import _lib as qlib
-    eng.set_option(qlib.OPT_BIG_ROUTE, args.big_route)
     eng.set_option(qlib.OPT_SYM_ROUTE, args.sym_route)
     handle = eng.upload_nodes(*drec)
     steps = min(args.steps, 50)

@@ -244,16 +244,19 @@ int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period);
 /* Per-context options that select between kernel routes with IDENTICAL contracts (A/B measurements, tests of a route
  * against the one it replaced).  Results never depend on them beyond rounding.
  *   QPN_OPT_MID_ROUTE  node records with n, m <= 128 and one of them > 32 (qpn_solve_nodes*): 1 = one fused kernel per node
- *                      (default: ONE wavefront per node for max(n, m) <= 48, one workgroup per node beyond), 3 = the workgroup
- *                      kernel also for 33 .. 48, 2 = round 2's routes (three kernels with an HBM workspace up to 64, the route
- *                      of large nodes beyond), 0 = the route of large nodes.
- *                      (The library reads no environment variable; diagnostic builds with -DQPN_DEV_SWITCHES accept a preset.)
- *   QPN_OPT_BIG_ROUTE  node records with 64 < n <= 256 and m <= 256 beyond the sizes above (BASELINE config 5): 1 = the blocked
- *                      matrix-core crash straight from the records (default), 0 = round 2's route over an assembled M.
+ *                      (default: ONE wavefront per node for max(n, m) <= 48, one workgroup per node beyond), 0 = the general
+ *                      route (assembled blocks -> the route of large nodes / the general kernels): the cross-check of the tests.
+ *                      (Round 3's values 2 and 3 -- round 2's three-kernel route, the workgroup kernel for 33 .. 48 -- are gone;
+ *                      the library reads no environment variable; diagnostic builds with -DQPN_DEV_SWITCHES accept a preset.)
+ *   QPN_OPT_BIG_ROUTE  kept for callers that set the default: takes 1 only (the blocked matrix-core crash straight from the
+ *                      records, BASELINE config 5); round 2's route over an assembled M is gone as a node-record switch -- the
+ *                      same kernels serve large node-shaped items passed as M through qpn_solve_avi_batch.
  *   QPN_OPT_SYM_ROUTE  resident records (qpn_nodes_upload) whose Qd blocks are ALL bitwise symmetric: 1 = kernel variants that
  *                      use the symmetry of H and of S = A H^-1 A' (default; today n = m = 32: 8 of 88 fp64 MFMAs per solve less),
  *                      0 = the general variants.  Records with any asymmetric Qd, and records passed per call, always take
- *                      the general variants. */
+ *                      the general variants.
+ * A resident handle remembers under which option values it learned that none of its nodes declines; after a change it asks again
+ * on its next sweep (another kernel variant applies its pivot test to slightly different numbers). */
 #define QPN_OPT_MID_ROUTE 1
 #define QPN_OPT_BIG_ROUTE 2
 #define QPN_OPT_SYM_ROUTE 3

@@ -8,7 +8,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${QPN_OUT:-$here/../libqpn_hip.so}"
 obj="${QPN_OBJ:-$here/_obj}"
 mkdir -p "$obj"
-units=(qpn_capi qpn_avi_solve qpn_avi_reg qpn_avi_big qpn_avi_schur qpn_avi_schur_big qpn_avi_schur_big2 qpn_avi_schur_mid qpn_avi_schur_wg qpn_avi_schur_wg2 qpn_avi_schur48 qpn_kkt qpn_pieces qpn_verify)
+units=(qpn_capi qpn_avi_solve qpn_avi_reg qpn_avi_big qpn_avi_schur qpn_avi_schur_big qpn_avi_schur_big2 qpn_avi_schur_wg qpn_avi_schur_wg2 qpn_avi_schur48 qpn_kkt qpn_pieces qpn_verify)
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-parameter "$@")
 # a change of flags rebuilds everything
 sig="$(printf '%s ' "${flags[@]}" | sha1sum | cut -c1-16)"

@@ -113,9 +113,7 @@ __device__ __forceinline__ double rcp64(double x)
     return fma(r, e, r);
 }
 
-#ifndef QPN_STG_UNIT
 #define QPN_STG_UNIT 64       /* stagger step of the first round: 64 x 64 clocks = 1.7 us per wave slot */
-#endif
 constexpr int kResidentMI355X = 16 * 256;      // wavefronts of this kernel resident at once: 16 per CU, 256 CUs
 
 // SHAPE: 0 = sizes read at run time (any n, m <= 32); 32 / 16 = every item of the launch is n = m = SHAPE, a compile-time
@@ -1137,11 +1135,7 @@ __global__ __launch_bounds__(WAVE, 4) void avi_solve_schur(AviBatchArgs a, Schur
             double rl1 = 0.0, rl2 = 0.0;                                            // columns of lambda: -A' (x rows), two chains
 #pragma unroll 8
             for (int k = 0; k < 16; k += 2) { rl1 = fma(-sA[rof2 + k], szl[k], rl1); rl2 = fma(-sA[rof2 + k + 1], szl[k + 1], rl2); }
-#ifdef V1
-            rq += rl1 + rl2;
-#else
             rq += sum_halves(rl1 + rl2);
-#endif
         } else {
 #pragma unroll 8
         for (int k = 0; k < nm; ++k) rq = fma(-sA[roff + k], sz[nn + k], rq);      // columns of lambda: -A' (x rows)

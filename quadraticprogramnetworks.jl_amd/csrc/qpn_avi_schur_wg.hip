@@ -940,8 +940,9 @@ hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream)
     const int NT = n <= 48 ? 3 : 4, MT = m <= 48 ? 3 : 4;
     const size_t lds = (size_t)wg_lds_doubles(n, m, 16 * NT, 16 * MT) * sizeof(double);
     const dim3 grid((unsigned)batch);
-    if (NT == 3 && MT == 3) hipLaunchKernelGGL((schur_wg_nodes<3, 3>), grid, dim3(192), lds, stream, a);
-    else if (NT == 3) hipLaunchKernelGGL((schur_wg_nodes<3, 4>), grid, dim3(256), lds, stream, a);
+    // (max(n, m) <= 48 is the one-wavefront kernel's class, qpn_avi_schur48.hip: the dispatcher never sends it here)
+    if (NT == 3 && MT == 3) return hipErrorInvalidValue;
+    if (NT == 3) hipLaunchKernelGGL((schur_wg_nodes<3, 4>), grid, dim3(256), lds, stream, a);
     else if (MT == 3) hipLaunchKernelGGL((schur_wg_nodes<4, 3>), grid, dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((schur_wg_nodes<4, 4>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();

@@ -34,13 +34,11 @@ struct qpn_ctx {
     size_t mirror_bytes = 0;
     int32_t mirror_count = 0;
     double *mirror_peer[QPN_MAX_MIRRORS] = {};
-    // route of mid-size node records (qpn_ctx_set_option QPN_OPT_MID_ROUTE; the environment variable QPN_NODES_MID, read ONCE
-    // when the context is created, sets the default): 1 the fused kernels (one wavefront per node up to 48, one workgroup per node
-    // beyond), 3 the workgroup kernel also for 33 .. 48, 2 round 2's three kernels, 0 the route of the large nodes
+    // route of mid-size node records (qpn_ctx_set_option QPN_OPT_MID_ROUTE): 1 the fused kernels (one wavefront per node up to 48,
+    // one workgroup per node beyond), 0 the route of the large nodes / the general kernels (the tests' cross-check)
     int32_t mid_route = 1;
-    // route of large node records (QPN_OPT_BIG_ROUTE): 1 the blocked crash straight from the records (qpn_avi_schur_big2.hip),
-    // 0 round 2's route (M assembled, qpn_avi_schur_big.hip)
-    int32_t big_route = 1;
+    // every route option change bumps this; a resident handle that learned its declines under another epoch asks again
+    int32_t route_epoch = 0;
     // QPN_OPT_SYM_ROUTE: 1 = resident records whose Qd blocks are all bitwise symmetric take the kernel variants that use it
     int32_t sym_route = 1;
 };
@@ -140,7 +138,7 @@ int qpn_ctx_create(int device_id, qpn_ctx **out)
     }
     ctx->stream = ctx->own_stream;
     // diagnostic builds (-DQPN_DEV_SWITCHES) only: a preset of the mid-size route, read ONCE here; qpn_ctx_set_option overrides it
-    if (const char *e = QPN_DEV_ENV("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '3' && !e[1]) ctx->mid_route = e[0] - '0'; }
+    if (const char *e = QPN_DEV_ENV("QPN_NODES_MID")) { if (e[0] >= '0' && e[0] <= '1' && !e[1]) ctx->mid_route = e[0] - '0'; }
     *out = ctx;
     return QPN_OK;
 }
@@ -150,15 +148,16 @@ int qpn_ctx_set_option(qpn_ctx *ctx, int32_t option, int32_t value)
     if (!ctx) return QPN_ERR_ARG;
     switch (option) {
     case QPN_OPT_MID_ROUTE:
-        if (value < 0 || value > 3) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_MID_ROUTE takes 0, 1, 2 or 3");
+        if (value < 0 || value > 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_MID_ROUTE takes 0 or 1");
+        if (ctx->mid_route != value) ctx->route_epoch++;
         ctx->mid_route = value;
         return QPN_OK;
     case QPN_OPT_BIG_ROUTE:
-        if (value < 0 || value > 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_BIG_ROUTE takes 0 or 1");
-        ctx->big_route = value;
+        if (value != 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_BIG_ROUTE takes 1 (round 2's route over an assembled M is gone)");
         return QPN_OK;
     case QPN_OPT_SYM_ROUTE:
         if (value < 0 || value > 1) return fail_arg(ctx, "qpn_ctx_set_option: QPN_OPT_SYM_ROUTE takes 0 or 1");
+        if (ctx->sym_route != value) ctx->route_epoch++;
         ctx->sym_route = value;
         return QPN_OK;
     default:
@@ -809,6 +808,9 @@ struct qpn_nodes {
     int32_t period = 16, calls = 0;
     // every Qd block bitwise symmetric?  Settled when the records arrive (one pass, nodes_check_symmetry)
     bool sym = false;
+    // the context's route epoch the decline knowledge was learned under (qpn_ctx_set_option bumps it: another kernel variant
+    // applies its pivot test to slightly different numbers, so "no node declines" has to be asked again)
+    int32_t route_epoch = 0;
 };
 
 namespace {
@@ -835,13 +837,21 @@ void nodes_poll_declines(qpn_nodes *h)
 {
     if (h && h->decl_state == 1 && hipEventQuery(h->decl_ev) == hipSuccess) h->decl_state = (*h->decl_host == 0) ? 2 : 3;
 }
+// a route option changed since the handle last learned its declines: forget the answer (after the count in flight has landed)
+void nodes_sync_route(qpn_ctx *ctx, qpn_nodes *h)
+{
+    if (!h || h->route_epoch == ctx->route_epoch) return;
+    if (h->decl_state == 1) (void)hipEventSynchronize(h->decl_ev);
+    h->decl_state = 0;
+    h->route_epoch = ctx->route_epoch;
+}
 
 // The launches of one sweep over device-resident records and outputs.  `h` (may be null) owns the records:
 // its decline knowledge and its schedule are used and refreshed.  wM.. = assembled-block workspace for the
 // general path (null only when h knows that no node declines).
 int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_t m, int32_t p, const NodeDev &d,
                        int64_t stride_w, const qpn_avi_opts &o, double *x_dev, int64_t stride_x, double *wM, double *wq,
-                       double *wl, double *wu, uint8_t *wk, double *wbig, void *wmid, bool wg_shape)
+                       double *wl, double *wu, uint8_t *wk, double *wbig, bool wg_shape)
 {
     hipStream_t s = ctx->stream;
     const int N = n + m;
@@ -924,10 +934,10 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
             }
             ctx->auto_calls++;
         }
-    } else if (wmid || wg_shape) {
-        // mid-size nodes (n, m <= 64): one workgroup per node straight from the records, ONE launch (qpn_avi_schur_wg.hip;
-        // wmid: round 2's three kernels, qpn_avi_schur_mid.hip); what they decline (status = -1) is assembled and solved by
-        // the general kernels in gated launches
+    } else if (wg_shape) {
+        // mid-size nodes (n, m <= 128): one wavefront (max(n, m) <= 48) or one workgroup per node straight from the records, ONE
+        // launch (qpn_avi_schur48.hip, qpn_avi_schur_wg.hip, qpn_avi_schur_wg2.hip); what they decline (status = -1) is assembled
+        // and solved by the general kernels in gated launches
         bool need_general = true;
         if (h) {
             nodes_poll_declines(h);
@@ -937,7 +947,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                 a.decl_count = h->decl_dev;
             }
         }
-        if (wg_shape) {
+        {
             // the kernel writes the primal blocks into the iterate itself once it is known that nothing declines (the
             // general kernels behind it do not); until then the strided copy below does
             if (x_dev && !need_general) {
@@ -950,7 +960,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
             // the handle's longest-first schedule as in the 32-class (launches beyond the resident set only: 2 048 wavefronts of the
             // one-wavefront kernel, 1 024 workgroups of the 49-64 class, 256 of the 65-128 class): the kernel feeds the smoothed
             // pivot counts, the order is re-sorted from them
-            const bool one_wave = ctx->mid_route == 1 && qpn_schur48_shape(n, m), two_role = qpn_schur_wg2_shape(n, m);
+            const bool one_wave = qpn_schur48_shape(n, m), two_role = qpn_schur_wg2_shape(n, m);
             const bool sched = h && h->period > 0 && batch > (one_wave ? 2048 : (two_role ? 256 : 1024));
             if (sched) { a.sched_key = h->key; if (h->order_valid) a.order = h->order; }
             if (two_role) HIPCHK(ctx, qpn_launch_schur_wg2_nodes(a, s));
@@ -966,7 +976,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
                 h->calls++;
             }
             a.x = nullptr; a.n_mirror = 0;
-        } else HIPCHK(ctx, qpn_launch_schur_mid_nodes(a, wmid, s));
+        }
         if (need_general) {
             if (!wM) return fail_arg(ctx, "qpn_solve_nodes: internal error (no workspace for the general path)");
             HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
@@ -983,7 +993,7 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
             HIPCHK(ctx, hipEventRecord(h->decl_ev, s));
             h->decl_state = 1;
         }
-    } else if (ctx->big_route == 1 && qpn_schur_big2_shape(n, m) && wbig && (o.max_pivots <= 0 || o.max_pivots - n >= 1)) {
+    } else if (qpn_schur_big2_shape(n, m) && wbig && (o.max_pivots <= 0 || o.max_pivots - n >= 1)) {
         // large nodes (BASELINE config 5): the blocked crash straight from the records (qpn_avi_schur_big2.hip), the
         // delayed-update Lemke kernel on the Schur problems, read-back and post-check on the records; no M is assembled unless a
         // node declines -- those (status = -1) are assembled and solved by the general kernel in gated launches
@@ -1035,19 +1045,17 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
     const bool mfma_shape = n <= 32 && m <= 32 && m >= 1;
     // the handle may already know that the general path has nothing to do: no workspace for it then
     nodes_poll_declines(h);
-    // mid-size nodes: the fused workgroup kernel (no workspace) or, for A/B runs, the routes it replaced (ctx->mid_route)
-    const bool mid_ok = qpn_schur_mid_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
+    nodes_sync_route(ctx, h);
+    // mid-size nodes: the fused kernels (no workspace); QPN_OPT_MID_ROUTE = 0 sends them down the general route
+    const bool mid_ok = qpn_schur_wg_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
     const bool wg2_ok = qpn_schur_wg2_shape(n, m) && (o.max_pivots <= 0 || o.max_pivots - n >= 1);
-    const bool wg_shape = (ctx->mid_route == 1 || ctx->mid_route == 3) && (mid_ok || wg2_ok);
-    const bool mid_shape = ctx->mid_route == 2 && mid_ok;
-    const bool need_ws = !(h && (mfma_shape || mid_shape || wg_shape) && h->decl_state == 2);
+    const bool wg_shape = ctx->mid_route == 1 && (mid_ok || wg2_ok);
+    const bool need_ws = !(h && (mfma_shape || wg_shape) && h->decl_state == 2);
 
     NodeDev d{Qd, R, qd, Ad, B, l, u, w, z, status, resid, pivots, active};
     double *wM = nullptr, *wq = nullptr, *wl = nullptr, *wu = nullptr, *wbig = nullptr; uint8_t *wk = nullptr;
-    void *wmid = nullptr;
     double *hQ, *hR, *hq, *hA, *hB, *hl, *hu, *hw, *hz = nullptr, *hres, *hx = nullptr; int32_t *hst, *hpv; uint8_t *hact;
     Carver cv(ctx);
-    if (mid_shape) cv.add(&wmid, qpn_schur_mid_workspace_bytes(batch, n, m));
     if (need_ws) {
         cv.add((void **)&wM, bN * N * 8); cv.add((void **)&wq, bN * 8); cv.add((void **)&wl, bN * 8);
         cv.add((void **)&wu, bN * 8); cv.add((void **)&wk, bN);
@@ -1088,7 +1096,7 @@ int solve_nodes_any(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int32_
 
     double *x_dev = host ? hx : x;
     const int64_t sx_dev = host ? (int64_t)n : stride_x;
-    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig, wmid, wg_shape);
+    rc = solve_nodes_launch(ctx, h, batch, n, m, p, d, stride_w, o, x_dev, sx_dev, wM, wq, wl, wu, wk, wbig, wg_shape);
     if (rc != QPN_OK) return rc;
     if (host) {
         if (z) HIPCHK(ctx, hipMemcpyAsync(z, d.z, bN * 8, hipMemcpyDeviceToHost, s));

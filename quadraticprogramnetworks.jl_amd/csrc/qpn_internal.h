@@ -120,19 +120,7 @@ bool qpn_schur_big2_shape(int n, int m);
 hipError_t qpn_launch_schur_big2_stage_a(const AviBatchArgs &a, void *ws, double *dict, SchurBigWs *out, hipStream_t stream);   // a.nd set
 hipError_t qpn_launch_schur_big2_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
 
-// qpn_avi_schur_mid.hip: node records with n, m <= 64 (one of them > 32): four wavefronts per node, no assembled M
-struct SchurMidWs {
-    double *W, *S, *c, *lam, *gq;      // W~ column-major [m_pad][n_pad] then h [n_pad] (stride w_stride); S m x m; c, lam (m); q (n+m)
-    int32_t *st2, *piv2;
-    uint8_t *ones;
-    int64_t w_stride;
-    int32_t s_bs;            // > 0: S in the register-block layout of avi_solve_reg<s_bs> (stride 4096 doubles per node)
-};
-bool qpn_schur_mid_shape(int n, int m);
-size_t qpn_schur_mid_workspace_bytes(int batch, int n, int m);
-hipError_t qpn_launch_schur_mid_nodes(const AviBatchArgs &a, void *ws, hipStream_t stream);   // a.nd set; declined nodes keep status -1
-
-// qpn_avi_schur_wg.hip: the same node records in ONE fused workgroup kernel (crash, Lemke, read-back, post-check; no workspace)
+// qpn_avi_schur_wg.hip: node records with 49 <= max(n, m) <= 64 in ONE fused workgroup kernel (crash, Lemke, read-back, post-check; no workspace)
 bool qpn_schur_wg_shape(int n, int m);
 hipError_t qpn_launch_schur_wg_nodes(const AviBatchArgs &a, hipStream_t stream);
 // one wavefront per node, 33 <= max(n, m) <= 48 (qpn_avi_schur48.hip)

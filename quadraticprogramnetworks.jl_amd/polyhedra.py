@@ -401,10 +401,37 @@ def implicit_bounds_batch(polys, engine, tol=1e-4):
             if sg < 0 and u[i] == INF:
                 u2[k, i] = big[k]
         st, x, _ = _solve_lps(cost, A2, l2, u2, engine)
+        val = [float(trips[b][0][i] @ x[k, :trips[b][0].shape[1]]) if st[k] == 1 else np.nan for k, (b, i, sg) in enumerate(jobs)]
+        # an optimum AT the far bound is read as "unbounded" only if it follows the bound: those LPs are solved once more with the
+        # bound ten times as far out -- an unbounded row's optimum moves with it, a bounded row whose extreme merely lies beyond
+        # 1e6 x the scale keeps its value (and is reported as the finite number it is)
+        def closed_here(k):                                 # was this job's open side closed artificially?
+            b, i, sg = jobs[k]
+            return (sg > 0 and trips[b][1][i] == -INF) or (sg < 0 and trips[b][2][i] == INF)
+        # (a row whose whole range lies beyond the far bound makes the closed LP infeasible -- RAY_TERM -- although the set is
+        #  not empty: such jobs are looked at again too)
+        again = [k for k in range(len(jobs)) if (st[k] == 1 and abs(val[k]) >= big[k] * (1.0 - 1e-6)) or (st[k] == 2 and closed_here(k))]
+        if again:
+            l3 = l2[again].copy(); u3 = u2[again].copy()
+            for t, k in enumerate(again):
+                b, i, sg = jobs[k]
+                if sg > 0: l3[t, i] = -10.0 * big[k]
+                else: u3[t, i] = 10.0 * big[k]
+            st3, x3, _ = _solve_lps(cost[again], A2[again], l3, u3, engine)
+            for t, k in enumerate(again):
+                b, i, sg = jobs[k]
+                if st3[t] == 1:
+                    v3 = float(trips[b][0][i] @ x3[t, :trips[b][0].shape[1]])
+                    if abs(v3) < 10.0 * big[k] * (1.0 - 1e-6):
+                        val[k] = v3; big[k] = INF; st[k] = 1     # bounded after all
+                    else:
+                        big[k] = 0.0; val[k] = 0.0; st[k] = 1    # follows the bound: unbounded
+                elif st3[t] == 2:
+                    big[k] = 0.0; val[k] = 0.0; st[k] = 1        # still out of reach ten times further out: read as unbounded
         ext = {}
         for k, (b, i, sg) in enumerate(jobs):
             if st[k] == 1:
-                v = float(trips[b][0][i] @ x[k, :trips[b][0].shape[1]])
+                v = val[k]
                 if abs(v) >= big[k] * (1.0 - 1e-6):
                     v = -INF if sg > 0 else INF                 # at the far bound: unbounded in that direction
             elif st[k] == 2:

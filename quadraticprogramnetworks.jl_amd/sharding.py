@@ -226,3 +226,140 @@ class SharedIterate:
             if a:
                 self.eng.shared_free(a)
         self.addr = self.box = 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharding the NET by cluster: whole independent subtrees per rank, exchange by need
+# ---------------------------------------------------------------------------------------------------------------------
+def net_clusters(qpn):
+    """Connected components of the net's dependency graph over ALL levels: nodes joined by an edge (a parent reads its child's
+    solution graph, src/programs.jl:274-285) or by one reading a variable the other owns (cost or constraint rows:
+    src/avi.jl:335-340).  BASELINE config 4's 5 000 leader-follower pairs are 5 000 clusters of two nodes.  A cluster never
+    reads another cluster's variables, so its outer loop (src/algorithm.jl:13-117) runs to its end without seeing the rest
+    of the net.  -> list of sorted node-id lists, ordered by smallest id."""
+    import numpy as np
+    ids = sorted(qpn.qps)
+    parent = {i: i for i in ids}
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    def join(a, b):
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+
+    owner = {}
+    for i in ids:
+        for v in qpn.qps[i].var_indices:
+            if v in owner:
+                join(owner[v], i)
+            else:
+                owner[v] = i
+    for i in ids:
+        for j in qpn.network_edges.get(i, ()):
+            join(i, j)
+        qp = qpn.qps[i]
+        reads = [qp.f.local()[0]] + [qpn.constraints[c].poly.support() for c in qp.constraint_indices]
+        for v in np.unique(np.concatenate(reads)).tolist():
+            o = owner.get(v)
+            if o is not None:
+                join(o, i)
+    comps = {}
+    for i in ids:
+        comps.setdefault(find(i), []).append(i)
+    return [sorted(c) for _, c in sorted(comps.items())]
+
+
+def sub_net(qpn, node_ids):
+    """The net restricted to `node_ids` (whole clusters): a QPNet of its own over the variables those nodes own or read
+    (variables nobody in the set owns stay what they are: parameters), nodes and constraints renumbered in order.
+    -> (sub-net, variables [local -> global index], node ids [local id - 1 -> global id])."""
+    import numpy as np
+    from .programs import Poly, QPNet
+    node_ids = sorted(node_ids)
+    keep = set(node_ids)
+    vs = []
+    cons = []
+    for i in node_ids:
+        qp = qpn.qps[i]
+        vs.append(np.asarray(qp.var_indices, dtype=np.int64)); vs.append(qp.f.local()[0])
+        for c in qp.constraint_indices:
+            if c not in cons:
+                cons.append(c)
+            vs.append(qpn.constraints[c].poly.support())
+    var = np.unique(np.concatenate(vs))
+    pos = {int(v): k for k, v in enumerate(var.tolist())}
+    net = QPNet(var.size)
+    cmap = {}
+    for c in sorted(cons):
+        P = qpn.constraints[c].poly
+        cols, A = P.local()
+        cid = max(net.constraints.keys(), default=0) + 1
+        from .programs import Constraint
+        net.constraints[cid] = Constraint(Poly.from_local(var.size, [pos[int(v)] for v in cols.tolist()], A, P.l, P.u, normalise=False,
+                                                          open_lo=P.open_lo, open_hi=P.open_hi))
+        cmap[c] = cid
+    nmap = {}
+    for i in node_ids:
+        qp = qpn.qps[i]
+        idx, Ql, ql = qp.f.local()
+        nmap[i] = net.add_qp(Ql, ql, [cmap[c] for c in qp.constraint_indices], [pos[int(v)] for v in qp.var_indices], k=qp.f.k,
+                             idx=[pos[int(v)] for v in idx.tolist()])
+    net.add_edges([(nmap[i], nmap[j]) for i in node_ids for j in qpn.network_edges.get(i, ()) if j in keep])
+    net.assign_constraint_groups()
+    net.options = qpn.options
+    net.default_initialization = np.asarray(qpn.default_initialization, dtype=np.float64)[var].copy()
+    return net, var, node_ids
+
+
+def assign_clusters(clusters, world):
+    """Whole clusters to ranks, balanced by node count (largest first, each to the lightest rank).  -> list per rank of cluster indices."""
+    load = [0] * world
+    mine = [[] for _ in range(world)]
+    for k in sorted(range(len(clusters)), key=lambda k: (-len(clusters[k]), k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        mine[r].append(k); load[r] += len(clusters[k])
+    return [sorted(m) for m in mine]
+
+
+def solve_sharded(qpn, x_init=None, dist=None, engine=None):
+    """solve(qpn) with the net sharded by cluster over the ranks of `dist` (one process per GPU): every rank runs the outer loop
+    on the sub-net of its own clusters -- no exchange while it sweeps, because no cluster reads another's variables -- and the
+    ranks meet ONCE, at the end: the blocks of the iterate each of them owns (all-gather; gloo in the CPU tests, RCCL on GPUs)
+    and the solved flags.  Per sweep nothing crosses a link; the all-gather of the whole iterate per sweep that the node-range
+    sharding of the bench does (GatheredIterate) is what a parent on ANOTHER rank would need -- clusters keep parents and children
+    together.  dist == None: one rank.  -> dict(solved, x_opt, clusters, owned [the cluster indices of this rank])."""
+    import numpy as np
+    from . import algorithm
+    x0 = np.asarray(qpn.default_initialization if x_init is None else x_init, dtype=np.float64)
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    clusters = net_clusters(qpn)
+    mine = assign_clusters(clusters, world)[rank]
+    x = x0.copy()
+    ok = True
+    err = None
+    if mine:
+        nodes = sorted(i for k in mine for i in clusters[k])
+        net, var, _ = sub_net(qpn, nodes)
+        ret = algorithm.solve(net, x0[var], engine=engine)
+        ok = bool(ret["solved"])
+        err = ret.get("error")
+        owned = np.unique(np.concatenate([np.asarray(qpn.qps[i].var_indices, dtype=np.int64) for i in nodes]))
+        if ok:
+            loc = {int(v): k for k, v in enumerate(var.tolist())}
+            x[owned] = ret["x_opt"][[loc[int(v)] for v in owned.tolist()]]
+    else:
+        owned = np.zeros(0, np.int64)
+    if dist is not None and world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (ok, err, owned, x[owned]))      # one exchange for the whole solve
+        ok = all(p[0] for p in parts)
+        err = next((p[1] for p in parts if p[1]), None)
+        for p in parts:
+            x[p[2]] = p[3]
+    return dict(solved=ok, x_opt=x if ok else None, x_fail=None if ok else x, error=err, clusters=clusters, owned=mine)

@@ -108,8 +108,8 @@ def test_config5_subset_against_oracle(oracle, full5):
 def test_large_nodes_from_records_vs_oracle_and_previous_route(engine, oracle, n, m, cnt):
     """The blocked crash straight from the records (csrc/qpn_avi_schur_big2.hip: rank-64 block pivots on a tile-format
     workspace, sizes that are not multiples of 16 padded in the conversion pass) against the oracle -- status, masks bit-exact,
-    primals within 1e-9 relative, pivot counts -- and against round 2's route over an assembled M (QPN_OPT_BIG_ROUTE = 0):
-    same masks and pivot counts, primals within 1e-9."""
+    primals within 1e-9 relative, pivot counts -- and against the explicit-M route over the assembled blocks: same masks and
+    pivot counts, primals within 1e-9."""
     from qpn_amd import _lib
     from qpn_amd.engine import colmajor
     Q, R, qd, A, B, l, u = P.synth_nodes(9000 + n + m, cnt, n, m, 4)
@@ -122,11 +122,10 @@ def test_large_nodes_from_records_vs_oracle_and_previous_route(engine, oracle, n
     assert np.array_equal(rh["active"], rc["active"]) and np.array_equal(rh["pivots"], rc["pivots"])
     scale = np.maximum(1.0, np.max(np.abs(rc["z"]), axis=1, keepdims=True))
     assert np.max(np.abs(rh["z"] - rc["z"]) / scale) <= 1e-9 and np.max(rh["resid"]) <= 1e-8
-    engine.set_option(_lib.OPT_BIG_ROUTE, 0)
-    try:
-        r0 = engine.solve_nodes(*args)
-    finally:
-        engine.set_option(_lib.OPT_BIG_ROUTE, 1)
+    # the same nodes as an assembled M through the explicit-M route of large node-shaped items (qpn_assemble_nodes +
+    # qpn_solve_avi_batch: the kernels round 2 ran config 5 on -- its node-record switch QPN_OPT_BIG_ROUTE = 0 is gone)
+    Mc, qq, ll, uu, kk = engine.assemble_nodes(*args)
+    r0 = engine.solve_avi_batch(Mc, qq, ll, uu, kind=kk)
     assert np.array_equal(r0["status"], rh["status"]) and np.array_equal(r0["active"], rh["active"])
     assert np.array_equal(r0["pivots"], rh["pivots"]) and np.max(np.abs(r0["z"] - rh["z"]) / scale) <= 1e-9
 

