@@ -77,7 +77,8 @@ def solve_base(qpn, x_init, level=1, proj_vectors=None, rng=None, engine=None):
             S.update(graphs)
             if not equilibrium:                                                      # :91-109
                 try:
-                    xnew = solve_qep(qpn, players, x, sub_assign, engine=engine)
+                    xnew = solve_qep(qpn, players, x, sub_assign, engine=engine,
+                                     settled={pid for pid, r in zip(players, results) if r["solution"]})
                 except AVISolveError:
                     return dict(solved=False, x_fail=x, x_opt=None)
                 if np.linalg.norm(xnew - x) < 1e-4:                                  # :96-99

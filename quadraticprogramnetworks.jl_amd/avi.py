@@ -235,7 +235,7 @@ def assemble_pool_batch(blocks, w, engine=None, form="reduced", qd=None, l=None,
 
 # ---- src/avi.jl:382-444 -------------------------------------------------------------------------
 def solve_qep(qp_net, player_pool, x, S: Optional[Dict[int, object]] = None, engine=None,
-              reference_form=False):
+              reference_form=False, settled=None):
     """The AVI step of a level at the current x; returns x_opt.  The reference forms ONE AVI for the whole pool
     (:399-400); that AVI is block diagonal over the connected components of the pool's coupling graph, so the components
     are solved as batches (level_batch.solve_level): single-node components as node records (create_labeled_gavi_from_qp
@@ -244,4 +244,4 @@ def solve_qep(qp_net, player_pool, x, S: Optional[Dict[int, object]] = None, eng
     share decision variables, else the reduced form).  The host mirrors combine_gavis / combine_gavis_reduced above remain
     as the checkers of that kernel (tests/test_gpu_pools.py)."""
     from .level_batch import solve_level
-    return solve_level(qp_net, list(player_pool), x, S or {}, engine=engine, reference_form=reference_form)
+    return solve_level(qp_net, list(player_pool), x, S or {}, engine=engine, reference_form=reference_form, settled=settled)

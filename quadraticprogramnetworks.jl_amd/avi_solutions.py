@@ -147,7 +147,7 @@ def solution_graph_pieces(Q, q, A, l, u, dec_inds, x, lam, engine=None, tol=1e-2
         Ag = np.zeros((Al.shape[0], len(x)))
         Ag[:, dec] = Al[:, :n]; Ag[:, par] = Al[:, n:]
         Pg = _dedupe(Poly(Ag, ll, ul))
-        if Pg.contains(x, tol=1e-3):                       # (level_batch.MEMBER_TOL)
+        if Pg.contains(x, tol=1e-5):                       # (level_batch.MEMBER_TOL)
             out.append(Pg)
     return out
 

@@ -32,6 +32,7 @@ struct VerifyArgs {
     double *lambda;
     int32_t *path;
     double *sG, *sq, *slb, *sub, *sz;
+    int32_t gate;        // verify_stage1 only: != 0 -> take just the nodes whose path is -2 (left over by verify_node64)
 };
 
 template <int LDV>
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
     const int n = a.n, m = a.m, p = a.p;
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
+    if (a.gate && a.path[b] != -2) return;
     __shared__ double sA[LDV * (LDV - 1)];   // Ad, column-major, ld = LDV
     __shared__ double sGa[LDV * (LDV - 1)];  // Gram block of the active rows, then its Cholesky factor
     __shared__ double sqt[64];        // q~
@@ -250,8 +252,7 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
     __shared__ __attribute__((aligned(16))) double sM[32 * V32_LDA];
     __shared__ __attribute__((aligned(16))) double sx[32];       // x, then q~: [parity][16]
     __shared__ __attribute__((aligned(16))) double sv[32];       // broadcast vector (rhs, y)
-    __shared__ int srow[32];
-    __shared__ double ssg[32];
+    __shared__ double sd[32];          // 1 / |row| of the active rows, by column
 
     const double *Q_ = a.Qd + (size_t)b * n * n;
     const double *A_ = a.Ad + (size_t)b * m * n;
@@ -336,12 +337,23 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
     else if (cls == 2) mycol = np + __popc(bn & below);
     else if (cls == 3) mycol = np + nn + __popc(bb & below);
     const double mysgr = (cls == 2) ? -1.0 : 1.0;             // sign of row r5 as a column of A_bar
-    // ---- A_bar' (signed active rows, compacted) and q~ to LDS
+    // The active rows enter the least-squares problem EQUILIBRATED: row r scaled to unit length, y'_c = |row| y_c.  A solution
+    // graph's rows are normalised to a leading coefficient of 1 (src/sets.jl:76-89), so a piece row with a small leading entry is
+    // 1e7 times longer than its neighbours; unscaled, the Gram block's diagonal spans 1e14 and the factorisation's rank test
+    // (relative to the LARGEST diagonal) drops every ordinary column.  Signs, ranks and the residual A_bar y - q~ do not depend on
+    // the scaling; y itself is scaled back for the sign test's tolerance and for lambda.
+    double rn0 = 0.0, rn1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) { rn0 = fma(va[t], va[t], rn0); rn1 = fma(va[t + 1], va[t + 1], rn1); }
+    const double rn2 = vsum_halves(rn0 + rn1);
+    const double dinv = rn2 > 0.0 ? 1.0 / sqrt(rn2) : 0.0;
+    const double rsc = mysgr * dinv;
+    // ---- A_bar' (signed, scaled active rows, compacted) and q~ to LDS
     vwave_sync();                                             // (the x reads are done)
     if (mycol >= 0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = mysgr * va[t];
-        if (ch == 0) { srow[mycol] = r5; ssg[mycol] = mysgr; }
+        for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = rsc * va[t];
+        if (ch == 0) sd[mycol] = dinv;
     }
     if (l < 32) sx[(l & 1) * 16 + (l >> 1)] = (FULL || l < n) ? qt : 0.0;
     vwave_sync();
@@ -356,9 +368,10 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
         }
     }
     const double aq = vsum_halves(g0 + g1);                   // (Ad q~)_r5
-    if (mycol >= 0 && ch == 0) sv[mycol] = mysgr * aq;
+    if (mycol >= 0 && ch == 0) sv[mycol] = rsc * aq;
     vwave_sync();
     const double rhs = (l < k) ? sv[l] : 0.0;                 // A_bar' q~ by column (lane c < k <-> column c)
+    const double dcol = (l < k) ? sd[l] : 0.0;                // this column's scale
     const int lc = l & 15, lq = l >> 4;
     const bool two = k > 16;                                  // (wave-uniform)
     const bool mine = l < k;
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
     auto stage_active_rows = [&]() {
         if (mycol >= 0) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = mysgr * va[t];
+            for (int t = 0; t < 16; ++t) sM[mycol * V32_LDA + 2 * t + ch] = rsc * va[t];
         }
     };
     // r = A_bar y - q~ by lane t < n (y handed over through sv), on the staged active rows; returns this lane's entry
@@ -485,14 +498,14 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
     double y; bool piv;
     lsq_on(mine, y, piv);
     // :119  sign test; then the residual A_bar y - q~ on the re-staged active rows
-    const bool badsign = l < np + nn && !(y > -a.tol);
+    const bool badsign = l < np + nn && !(y * dcol > -a.tol);
     stage_active_rows();
     double rt = residual_entry(y);
     {
         const double res = wave_sum32_f64(rt * rt);
         const bool ok = !qpn_ballot(badsign) && sqrt(res) <= a.tol;
         if (ok) {
-            if (l < m) lam[l] = (mycol >= 0) ? mysgr * sv[mycol] : 0.0;    // :120-123
+            if (l < m) lam[l] = (mycol >= 0) ? rsc * sv[mycol] : 0.0;      // :120-123 (scaled back)
             if (l == 0) { a.solution[b] = 1; a.path[b] = 2; }
             return;
         }
@@ -576,7 +589,327 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
         const bool ok = sqrt(res) <= 1e-4;
         if (l < k) sv[l] = ycur;
         vwave_sync();
-        if (l < m) lam[l] = (mycol >= 0) ? mysgr * sv[mycol] : 0.0;
+        if (l < m) lam[l] = (mycol >= 0) ? rsc * sv[mycol] : 0.0;
+        if (l == 0) { a.solution[b] = ok ? 1 : 0; a.path[b] = ok ? 3 : 4; }
+    }
+}
+
+// ---- verify_node64: the same design for n, m <= 64 (one of them > 32), one wavefront per node, lane r <-> row r ------------
+// Qd and Ad stream through registers in panels of 16 columns (whole 512-byte columns, coalesced): pass 1 forms q~ and ax, pass 2
+// (Ad again: L2 / Infinity Cache) stages the signed active rows in LDS and forms Ad q~.  Up to 32 active rows (nodes with more are
+// flagged -2 and taken by verify_stage1<65> in a gated launch behind this one): the Gram block is 16 or 48 MFMAs over 16
+// k-steps, the factor and the bounded least-squares fallback are verify_node32's.  The active rows keep their own LDS region
+// (16.9 KB) next to the Gram block / factor (8.4 KB): 26.6 KB per wavefront, six wavefronts per CU.
+constexpr int V64_LDA = 66;      // active rows: entry (row c, column t) at c * 66 + t (operand reads conflict-free)
+
+__global__ __launch_bounds__(WAVE, 2) void verify_node64(VerifyArgs a)
+{
+    const int n = a.n, m = a.m, p = a.p;
+    const int l = threadIdx.x;
+    const int b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) double sM[32 * V64_LDA];
+    __shared__ __attribute__((aligned(16))) double sG[32 * V32_LDG];
+    __shared__ __attribute__((aligned(16))) double sx[64];       // x, then q~, then the residual
+    __shared__ __attribute__((aligned(16))) double sv[32];
+    __shared__ double sd[32];          // 1 / |row| of the active rows, by column (see verify_node32: the rows are equilibrated)
+
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *B_ = a.B + (size_t)b * m * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double *lam = a.lambda + (size_t)b * m;
+    const bool isx = l < n, isrow = l < m;
+    const int nch = (n + 15) >> 4;
+
+    sx[l] = isx ? a.xd[(size_t)b * n + l] : 0.0;
+    double qt = isx ? a.qd[(size_t)b * n + l] : 0.0;
+    double ax = 0.0, lr = 0.0, ur = 0.0;
+    if (isrow) { lr = a.l[(size_t)b * m + l]; ur = a.u[(size_t)b * m + l]; }
+    for (int k0 = 0; k0 < p; k0 += 4) {
+        double rv[4], bv[4], wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = k0 + k;
+            const bool ok = kk < p;
+            wv[k] = ok ? w_[kk] : 0.0;
+            rv[k] = (ok && isx) ? R_[(size_t)kk * n + l] : 0.0;
+            bv[k] = (ok && isrow) ? B_[(size_t)kk * m + l] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qt = fma(rv[k], wv[k], qt); ax = fma(bv[k], wv[k], ax); }
+    }
+    vwave_sync();
+    // ---- pass 1: q~ (:58-60) and ax (:84), 16 columns of Qd and of Ad in flight per panel
+    {
+        double q1 = 0.0, a1 = 0.0;
+        for (int c = 0; c < nch; ++c) {
+            double vq[16], va[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int cj = 16 * c + t;
+                vq[t] = (cj < n && isx) ? Q_[(size_t)cj * n + l] : 0.0;
+                va[t] = (cj < n && isrow) ? A_[(size_t)cj * m + l] : 0.0;
+            }
+            const vd2 *xh = reinterpret_cast<const vd2 *>(sx + 16 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const vd2 xx = xh[j];
+                qt = fma(vq[2 * j], xx[0], qt); q1 = fma(vq[2 * j + 1], xx[1], q1);
+                ax = fma(va[2 * j], xx[0], ax); a1 = fma(va[2 * j + 1], xx[1], a1);
+            }
+        }
+        qt += q1; ax += a1;
+    }
+    // :86  feasibility, tol 1e-3
+    const bool infeas = isrow && !(lr - 1e-3 <= ax && ax - 1e-3 <= ur);
+    if (qpn_ballot(infeas)) {
+        if (isrow) lam[l] = 0.0;
+        if (l == 0) { a.solution[b] = 0; a.path[b] = 0; }
+        return;
+    }
+    // :98-103  active-row classes
+    const bool pos0 = isrow && ax < lr + 1e-2, neg0 = isrow && ax > ur - 1e-2;
+    const int cls = (pos0 ? 1 : 0) | (neg0 ? 2 : 0);
+    const unsigned long long bp = qpn_ballot(cls == 1), bn = qpn_ballot(cls == 2), bb = qpn_ballot(cls == 3);
+    const int np = __popcll(bp), nn = __popcll(bn), nb = __popcll(bb);
+    const int k = np + nn + nb;
+    if (k > 32) {                                             // more active rows than this kernel's Gram block holds
+        if (l == 0) { a.solution[b] = 0; a.path[b] = -2; }
+        return;
+    }
+    const unsigned long long below = (1ull << l) - 1ull;
+    int mycol = -1;
+    if (cls == 1) mycol = __popcll(bp & below);
+    else if (cls == 2) mycol = np + __popcll(bn & below);
+    else if (cls == 3) mycol = np + nn + __popcll(bb & below);
+    const double mysgr = (cls == 2) ? -1.0 : 1.0;
+    vwave_sync();                                             // (the x reads are done)
+    sx[l] = isx ? qt : 0.0;
+    vwave_sync();
+    // ---- pass 2: row lengths and (Ad q~)_r first, then (Ad again) the signed, equilibrated active rows to LDS
+    double aq = 0.0, rn2 = 0.0;
+    {
+        double g1 = 0.0, r1 = 0.0;
+        for (int c = 0; c < nch; ++c) {
+            double va[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int cj = 16 * c + t;
+                va[t] = (cj < n && isrow) ? A_[(size_t)cj * m + l] : 0.0;
+            }
+            const vd2 *qh = reinterpret_cast<const vd2 *>(sx + 16 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const vd2 qq = qh[j];
+                aq = fma(va[2 * j], qq[0], aq); g1 = fma(va[2 * j + 1], qq[1], g1);
+                rn2 = fma(va[2 * j], va[2 * j], rn2); r1 = fma(va[2 * j + 1], va[2 * j + 1], r1);
+            }
+        }
+        aq += g1; rn2 += r1;
+    }
+    const double dinv = rn2 > 0.0 ? 1.0 / sqrt(rn2) : 0.0;
+    const double rsc = mysgr * dinv;
+    if (qpn_ballot(mycol >= 0)) {
+        for (int c = 0; c < nch; ++c) {
+            double va[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int cj = 16 * c + t;
+                va[t] = (cj < n && mycol >= 0) ? A_[(size_t)cj * m + l] : 0.0;
+            }
+            if (mycol >= 0) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sM[mycol * V64_LDA + 16 * c + t] = rsc * va[t];
+            }
+        }
+    }
+    if (mycol >= 0) { sv[mycol] = rsc * aq; sd[mycol] = dinv; }
+    vwave_sync();
+    const double rhs = (l < k) ? sv[l] : 0.0;
+    const double dcol = (l < k) ? sd[l] : 0.0;
+    const int lc = l & 15, lq = l >> 4;
+    const bool two = k > 16;
+    const bool mine = l < k;
+    const int nks = (n + 3) >> 2;                             // k-steps of the Gram block (wave-uniform)
+
+    auto lsq_on = [&](bool inP, double &y_out, bool &pivoted) {
+        {
+            vd4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = {0.0, 0.0, 0.0, 0.0}, g11 = {0.0, 0.0, 0.0, 0.0};
+            for (int s0 = 0; s0 < nks; s0 += 4) {
+                double x0[4], x1[4];
+#pragma unroll
+                for (int u_ = 0; u_ < 4; ++u_) {
+                    const int t = 4 * (s0 + u_) + lq;
+                    const bool okt = s0 + u_ < nks && t < n;
+                    const double v0 = sM[lc * V64_LDA + (okt ? t : 0)];
+                    x0[u_] = (lc < k && okt) ? v0 : 0.0;
+                    const double v1 = two ? sM[(16 + lc) * V64_LDA + (okt ? t : 0)] : 0.0;
+                    x1[u_] = (two && 16 + lc < k && okt) ? v1 : 0.0;
+                }
+#pragma unroll
+                for (int u_ = 0; u_ < 4; ++u_) {
+                    g00 = VMFMA(x0[u_], x0[u_], g00);
+                    if (two) { g01 = VMFMA(x0[u_], x1[u_], g01); g11 = VMFMA(x1[u_], x1[u_], g11); }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = lq + 4 * g, j = lc;
+                if (i < k && j < k) sG[j * V32_LDG + i] = g00[g];
+                if (two) {
+                    const int j2 = 16 + lc;
+                    if (j2 < k) { sG[j2 * V32_LDG + i] = g01[g]; sG[i * V32_LDG + j2] = g01[g]; }
+                    if (16 + i < k && j2 < k) sG[j2 * V32_LDG + 16 + i] = g11[g];
+                }
+            }
+        }
+        vwave_sync();
+        bool done = !inP;
+        int mystep = -1;
+        double diag = inP ? sG[l * V32_LDG + l] : 0.0;
+        const double dscale = wave_max_f64(inP ? diag : 0.0);
+        const double dfloor = 1e-12 * (dscale > 1.0 ? dscale : 1.0);
+        int rank = 0;
+        int ordv = 0;
+        double bvec = inP ? rhs : 0.0, myinv = 0.0;
+        for (int s = 0; s < k; ++s) {
+            const double dmax = wave_max_f64(done ? -1.0 : diag);
+            if (!(dmax > dfloor)) break;
+            const int pv = wave_first(!done && diag == dmax);
+            const double lpp = sqrt(dmax), inv = 1.0 / lpp;
+            double acc = done ? 0.0 : sG[pv * V32_LDG + l];
+            for (int t0 = 0; t0 < s; t0 += 4) {
+                double av[4], bw[4];
+#pragma unroll
+                for (int u_ = 0; u_ < 4; ++u_) {
+                    const int t = t0 + u_;
+                    const int o = readlane_i32(ordv, t < s ? t : s - 1);
+                    av[u_] = sG[o * V32_LDG + (mine ? l : 0)];
+                    bw[u_] = (t < s) ? sG[o * V32_LDG + pv] : 0.0;
+                }
+#pragma unroll
+                for (int u_ = 0; u_ < 4; ++u_) acc = fma(-av[u_], bw[u_], acc);
+            }
+            const double lis = (l == pv) ? lpp : acc * inv;
+            if (!done) sG[pv * V32_LDG + l] = lis;
+            const double ws = readlane_f64(bvec, pv) * inv;
+            if (!done && l != pv) { diag = fma(-lis, lis, diag); bvec = fma(-lis, ws, bvec); }
+            if (l == pv) { done = true; mystep = s; bvec = ws; myinv = inv; }
+            if (l == s) ordv = pv;
+            rank++;
+            vwave_sync();
+        }
+        double y = 0.0;
+        for (int s = rank - 1; s >= 0; --s) {
+            const int pvs = readlane_i32(ordv, s);
+            const double ys = readlane_f64(bvec * myinv, pvs);
+            if (mystep >= 0 && mystep < s) bvec = fma(-sG[l * V32_LDG + pvs], ys, bvec);
+            if (l == pvs) y = ys;
+        }
+        y_out = y; pivoted = mystep >= 0;
+        vwave_sync();
+    };
+    // r = A_bar y - q~, lane t < n
+    auto residual_entry = [&](double y) -> double {
+        if (l < k) sv[l] = y;
+        vwave_sync();
+        double s0 = -qt;
+        const int tcol = isx ? l : 0;
+        for (int c0 = 0; c0 < k; c0 += 4) {
+            double av[4], yv[4];
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) {
+                const int c = c0 + u_;
+                av[u_] = sM[(c < k ? c : k - 1) * V64_LDA + tcol];
+                yv[u_] = (c < k) ? sv[c] : 0.0;
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) s0 = fma(av[u_], yv[u_], s0);
+        }
+        return isx ? s0 : 0.0;
+    };
+
+    double y; bool piv;
+    lsq_on(mine, y, piv);
+    const bool badsign = l < np + nn && !(y * dcol > -a.tol);
+    double rt = residual_entry(y);
+    {
+        const double res = wave_sum_f64(rt * rt);
+        const bool ok = !qpn_ballot(badsign) && sqrt(res) <= a.tol;
+        if (ok) {
+            if (isrow) lam[l] = (mycol >= 0) ? rsc * sv[mycol] : 0.0;
+            if (l == 0) { a.solution[b] = 1; a.path[b] = 2; }
+            return;
+        }
+    }
+    // ---- :129-137  bounded least squares inside the wavefront (verify_node32's iteration)
+    {
+        const bool cons = l < np + nn;
+        bool inP = mine && piv;
+        bool blocked = false;
+        double ycur = 0.0, sl = y;
+        int iters = 0;
+        const int cap = 3 * k + 12;
+        bool failed = false;
+        for (;;) {
+            for (;;) {
+                const bool bad = inP && cons && !(sl > 0.0);
+                if (!qpn_ballot(bad)) { ycur = inP ? sl : 0.0; break; }
+                const double ratio = bad ? ycur / (ycur - sl) : QINF;
+                const double alpha = wave_min_f64((bad && ratio == ratio) ? ratio : (bad ? 0.0 : QINF));
+                if (inP) ycur = fma(alpha, sl - ycur, ycur);
+                const bool leave = bad && (!(ratio == ratio) || ratio <= alpha);
+                if (leave) { inP = false; ycur = 0.0; }
+                if (++iters > cap) { failed = true; break; }
+                bool pv2;
+                lsq_on(inP, sl, pv2);
+                if (inP && !pv2) { inP = false; ycur = 0.0; }
+            }
+            if (failed) break;
+            rt = residual_entry(ycur);
+            vwave_sync();
+            sx[l] = rt;                                       // (q~ lives in registers by now)
+            vwave_sync();
+            double wgr = 0.0;
+            if (mine) {
+                const vd2 *rowc = reinterpret_cast<const vd2 *>(sM + l * V64_LDA);
+                const vd2 *rr = reinterpret_cast<const vd2 *>(sx);
+                double w0 = 0.0, w1 = 0.0;
+                for (int t2 = 0; t2 < (n + 1) / 2; ++t2) {
+                    const vd2 aa = rowc[t2], r2 = rr[t2];
+                    w0 = fma(aa[0], r2[0], w0);
+                    if (2 * t2 + 1 < n) w1 = fma(aa[1], r2[1], w1);
+                }
+                wgr = -(w0 + w1);
+            }
+            const double gscale = wave_max_f64(mine ? fabs(rhs) : 0.0);
+            const bool cand = mine && cons && !inP && !blocked && wgr > 1e-11 * (gscale > 1.0 ? gscale : 1.0);
+            if (!qpn_ballot(cand)) break;
+            const double wmax = wave_max_f64(cand ? wgr : -1.0);
+            const int enter = wave_first(cand && wgr == wmax);
+            if (l == enter) inP = true;
+            if (++iters > cap) { failed = true; break; }
+            bool pv2;
+            lsq_on(inP, sl, pv2);
+            if (inP && !pv2) { inP = false; if (l == enter) blocked = true; }
+            const double s_enter = readlane_f64(sl, enter);
+            if (!(s_enter > 0.0)) {
+                if (l == enter) { inP = false; blocked = true; }
+                lsq_on(inP, sl, pv2);
+                if (inP && !pv2) inP = false;
+            }
+        }
+        if (failed) {
+            if (isrow) lam[l] = 0.0;
+            if (l == 0) { a.solution[b] = 0; a.path[b] = 5; }
+            return;
+        }
+        const double res = wave_sum_f64(rt * rt);
+        const bool ok = sqrt(res) <= 1e-4;
+        if (l < k) sv[l] = ycur;
+        vwave_sync();
+        if (isrow) lam[l] = (mycol >= 0) ? rsc * sv[mycol] : 0.0;
         if (l == 0) { a.solution[b] = ok ? 1 : 0; a.path[b] = ok ? 3 : 4; }
     }
 }
@@ -880,6 +1213,11 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
         if (n == 32 && m == 32) hipLaunchKernelGGL(verify_node32<true>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
         else hipLaunchKernelGGL(verify_node32<false>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
         return hipGetLastError();
+    }
+    // 33 .. 64: verify_node64 (up to 32 active rows: the usual case), then the older kernels over what it flagged -2
+    if (m >= 1) {
+        hipLaunchKernelGGL(verify_node64, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
+        a.gate = 1;
     }
     hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     hipError_t e = hipGetLastError();

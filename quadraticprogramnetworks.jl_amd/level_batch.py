@@ -32,14 +32,17 @@ import numpy as np
 from .programs import Poly
 
 INF = np.inf
-# A local piece enters a node's solution graph only when it contains the current point within verify_solution's own feasibility
-# tolerance (src/qp_processing.jl:86).  comp_indices classifies with 1e-2 (src/avi_solutions.jl:511), so a row up to 1e-2 away
+# A local piece enters a node's solution graph only when it contains the current point -- within MEMBER_TOL, tighter than
+# verify_solution's accept band (1e-4, src/qp_processing.jl:57, :119) and far tighter than its feasibility tolerance (1e-3, :86).  comp_indices classifies with 1e-2 (src/avi_solutions.jl:511), so a row up to 1e-2 away
 # from its bound still spawns the recipe "at the bound"; the reference keeps every such piece that is non-empty
 # (src/avi_solutions.jl:247-249).  A piece the point misses by more than 1e-3 fails the PARENT's verify by construction (:86-89:
 # infeasible), the parent's solve_qep then moves onto it, the next sweep finds the mirror image, and the loop ends in the
 # reference's own "Cycling detected" (observed: one pair in 60 at n = m = 16).  Such pieces say nothing about optimality AT the
-# point, so they are left out.
-MEMBER_TOL = 1e-3
+# point, so they are left out.  The tolerance has to sit BELOW the accept band: two neighbouring pieces' exact minimisers can lie
+# 1e-4 apart (the parent optimal under B a hair inside B, and within 1e-3 of A's boundary): with a membership test as loose as
+# verify's feasibility test each of the two points counts as a member of the other piece without being optimal there, and the
+# parent is sent back and forth by 1e-4 for ever (observed: one pair in ~1 000 at n = m = 16).
+MEMBER_TOL = 1e-5
 CODE_TOL = 1e-4          # _refine_row_codes: a row keeps a code whose own condition the point meets within verify's tolerance (:57)
 ROW_PAD = 16            # constraint rows of a record batch are padded with inert rows to a multiple of this (one MFMA tile)
 
@@ -233,9 +236,18 @@ def _leaf_batches(qpn, players, engine):
     return got
 
 
-def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]] = None, engine=None, reference_form=False):
+def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]] = None, engine=None, reference_form=False,
+                settled: Optional[set] = None):
     """solve_qep (src/avi.jl:382-444) for a whole level: x_opt with every component's decision block replaced by the
-    solution of its AVI.  Raises avi.AVISolveError when any component's solve does not end in SUCCESS (:426)."""
+    solution of its AVI.  Raises avi.AVISolveError when any component's solve does not end in SUCCESS (:426).
+
+    `settled` (ids of players verify_solution has just accepted): a component ALL of whose players are settled is left where it
+    is.  The reference re-solves it with the rest of the level, under its children's FIRST pieces (src/algorithm.jl:54, :95); the
+    point passes verify_solution under every piece combination, so that solve returns it again -- up to the 1e-4 band of the
+    accept tests, inside which two pieces' exact minimisers can differ: re-solved sweep after sweep while OTHER components are
+    still moving, such a component jumps between them and the level ends in "Cycling detected", although the component on its
+    own (or the net sharded by cluster, sharding.solve_sharded) is done.  With the split into components the engine knows
+    which blocks of the level's AVI are already at rest."""
     from .avi import AVISolveError, StatusCode, _eng
     from .engine import colmajor
     eng = _eng(engine)
@@ -243,6 +255,8 @@ def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]
     x = np.asarray(x, dtype=np.float64)
     x_opt = x.copy()
     comps = components(qpn, players, assign)
+    if settled:
+        comps = [c for c in comps if not all(i in settled for i in c)]
     singles = [c[0] for c in comps if len(c) == 1]
     multis = [c for c in comps if len(c) > 1]
     bad = []

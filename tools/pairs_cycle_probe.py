@@ -15,8 +15,10 @@ hist = []
 orig = alg.solve_qep
 
 
-def sq(qpn, players, x, S, engine=None):
-    xn = orig(qpn, players, x, S, engine=engine)
+def sq(qpn, players, x, S, engine=None, **kw):
+    xn = orig(qpn, players, x, S, engine=engine, **kw)
+    uns = [i for i in players if i not in (kw.get('settled') or set())]
+    print('solve_qep: players', len(players), 'unsettled', len(uns), uns[:8], '|dx| %.3e' % np.linalg.norm(xn - x), flush=True)
     hist.append((len(players), xn.copy()))
     return xn
 

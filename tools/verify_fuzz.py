@@ -23,6 +23,11 @@ for t in range(trials):
         A = A[:, :0, :]; B = B[:, :0, :]; l = l[:, :0]; u = u[:, :0]
     kind = rng.integers(0, 5, size=l.shape)
     l = np.where(kind == 1, -np.inf, l); u = np.where(kind == 2, np.inf, u)
+    if m and rng.integers(0, 3) == 0:
+        # badly scaled rows: a solution graph's rows are normalised to a leading coefficient of 1 (src/sets.jl:76-89), which can
+        # leave a row 1e7 times longer than its neighbours
+        sc = 10.0 ** rng.uniform(-2, 7, size=(cnt, A.shape[1], 1)) * (rng.random((cnt, A.shape[1], 1)) < 0.3) + 1.0
+        A = A * sc; B = B * sc; l = l * sc[:, :, 0]; u = u * sc[:, :, 0]
     w = rng.standard_normal(p)
     M, q, lo, hi, kd = P.reduced_blocks(Q, Rm, qd, A, B, l, u, w)
     z = binding.solve_avi_batch(M, q, lo, hi, kind=kd)["z"]
