@@ -255,6 +255,47 @@ function local_pieces(Qd::Matrix{Float64}, R::Matrix{Float64}, qd::Vector{Float6
 end
 
 """
+    recipes_batch(masks, counts) -> (K, node_of)
+
+`all_Ks` (src/avi_solutions.jl:200-215) for MANY solutions in one launch (`qpn_recipes_batch`): `masks` is N x nodes (the `active`
+output of a solve, one column per node), `counts[b]` the number of recipes wanted of node b (at most the product of its rows'
+code counts).  Returns the recipes K (N x total, one column per recipe) and the 0-based node of each.
+"""
+function recipes_batch(masks::Matrix{UInt8}, counts::Vector{<:Integer})
+    N, nodes = size(masks)
+    offsets = Int64[0; cumsum(Int64.(counts))]
+    total = Int(offsets[end])
+    K = zeros(UInt8, N, total); node_of = zeros(Int32, total)
+    rc = ccall((:qpn_recipes_batch, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}, Ptr{Int64}, Ptr{UInt8}, Ptr{Int32}, Cint),
+               ctx(), Int32(nodes), Int32(N), masks, offsets, K, node_of, QPN_MEM_HOST)
+    rc == 0 || error("qpn_recipes_batch failed ($rc)")
+    (K, node_of)
+end
+
+"""
+    reduced_pieces(Qd, R, qd, Ad, B, l, u, K, node_of; tol = 1e-9) -> (Ar, lr, ur, rows, flags)
+
+`local_piece` (src/avi_solutions.jl:400-496) for the recipes K (one column each) over the node records (third index = node, as
+`solve_nodes!` takes them), with the m multiplier columns eliminated through each piece's own equality rows (`qpn_reduced_pieces`):
+piece t lives on the records of node `node_of[t]` (0-based).  `Ar[:, :, t]` is the cap x (n + p) row matrix over `[x_d; x_p]`
+(cap = n + 2m), of which the first `rows[t]` rows are live; `flags[t] != 0`: a multiplier was pinned by no equality row -- that
+piece needs the polyhedral projection (src/avi_solutions.jl:79-91) on the host.
+"""
+function reduced_pieces(Qd::Array{Float64,3}, R::Array{Float64,3}, qd::Matrix{Float64}, Ad::Array{Float64,3}, B::Array{Float64,3},
+                        l::Matrix{Float64}, u::Matrix{Float64}, K::Matrix{UInt8}, node_of::Vector{Int32}; tol::Float64 = 1e-9)
+    n, nodes = size(qd); m = size(l, 1); p = size(R, 2); pieces = size(K, 2); cap = n + 2m
+    Ar = zeros(cap, n + p, pieces); lr = zeros(cap, pieces); ur = zeros(cap, pieces)
+    rows = zeros(Int32, pieces); flags = zeros(Int32, pieces)
+    rc = ccall((:qpn_reduced_pieces, LIB), Cint,
+               (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                Ptr{Cdouble}, Ptr{Int32}, Ptr{UInt8}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Cint),
+               ctx(), Int32(pieces), Int32(nodes), Int32(n), Int32(m), Int32(p), Qd, R, qd, Ad, B, l, u, node_of, K, tol, Ar, lr, ur, rows, flags,
+               QPN_MEM_HOST)
+    rc == 0 || error("qpn_reduced_pieces failed ($rc)")
+    (Ar, lr, ur, rows, flags)
+end
+
+"""
     order_nodes_by_pivots!(pivots)
 
 Schedule hint for later `solve_nodes!` calls over the same nodes (longest solves first); `pivots` is the
@@ -269,9 +310,8 @@ end
 set_auto_schedule!(period::Integer) = (ccall((:qpn_ctx_set_auto_schedule, LIB), Cint, (Ptr{Cvoid}, Int32), ctx(), Int32(period)); nothing)
 clear_node_order!() = (ccall((:qpn_set_node_order, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int32, Cint), ctx(), C_NULL, Int32(0), QPN_MEM_HOST); nothing)
 # kernel routes with identical contracts (A/B measurements; include/qpn_hip.h, QPN_OPT_*): MID_ROUTE 1 = fused workgroup kernel per
-# node of 33 .. 128 variables or constraints (default; one wavefront per node up to 48), 3 = the workgroup kernel also below 49,
-# 2 / 0 = the routes it replaced; BIG_ROUTE 1 = blocked crash straight from
-# the records for nodes up to 256 x 256 (default), 0 = over an assembled M
+# node of 33 .. 128 variables or constraints (default; one wavefront per node up to 48), 0 = the general route (the cross-check);
+# BIG_ROUTE takes 1 only (blocked crash straight from the records for nodes up to 256 x 256)
 # SYM_ROUTE 1 = resident records whose Qd blocks are all bitwise symmetric take the kernel variants that use it (default), 0 = never.
 const QPN_OPT_MID_ROUTE = Int32(1)
 const QPN_OPT_BIG_ROUTE = Int32(2)
