@@ -600,10 +600,16 @@ static void lsq_qrcp(int n, int k, double *C, double *b, double *y)
 {
     int *perm = (int *)malloc(sizeof(int) * (size_t)(k > 0 ? k : 1));
     double *cn = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+    double *dsc = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+    /* the columns are brought to unit length first (y is scaled back at the end): the pivot order and the rank decision
+     * then do not depend on how a constraint row happens to be scaled -- one row of length 1e7 among rows of length 1
+     * must not push the others under the rank threshold.  (The device kernels do the same on their Gram block.) */
     for (int j = 0; j < k; ++j) {
         perm[j] = j;
         double s = 0; for (int i = 0; i < n; ++i) s += C[(size_t)j * n + i] * C[(size_t)j * n + i];
-        cn[j] = s;
+        dsc[j] = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+        for (int i = 0; i < n; ++i) C[(size_t)j * n + i] *= dsc[j];
+        cn[j] = s > 0.0 ? 1.0 : 0.0;
     }
     int rank = 0; int steps = n < k ? n : k;
     double scale = 0; for (int j = 0; j < k; ++j) if (cn[j] > scale) scale = cn[j];
@@ -614,6 +620,12 @@ static void lsq_qrcp(int n, int k, double *C, double *b, double *y)
             cn[j] = t; if (t > best) { best = t; jm = j; }
         }
         if (best <= 1e-24 * (scale > 1 ? scale : 1)) break;
+        /* norms within 2^-30 of the largest count as equal and the lowest column wins: after the equilibration every column
+         * starts at length 1 up to rounding, and that rounding must not choose the pivot (it decides which multipliers of a
+         * rank-deficient block are 0).  The device kernels apply the same rule (PIV_BAND in qpn_verify.hip). */
+        jm = -1;                                     /* (lowest ORIGINAL column: perm[], positions move with the swaps) */
+        for (int j = s; j < k; ++j) if (cn[j] >= best * (1.0 - 0x1p-30) && (jm < 0 || perm[j] < perm[jm])) jm = j;
+        best = cn[jm];
         if (jm != s) {
             for (int i = 0; i < n; ++i) { double t = C[(size_t)s * n + i]; C[(size_t)s * n + i] = C[(size_t)jm * n + i]; C[(size_t)jm * n + i] = t; }
             int t = perm[s]; perm[s] = perm[jm]; perm[jm] = t;
@@ -643,8 +655,8 @@ static void lsq_qrcp(int n, int k, double *C, double *b, double *y)
         for (int j = s + 1; j < rank; ++j) t -= C[(size_t)j * n + s] * yy[j];
         yy[s] = t / C[(size_t)s * n + s];
     }
-    for (int j = 0; j < k; ++j) y[perm[j]] = j < rank ? yy[j] : 0.0;
-    free(yy); free(perm); free(cn);
+    for (int j = 0; j < k; ++j) y[perm[j]] = j < rank ? yy[j] * dsc[perm[j]] : 0.0;
+    free(yy); free(perm); free(cn); free(dsc);
 }
 
 int qpo_verify_solution(int n, int m, int p, const double *Qd, const double *R, const double *qd,

@@ -1454,7 +1454,9 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     hipStream_t s = ctx->stream;
     const size_t mm = (size_t)(m > 0 ? m : 1);
     // scratch of the bounded-LSQ fallback (src/qp_processing.jl:129-137): Gram block + vectors
-    double *sG, *sq, *slb, *sub, *sz, *sres; int32_t *sst;
+    double *sG, *sq, *slb, *sub, *sz, *sres, *gws = nullptr; int32_t *sst;
+    const bool wide = n > 64 || m > 64;
+    const size_t mp16 = (size_t)((m + 15) & ~15);
     if (mem == QPN_MEM_DEVICE) {
         Carver cv(ctx);
         cv.add((void **)&sG, (size_t)batch * mm * mm * 8); cv.add((void **)&sq, (size_t)batch * mm * 8);
@@ -1462,10 +1464,11 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
         cv.add((void **)&sz, (size_t)batch * mm * 8); cv.add((void **)&sres, (size_t)batch * 8);
         cv.add((void **)&sst, (size_t)batch * 4);
         if (wide_avi) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, m));
+        if (wide && m > 0) cv.add((void **)&gws, (size_t)batch * 2 * mp16 * mp16 * 8);
         int rc = cv.commit();
         if (rc != QPN_OK) return rc;
         HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, Qd, R, qd, Ad, B, l, u, xd, w, stride_w, tol,
-                                            solution, lambda, path, sG, sq, slb, sub, sz, sres, sst, s, wbig));
+                                            solution, lambda, path, sG, sq, slb, sub, sz, sres, sst, s, wbig, gws));
         return QPN_OK;
     }
     if (mem != QPN_MEM_HOST) return fail_arg(ctx, "qpn_verify_nodes: bad mem kind");
@@ -1487,6 +1490,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     cv.add((void **)&sz, (size_t)batch * mm * 8); cv.add((void **)&sres, (size_t)batch * 8);
     cv.add((void **)&sst, (size_t)batch * 4);
     if (wide_avi) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, m));
+    if (wide && m > 0) cv.add((void **)&gws, (size_t)batch * 2 * mp16 * mp16 * 8);
     int rc = cv.commit();
     if (rc != QPN_OK) return rc;
     if (!records_on_device) {
@@ -1504,7 +1508,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     HIPCHK(ctx, hipMemcpyAsync(dx, xd, sz_.q, hipMemcpyHostToDevice, s));
     if (p > 0) HIPCHK(ctx, hipMemcpyAsync(dw, w, sz_.w, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, dQ, dR, dq, dA, dB, dl, du, dx, dw, stride_w, tol,
-                                        dsol, dlam, dpath, sG, sq, slb, sub, sz, sres, sst, s, wbig));
+                                        dsol, dlam, dpath, sG, sq, slb, sub, sz, sres, sst, s, wbig, gws));
     HIPCHK(ctx, hipMemcpyAsync(solution, dsol, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(path, dpath, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
     if (sz_.lu) HIPCHK(ctx, hipMemcpyAsync(lambda, dlam, sz_.lu, hipMemcpyDeviceToHost, s));

@@ -194,7 +194,8 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
                                    int64_t stride_w, double tol, int32_t *solution, double *lambda,
                                    int32_t *path, double *sG, double *sq, double *slb, double *sub,
                                    double *sz, double *sres, int32_t *sst, hipStream_t stream,
-                                   double *wbig = nullptr);      // wbig: large-item AVI workspace (m > 64 only)
+                                   double *wbig = nullptr,       // wbig: large-item AVI workspace (m > 64 only)
+                                   double *gws = nullptr);       // gws: [batch][2][pad16(m)^2] Gram block / factor of verify_wide_node (n or m > 64)
 int qpn_verify_max_dim();
 
 // ---- wave64 helpers (CDNA4: one wavefront = 64 lanes) --------------------------------

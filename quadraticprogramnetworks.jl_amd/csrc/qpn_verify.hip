@@ -14,6 +14,7 @@
 //   avi_solve_lds1  (qpn_avi_solve.hip) gated on path == -1.
 //   verify_stage2   accepts iff || Ad' lambda - q~ ||_2 <= 1e-4 (:138).
 #include "qpn_internal.h"
+#include <type_traits>
 
 #define QINF __builtin_huge_val()
 
@@ -34,6 +35,12 @@ struct VerifyArgs {
     double *sG, *sq, *slb, *sub, *sz;
     int32_t gate;        // verify_stage1 only: != 0 -> take just the nodes whose path is -2 (left over by verify_node64)
 };
+
+// Pivot choice of every factorisation below: the largest remaining diagonal, where diagonals within 2^-30 of the largest count as
+// equal and the lowest column wins.  With equilibrated rows every diagonal starts at 1 up to rounding; an exact `==` would let
+// that rounding pick the pivot, and the basic solution of a rank-deficient block (which multipliers are 0) would depend on it.
+// (The CPU restatement used by the tests applies the same rule.)
+constexpr double PIV_BAND = 1.0 - 0x1p-30;
 
 template <int LDV>
 __global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
@@ -131,9 +138,10 @@ __global__ __launch_bounds__(WAVE) void verify_stage1(VerifyArgs a)
     int rank = 0;
     double bvec = rhs;             // running right-hand side of the forward substitution
     for (int s = 0; s < k; ++s) {
-        const double dmax = wave_max_f64(done ? -1.0 : diag);
-        if (!(dmax > 1e-12 * (dscale > 1.0 ? dscale : 1.0))) break;
-        const int pv = wave_first(!done && diag == dmax);
+        const double dtop = wave_max_f64(done ? -1.0 : diag);
+        if (!(dtop > 1e-12 * (dscale > 1.0 ? dscale : 1.0))) break;
+        const int pv = wave_first(!done && diag >= dtop * PIV_BAND);
+        const double dmax = __shfl(diag, pv, WAVE);
         const double lpp = sqrt(dmax);
         // factor column: L(i,s) = G(i,pv)/lpp for the remaining i; L(pv,s) = lpp
         double lis = 0.0;
@@ -430,9 +438,10 @@ __global__ __launch_bounds__(WAVE, 4) void verify_node32(VerifyArgs a)
         int ordv = 0;                                         // lane s holds the pivot column of step s
         double bvec = inP ? rhs : 0.0, myinv = 0.0;
         for (int s = 0; s < k; ++s) {
-            const double dmax = wave_max_f64(done ? -1.0 : diag);
-            if (!(dmax > dfloor)) break;
-            const int pv = wave_first(!done && diag == dmax);
+            const double dtop = wave_max_f64(done ? -1.0 : diag);
+            if (!(dtop > dfloor)) break;
+            const int pv = wave_first(!done && diag >= dtop * PIV_BAND);
+            const double dmax = __shfl(diag, pv, WAVE);
             const double lpp = sqrt(dmax), inv = 1.0 / lpp;
             double acc = done ? 0.0 : sM[pv * V32_LDG + l];   // G(i, pv)
             for (int t0 = 0; t0 < s; t0 += 4) {
@@ -774,9 +783,10 @@ __global__ __launch_bounds__(WAVE, 2) void verify_node64(VerifyArgs a)
         int ordv = 0;
         double bvec = inP ? rhs : 0.0, myinv = 0.0;
         for (int s = 0; s < k; ++s) {
-            const double dmax = wave_max_f64(done ? -1.0 : diag);
-            if (!(dmax > dfloor)) break;
-            const int pv = wave_first(!done && diag == dmax);
+            const double dtop = wave_max_f64(done ? -1.0 : diag);
+            if (!(dtop > dfloor)) break;
+            const int pv = wave_first(!done && diag >= dtop * PIV_BAND);
+            const double dmax = __shfl(diag, pv, WAVE);
             const double lpp = sqrt(dmax), inv = 1.0 / lpp;
             double acc = done ? 0.0 : sG[pv * V32_LDG + l];
             for (int t0 = 0; t0 < s; t0 += 4) {
@@ -974,11 +984,468 @@ __device__ __forceinline__ double block_max_f64(double v, double *red)
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// ---- verify_wide_node (round 4): n or m beyond 64 (up to 512), up to 128 active rows -- BASELINE config 5's nodes ----------------
+// One workgroup of 256 threads per node.  Round 1's wide kernel (below: still the route of nodes with more than 128 active rows,
+// gated) formed the Gram block entry by entry from global memory (two strided columns per entry) and factored it right-looking
+// in global memory: 4.6 ms per 512 nodes of 256 x 256, 20 ms when every node takes the bounded least-squares fallback (a box-AVI of
+// size m on the large-item kernel).  Here:
+//   pass 1   q~ = Qd x + R w + qd and ax = Ad x + B w: thread <-> row (two rows per thread beyond 256), whole columns coalesced, four
+//            accumulators per row; feasibility, classes, the compacted column order [pos | neg | both];
+//   pass 2   Ad again (L2 / Infinity Cache), in panels of 16 (m <= 256) or 8 columns through LDS, double-buffered: the Gram block
+//            of the active rows on the matrix cores -- wave v owns the tiles e = v (mod 4) of the upper triangle, at most nine,
+//            in registers across the panels; an operand lane (lc, lq) reads panel column 4 s + lq at row srow[16 I + lc] -- and the
+//            right-hand side A_bar' q~ by column from the same panels;
+//   scaling  the rows are equilibrated through the Gram block's own diagonal (verify_node32), G goes to the node's workspace;
+//   factor   diagonally pivoted Cholesky, left-looking, thread <-> row, L in a second workspace block so that G survives for the
+//            fallback's re-solves; column-oriented back substitution;
+//   tests    signs, residual A_bar y - q~ (thread <-> entry, the active rows' entries read from the records), lambda;
+//   fallback verify_node32's active-set iteration, a block at a time: re-solves re-factor G's principal submatrix (no Gram pass).
+constexpr int VW_KMAX = 128;
+__device__ __forceinline__ int vw_ld(int m) { return m | 1; }
+
+__global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void verify_wide_node(VerifyArgs a, double *gws, int wp, int dyn_doubles)
+{
+    const int n = a.n, m = a.m, p = a.p;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
+    __shared__ double sx[WMAX];                  // x, then q~, then the residual
+    __shared__ double sdv[VW_KMAX], ssgv[VW_KMAX], sco[VW_KMAX];
+    __shared__ int srow[VW_KMAX], sord[VW_KMAX];
+    __shared__ unsigned char scls[WMAX];
+    __shared__ double red[4];
+    __shared__ int s_flag, s_k, s_np, s_nn, s_pv;
+    __shared__ int s_cnt[3][8];
+    __shared__ double s_bc[3];
+    extern __shared__ __attribute__((aligned(16))) double dynp[];         // two panels [wp][ldp]
+    const int ldp = vw_ld(m);
+
+    const double *Q_ = a.Qd + (size_t)b * n * n;
+    const double *A_ = a.Ad + (size_t)b * m * n;
+    const double *R_ = a.R + (size_t)b * n * p;
+    const double *B_ = a.B + (size_t)b * m * p;
+    const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
+    double *lam = a.lambda + (size_t)b * m;
+    const int mp = (m + 15) & ~15;
+    double *G = gws + (size_t)b * 2 * mp * mp;       // k x k, leading dimension ldg
+    double *L = G + (size_t)mp * mp;
+
+    for (int i = tid; i < n; i += WTPB) sx[i] = a.xd[(size_t)b * n + i];
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    // ---- pass 1: q~ (:58-60), ax (:84)
+    double qt[2] = {0.0, 0.0}, axv[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = tid + WTPB * h;
+        if (i < n) {
+            double s0 = a.qd[(size_t)b * n + i], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = 0;
+            for (; j + 16 <= n; j += 16) {                       // sixteen columns in flight
+                double v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = Q_[(size_t)(j + t) * n + i];
+#pragma unroll
+                for (int t = 0; t < 16; t += 4) {
+                    s0 = fma(v[t], sx[j + t], s0); s1 = fma(v[t + 1], sx[j + t + 1], s1);
+                    s2 = fma(v[t + 2], sx[j + t + 2], s2); s3 = fma(v[t + 3], sx[j + t + 3], s3);
+                }
+            }
+            for (; j < n; ++j) s0 = fma(Q_[(size_t)j * n + i], sx[j], s0);
+            for (int k = 0; k < p; ++k) s1 = fma(R_[(size_t)k * n + i], w_[k], s1);
+            qt[h] = (s0 + s1) + (s2 + s3);
+        }
+        if (i < m) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = 0;
+            for (; j + 16 <= n; j += 16) {
+                double v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = A_[(size_t)(j + t) * m + i];
+#pragma unroll
+                for (int t = 0; t < 16; t += 4) {
+                    s0 = fma(v[t], sx[j + t], s0); s1 = fma(v[t + 1], sx[j + t + 1], s1);
+                    s2 = fma(v[t + 2], sx[j + t + 2], s2); s3 = fma(v[t + 3], sx[j + t + 3], s3);
+                }
+            }
+            for (; j < n; ++j) s0 = fma(A_[(size_t)j * m + i], sx[j], s0);
+            for (int k = 0; k < p; ++k) s1 = fma(B_[(size_t)k * m + i], w_[k], s1);
+            axv[h] = (s0 + s1) + (s2 + s3);
+            const double lr = a.l[(size_t)b * m + i], ur = a.u[(size_t)b * m + i];
+            if (!(lr - 1e-3 <= axv[h] && axv[h] - 1e-3 <= ur)) s_flag = 1;          // :86
+            scls[i] = (unsigned char)(((axv[h] < lr + 1e-2) ? 1 : 0) | ((axv[h] > ur - 1e-2) ? 2 : 0));   // :98-103
+        }
+    }
+    __syncthreads();
+    if (s_flag) {
+        for (int r = tid; r < m; r += WTPB) lam[r] = 0.0;
+        if (tid == 0) { a.solution[b] = 0; a.path[b] = 0; }
+        return;
+    }
+    // q~ to LDS (x is done with), active columns [pos | neg | both], rows ascending within a class
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { const int i = tid + WTPB * h; if (i < n) sx[i] = qt[h]; }
+    // column of every active row: classes in the order [pos | neg | both] (:114), rows ascending within a class -- ballots per
+    // wavefront and half (rows tid and tid + 256), offsets from a 3 x 8 table of counts
+    {
+        int mycls[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int i = tid + WTPB * h; mycls[h] = i < m ? scls[i] : 0; }
+        unsigned long long bal[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bal[c][h] = qpn_ballot(mycls[h] == c + 1);
+                if (lane == 0) s_cnt[c][4 * h + wave] = __popcll(bal[c][h]);
+            }
+        __syncthreads();
+        int tot[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { tot[c] = 0; for (int q = 0; q < 8; ++q) tot[c] += s_cnt[c][q]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = mycls[h] - 1;
+            if (c >= 0) {
+                int pos = c == 0 ? 0 : (c == 1 ? tot[0] : tot[0] + tot[1]);
+                for (int q = 0; q < 4 * h + wave; ++q) pos += s_cnt[c][q];
+                pos += __popcll(bal[c][h] & below);
+                if (pos < VW_KMAX) { srow[pos] = tid + WTPB * h; ssgv[pos] = c == 1 ? -1.0 : 1.0; }
+            }
+        }
+        if (tid == 0) { s_k = tot[0] + tot[1] + tot[2]; s_np = tot[0]; s_nn = tot[1]; }
+    }
+    __syncthreads();
+    const int k = s_k, npn = s_np + s_nn;
+    if (k > VW_KMAX) {                                           // more active rows than the tiles of this kernel hold: round 1's route
+        if (tid == 0) { a.solution[b] = 0; a.path[b] = -2; }
+        return;
+    }
+    const int T = (k + 15) >> 4, ldg = 16 * T;
+    // ---- pass 2: Gram block (raw) on the matrix cores, right-hand side by column, panels of wp columns
+    vd4 acc[9];
+    int tI[9], tJ[9];
+    {
+        int e = 0, cnt = 0;
+        for (int I = 0; I < T; ++I)
+            for (int J = I; J < T; ++J, ++e)
+                if ((e & 3) == wave && cnt < 9) { tI[cnt] = I; tJ[cnt] = J; ++cnt; }
+        for (; cnt < 9; ++cnt) { tI[cnt] = -1; tJ[cnt] = -1; }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = vd4{0.0, 0.0, 0.0, 0.0};
+    double rhs = 0.0;
+    const int npanel = (n + wp - 1) / wp;
+    const int myrow = tid < k ? srow[tid] : 0;
+    // (software-pipelined: the next panel's 16 values per thread are requested before the current panel's work and stored to the
+    //  other buffer after it -- a load straight into LDS would stall the thread at the store until the data is there)
+    double pre[16];
+    auto fetch_panel = [&](int pn) {
+        const int j0 = pn * wp;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = tid + WTPB * q;
+            const int jj = idx / m, r = idx - jj * m;
+            pre[q] = (idx < wp * m && j0 + jj < n) ? A_[(size_t)(j0 + jj) * m + r] : 0.0;
+        }
+    };
+    auto store_panel = [&](double *buf) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = tid + WTPB * q;
+            const int jj = idx / m, r = idx - jj * m;
+            if (idx < wp * m) buf[jj * ldp + r] = pre[q];
+        }
+    };
+    fetch_panel(0);
+    store_panel(dynp);
+    __syncthreads();
+    for (int pn = 0; pn < npanel; ++pn) {
+        double *cur = dynp + (size_t)(pn & 1) * wp * ldp, *nxt = dynp + (size_t)((pn + 1) & 1) * wp * ldp;
+        if (pn + 1 < npanel) fetch_panel(pn + 1);
+        const int j0 = pn * wp;
+        if (tid < k) {
+            double r1 = 0.0;
+            for (int jj = 0; jj < wp; jj += 2) {
+                rhs = fma(cur[jj * ldp + myrow], (j0 + jj < n) ? sx[j0 + jj] : 0.0, rhs);
+                r1 = fma(cur[(jj + 1) * ldp + myrow], (j0 + jj + 1 < n) ? sx[j0 + jj + 1] : 0.0, r1);
+            }
+            rhs += r1;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (tI[q] < 0) continue;                             // (wave-uniform)
+            const int ci = 16 * tI[q] + lc, cj = 16 * tJ[q] + lc;
+            const int ri = ci < k ? srow[ci] : 0, rj = cj < k ? srow[cj] : 0;
+            for (int s4 = 0; s4 < wp / 4; ++s4) {
+                const double av = ci < k ? cur[(4 * s4 + lq) * ldp + ri] : 0.0;
+                const double bv = cj < k ? cur[(4 * s4 + lq) * ldp + rj] : 0.0;
+                acc[q] = VMFMA(av, bv, acc[q]);
+            }
+        }
+        if (pn + 1 < npanel) store_panel(nxt);
+        __syncthreads();
+    }
+    // ---- equilibration from the raw diagonal, then G (signed, scaled) to the workspace, both triangles
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        if (tI[q] < 0 || tI[q] != tJ[q]) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = 16 * tI[q] + lq + 4 * g, j = 16 * tJ[q] + lc;
+            if (i == j && i < k) sdv[i] = acc[q][g] > 0.0 ? 1.0 / sqrt(acc[q][g]) : 0.0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        if (tI[q] < 0) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = 16 * tI[q] + lq + 4 * g, j = 16 * tJ[q] + lc;
+            if (i < k && j < k) {
+                const double v = acc[q][g] * (sdv[i] * ssgv[i]) * (sdv[j] * ssgv[j]);
+                G[(size_t)j * ldg + i] = v;
+                if (tI[q] != tJ[q]) G[(size_t)i * ldg + j] = v;
+            }
+        }
+    }
+    const bool mine = tid < k;
+    const double dcol = mine ? sdv[tid] : 0.0;
+    rhs = mine ? rhs * dcol * ssgv[tid] : 0.0;
+    __threadfence_block();
+    __syncthreads();
+
+    // least squares on the column set P (thread c: inP): diagonally pivoted Cholesky of G(P, P), left-looking, L in its own block
+    // (the factor lives in the dynamic LDS block -- the panels are done with -- when k x k doubles fit it: config 5's nodes have
+    //  70 .. 95 active rows; otherwise in the workspace.  Two instantiations, so that each knows its address space.)
+    const bool lds_factor = (long long)k * (k | 1) <= (long long)dyn_doubles;
+    const int ldl = lds_factor ? (k | 1) : ldg;                   // (odd: a row of the factor, read across lanes, hits distinct banks)
+    auto lsq_impl = [&](auto in_lds, bool inP, double &y_out, bool &pivoted) {
+        double *Lf;
+        if constexpr (decltype(in_lds)::value) Lf = dynp; else Lf = L;
+        bool done = !inP;
+        int mystep = -1;
+        double diag = inP ? G[(size_t)tid * ldg + tid] : 0.0;
+        double dsc = wave_max_f64(inP ? diag : 0.0);
+        if (lane == 0) red[wave] = dsc;
+        __syncthreads();
+        const double dscale = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        const double dfloor = 1e-12 * (dscale > 1.0 ? dscale : 1.0);
+        __syncthreads();
+        int rank = 0;
+        double bvec = inP ? rhs : 0.0, myinv = 0.0;
+        for (int s = 0; s < k; ++s) {
+            // pivot (PIV_BAND above): the remaining diagonals go to LDS (`sx` is free here), ONE barrier, then every wave works
+            // the same pivot out of the k <= 128 values, two per lane
+            if (tid < VW_KMAX) sx[tid] = (mine && !done) ? diag : -1.0;
+            __syncthreads();                                      // A: (also: everything step s - 1 stored is visible)
+            const double d0 = sx[lane], d1 = sx[64 + lane];
+            const double dtop = wave_max_f64(fmax(d0, d1));
+            if (!(dtop > dfloor)) break;                          // (uniform)
+            const int f0 = wave_first(d0 >= dtop * PIV_BAND), f1 = wave_first(d1 >= dtop * PIV_BAND);
+            const int pv = f0 >= 0 ? f0 : 64 + f1;
+            const double dmax = sx[pv];
+            const double gcol = (mine && !done) ? G[(size_t)pv * ldg + tid] : 0.0;     // in flight behind the factor's columns
+            const double lpp = sqrt(dmax), inv = 1.0 / lpp;
+            double dot0 = 0.0, dot1 = 0.0, dot2 = 0.0, dot3 = 0.0;
+            // the products L(i, 0:s) . L(pv, 0:s): waves 0, 1 own rows 0 .. 127; waves 2, 3 shadow the same rows and take every other
+            // group of 8 columns off them (their partial sums cross in `sco`, one more barrier) -- all four SIMDs work
+            const int half = tid >> 7, rowi = tid & 127;
+            if (64 * (wave & 1) < k) {                            // (wave-uniform: every lane of a wave with rows takes part --
+                // v_readlane reads lanes whatever the exec mask says, so the lanes beyond k must hold the row as well)
+                // the pivot's row of the factor, one entry per lane (two registers: s <= 128), handed out by v_readlane below:
+                // the shared LDS pipe then carries ONE read per multiply-add (each thread's own row), not two
+                const double rp0 = lane < s ? Lf[(size_t)lane * ldl + pv] : 0.0;
+                const double rp1 = 64 + lane < s ? Lf[(size_t)(64 + lane) * ldl + pv] : 0.0;
+                const int tidc = rowi < k ? rowi : 0;             // (lanes beyond k read row 0: in range, result unused)
+                auto pivot_entry = [&](int t) -> double {         // (t wave-uniform)
+                    const double r = t < 64 ? rp0 : rp1;
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r), t & 63),
+                                            __builtin_amdgcn_readlane(__double2loint(r), t & 63));
+                };
+                int t0 = 8 * half;
+                for (; t0 + 8 <= s; t0 += 16) {
+                    double av[8];
+#pragma unroll
+                    for (int u_ = 0; u_ < 8; ++u_) av[u_] = Lf[(size_t)(t0 + u_) * ldl + tidc];
+#pragma unroll
+                    for (int u_ = 0; u_ < 8; u_ += 4) {
+                        dot0 = fma(av[u_], pivot_entry(t0 + u_), dot0);
+                        dot1 = fma(av[u_ + 1], pivot_entry(t0 + u_ + 1), dot1);
+                        dot2 = fma(av[u_ + 2], pivot_entry(t0 + u_ + 2), dot2);
+                        dot3 = fma(av[u_ + 3], pivot_entry(t0 + u_ + 3), dot3);
+                    }
+                }
+                if (t0 < s) {                                     // this half's last, partial group: columns past s - 1 read column
+                    double av[8];                                 // s - 1 (finite) against a pivot entry of 0
+#pragma unroll
+                    for (int u_ = 0; u_ < 8; ++u_) { const int t = t0 + u_; av[u_] = Lf[(size_t)(t < s ? t : s - 1) * ldl + tidc]; }
+#pragma unroll
+                    for (int u_ = 0; u_ < 8; u_ += 2) {
+                        dot0 = fma(av[u_], pivot_entry(t0 + u_), dot0);
+                        dot1 = fma(av[u_ + 1], pivot_entry(t0 + u_ + 1), dot1);
+                    }
+                }
+            }
+            dot0 = (dot0 + dot2) + (dot1 + dot3);
+            if (half == 1 && rowi < k) sco[rowi] = dot0;
+            __syncthreads();                                      // C
+            if (mine) dot0 += sco[tid];
+            dot1 = 0.0;
+            const double lis = (tid == pv) ? lpp : (gcol - (dot0 + dot1)) * inv;
+            if (mine && !done) Lf[(size_t)s * ldl + tid] = lis;
+            if (tid == pv) { s_bc[0] = bvec * inv; sord[s] = pv; }     // forward substitution: w_s = b_pv / lpp
+            __threadfence_block();
+            __syncthreads();                                      // B
+            const double ws = s_bc[0];
+            if (mine && !done && tid != pv) { diag = fma(-lis, lis, diag); bvec = fma(-lis, ws, bvec); }
+            if (tid == pv) { done = true; mystep = s; bvec = ws; myinv = inv; }
+            rank++;
+        }
+        __syncthreads();
+        double y = 0.0;
+        for (int s = rank - 1; s >= 0; --s) {                     // (column-oriented; the broadcast slot alternates: one barrier a step)
+            const int pvs = sord[s];
+            if (tid == pvs) { y = bvec * myinv; s_bc[1 + (s & 1)] = y; }
+            __syncthreads();
+            const double ys = s_bc[1 + (s & 1)];
+            if (mine && mystep >= 0 && mystep < s) bvec = fma(-Lf[(size_t)mystep * ldl + pvs], ys, bvec);
+        }
+        __syncthreads();
+        y_out = y; pivoted = mystep >= 0;
+    };
+    auto lsq_on = [&](bool inP, double &y_out, bool &pivoted) {
+        if (lds_factor) lsq_impl(std::true_type{}, inP, y_out, pivoted);
+        else lsq_impl(std::false_type{}, inP, y_out, pivoted);
+    };
+    // r = A_bar y - q~: thread <-> entry t (two per thread beyond 256); the residual's square sum over the block
+    double rt[2];
+    auto residual = [&](double ysc) -> double {
+        if (mine) sco[tid] = ysc * dcol * ssgv[tid];              // coefficient of the UNSCALED, unsigned row
+        __syncthreads();
+        double ss = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = tid + WTPB * h;
+            rt[h] = 0.0;
+            if (t < n) {
+                double s0 = -qt[h], s1 = 0.0;
+                int c = 0;
+                for (; c + 8 <= k; c += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u_ = 0; u_ < 8; ++u_) v[u_] = A_[(size_t)t * m + srow[c + u_]];
+#pragma unroll
+                    for (int u_ = 0; u_ < 8; u_ += 2) { s0 = fma(v[u_], sco[c + u_], s0); s1 = fma(v[u_ + 1], sco[c + u_ + 1], s1); }
+                }
+                for (; c < k; ++c) s0 = fma(A_[(size_t)t * m + srow[c]], sco[c], s0);
+                rt[h] = s0 + s1;
+                ss += rt[h] * rt[h];
+            }
+        }
+        return block_sum_f64(ss, red);
+    };
+
+    double y; bool piv;
+    lsq_on(mine, y, piv);
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    if (tid < npn && !(y * dcol > -a.tol)) s_flag = 1;           // :119 signs (y scaled back)
+    double res = residual(y);
+    __syncthreads();
+    if (!s_flag && sqrt(res) <= a.tol) {
+        for (int r = tid; r < m; r += WTPB) lam[r] = 0.0;
+        __syncthreads();
+        if (mine) lam[srow[tid]] = sco[tid];                      // :120-123
+        if (tid == 0) { a.solution[b] = 1; a.path[b] = 2; }
+        return;
+    }
+    // ---- :129-137  bounded least squares (verify_node32's active-set iteration; G's principal submatrices are re-factored)
+    {
+        const bool cons = tid < npn;
+        bool inP = mine && piv, blocked = false, failed = false;
+        double ycur = 0.0, sl = y;
+        int iters = 0;
+        const int cap = 3 * k + 12;
+        for (;;) {
+            for (;;) {
+                const bool bad = inP && cons && !(sl > 0.0);
+                if (tid == 0) s_flag = 0;
+                __syncthreads();
+                if (bad) s_flag = 1;
+                __syncthreads();
+                if (!s_flag) { ycur = inP ? sl : 0.0; break; }
+                const double ratio = bad ? ycur / (ycur - sl) : QINF;
+                const double mymin = (bad && ratio == ratio) ? ratio : (bad ? 0.0 : QINF);
+                const double alpha = -block_max_f64(-mymin, red);
+                if (inP) ycur = fma(alpha, sl - ycur, ycur);
+                if (bad && (!(ratio == ratio) || ratio <= alpha)) { inP = false; ycur = 0.0; }
+                if (++iters > cap) { failed = true; break; }
+                bool pv2;
+                __syncthreads();
+                lsq_on(inP, sl, pv2);
+                if (inP && !pv2) { inP = false; ycur = 0.0; }
+            }
+            if (failed) break;
+            res = residual(ycur);
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int t = tid + WTPB * h; if (t < n) sx[t] = rt[h]; }
+            __syncthreads();
+            double wgr = 0.0;
+            if (mine) {
+                double w0 = 0.0, w1 = 0.0;
+                int t = 0;
+                for (; t + 2 <= n; t += 2) {
+                    w0 = fma(A_[(size_t)t * m + myrow], sx[t], w0);
+                    w1 = fma(A_[(size_t)(t + 1) * m + myrow], sx[t + 1], w1);
+                }
+                if (t < n) w0 = fma(A_[(size_t)t * m + myrow], sx[t], w0);
+                wgr = -(w0 + w1) * dcol * ssgv[tid];              // scaled, signed column . (q~ - A_bar y)
+            }
+            const double gscale = block_max_f64(mine ? fabs(rhs) : 0.0, red);
+            const bool cand = mine && cons && !inP && !blocked && wgr > 1e-11 * (gscale > 1.0 ? gscale : 1.0);
+            const double wmax = block_max_f64(cand ? wgr : -1.0, red);
+            if (!(wmax > 0.0)) break;                             // optimal
+            if (tid == 0) s_pv = 0x7fffffff;
+            __syncthreads();
+            if (cand && wgr == wmax) atomicMin(&s_pv, tid);
+            __syncthreads();
+            const int enter = s_pv;
+            if (tid == enter) inP = true;
+            if (++iters > cap) { failed = true; break; }
+            bool pv2;
+            lsq_on(inP, sl, pv2);
+            if (inP && !pv2) { inP = false; if (tid == enter) blocked = true; }
+            if (tid == enter) s_bc[0] = sl;
+            __syncthreads();
+            const double s_enter = s_bc[0];
+            __syncthreads();
+            if (!(s_enter > 0.0)) {
+                if (tid == enter) { inP = false; blocked = true; }
+                lsq_on(inP, sl, pv2);
+                if (inP && !pv2) inP = false;
+            }
+        }
+        for (int r = tid; r < m; r += WTPB) lam[r] = 0.0;
+        if (failed) {                                             // :143-145
+            if (tid == 0) { a.solution[b] = 0; a.path[b] = 5; }
+            return;
+        }
+        __syncthreads();
+        const bool ok = sqrt(res) <= 1e-4;                        // :138 (res: the residual at ycur, from the last outer test)
+        if (mine) lam[srow[tid]] = sco[tid];
+        if (tid == 0) { a.solution[b] = ok ? 1 : 0; a.path[b] = ok ? 3 : 4; }
+    }
+}
+
 __global__ __launch_bounds__(WTPB) void verify_wide_stage1(VerifyArgs a)
 {
     const int n = a.n, m = a.m, p = a.p;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    if (a.gate && a.path[b] != -2) return;
     __shared__ double sx[WMAX], sqt[WMAX], ssg[WMAX], sdiag[WMAX], sb[WMAX], sy[WMAX], slv[WMAX];
     __shared__ int srow[WMAX], sstep[WMAX], scls[WMAX], sord[WMAX];
     __shared__ double red[4];
@@ -1059,10 +1526,10 @@ __global__ __launch_bounds__(WTPB) void verify_wide_stage1(VerifyArgs a)
         if (!(dmax > 1e-12 * (dscale > 1.0 ? dscale : 1.0))) break;
         if (tid == 0) s_pv = WMAX;
         __syncthreads();
-        for (int c = tid; c < k; c += WTPB) if (sstep[c] < 0 && sdiag[c] == dmax) atomicMin(&s_pv, c);     // lowest such column
+        for (int c = tid; c < k; c += WTPB) if (sstep[c] < 0 && sdiag[c] >= dmax * PIV_BAND) atomicMin(&s_pv, c);     // lowest such column
         __syncthreads();
         const int pv = s_pv;
-        const double lpp = sqrt(dmax);
+        const double lpp = sqrt(sdiag[pv]);
         for (int c = tid; c < k; c += WTPB) {
             double lis = 0.0;
             if (sstep[c] < 0) lis = c == pv ? lpp : G[(size_t)pv * m + c] / lpp;
@@ -1185,7 +1652,7 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
                                    const double *u, const double *xd, const double *w,
                                    int64_t stride_w, double tol, int32_t *solution, double *lambda,
                                    int32_t *path, double *sG, double *sq, double *slb, double *sub,
-                                   double *sz, double *sres, int32_t *sst, hipStream_t stream, double *wbig)
+                                   double *sz, double *sres, int32_t *sst, hipStream_t stream, double *wbig, double *gws)
 {
     if (batch <= 0) return hipSuccess;
     VerifyArgs a{};
@@ -1194,7 +1661,26 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
     a.stride_w = stride_w; a.tol = tol; a.solution = solution; a.lambda = lambda; a.path = path;
     a.sG = sG; a.sq = sq; a.slb = slb; a.sub = sub; a.sz = sz;
     if (n > 64 || m > 64) {
-        // wide nodes: workgroup per node; the bounded-LSQ fallback is a large box-AVI (N = m) on the large-item kernel
+        // wide nodes: verify_wide_node (up to 128 active rows, every path inside the workgroup), then round 1's kernels over what it
+        // flagged -2 (their bounded-LSQ fallback is a large box-AVI, N = m, on the large-item kernel)
+        if (m >= 1 && gws) {
+            static QpnPerDeviceOnce attr_once;
+            const int dv = attr_once.device();
+            if (!attr_once.done[dv]) {
+                hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(verify_wide_node), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                if (e0 != hipSuccess) return e0;
+                attr_once.done[dv] = true;
+            }
+            const int wp = m <= 256 ? 16 : 8;
+            // the panels, and room for a k x k factor (k <= min(m, 128)) up to what two workgroups per CU allow
+            size_t dyn = (size_t)2 * wp * (size_t)(m | 1) * sizeof(double);
+            const size_t km = (size_t)(m < 128 ? m : 128), want = km * km * sizeof(double), cap = 71 * 1024;
+            if (dyn < (want < cap ? want : cap)) dyn = want < cap ? want : cap;
+            hipLaunchKernelGGL(verify_wide_node, dim3((unsigned)batch), dim3(WTPB), dyn, stream, a, gws, wp, (int)(dyn / sizeof(double)));
+            hipError_t e1 = hipGetLastError();
+            if (e1 != hipSuccess) return e1;
+            a.gate = 1;
+        }
         hipLaunchKernelGGL(verify_wide_stage1, dim3((unsigned)batch), dim3(WTPB), 0, stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || m == 0) return e;
