@@ -20,6 +20,8 @@ def solve(qpn, x_init=None, engine=None, rng=None):
         x_init = qpn.default_initialization
     rng = rng if rng is not None else np.random.default_rng(1)
     qpn.iterate_cache = {}
+    qpn.__dict__["_process_memo"] = {}          # level_batch.process_level / the subset reduction below: results of the last sweep
+    qpn.__dict__["_subset_memo"] = {}
     return solve_base(qpn, np.asarray(x_init, dtype=np.float64), level=1, proj_vectors=[], rng=rng, engine=engine)
 
 
@@ -70,9 +72,16 @@ def solve_base(qpn, x_init, level=1, proj_vectors=None, rng=None, engine=None):
             lv = opts.levels_to_remove_subsets                                       # None = NaturalNumbers(): every level
             if graphs and (lv is None or level in lv):                               # :84, all nodes of the level in one batch
                 ids = [pid for pid in graphs if graphs[pid] is not None and len(graphs[pid]) > 1]
+                smemo = qpn.__dict__.setdefault("_subset_memo", {})
+                for pid in ids:                                                      # the graph process_level handed back unchanged:
+                    ent = smemo.get(pid)                                             # its reduction is known
+                    if ent is not None and ent[0] is graphs[pid]:
+                        graphs[pid] = ent[1]
+                ids = [pid for pid in ids if not (pid in smemo and smemo[pid][1] is graphs[pid])]
                 if ids:
                     from .avi import _eng
                     for pid, kept in zip(ids, remove_subsets_many([graphs[pid] for pid in ids], _eng(engine))):
+                        smemo[pid] = (graphs[pid], kept)
                         graphs[pid] = kept
             S.update(graphs)
             if not equilibrium:                                                      # :91-109

@@ -29,7 +29,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .programs import Poly
+from .programs import Poly, _positions
 
 INF = np.inf
 # A local piece enters a node's solution graph only when it contains the current point -- within MEMBER_TOL, tighter than
@@ -66,9 +66,24 @@ def _static(qpn, pid: int) -> dict:
     st = dict(dec=dec, base=base, par=par, Qd=f.block(dec, dec), qd=f.q_at(dec),
               Ad=(np.vstack([P.block(dec) for P in base]) if base else np.zeros((0, dec.size))),
               l=(np.concatenate([P.l for P in base]) if base else np.zeros(0)),
-              u=(np.concatenate([P.u for P in base]) if base else np.zeros(0)))
+              u=(np.concatenate([P.u for P in base]) if base else np.zeros(0)),
+              # the blocks on the static parameters: what a record under child pieces that bring no new column keeps as it is
+              R=f.block(dec, par), B=(np.vstack([P.block(par) for P in base]) if base else np.zeros((0, par.size))),
+              reads=np.union1d(dec, par))
     cache[pid] = st
     return st
+
+
+def _subtree_cols(qpn, pid: int) -> np.ndarray:
+    """Every variable process_qp(pid) can read: the decision variables and static parameters of the node and of all nodes
+    below it (the children's pieces are functions of exactly those)."""
+    cache = qpn.__dict__.setdefault("_subtree_cols", {})
+    got = cache.get(pid)
+    if got is None:
+        st = _static(qpn, pid)
+        parts = [st["dec"], st["par"]] + [_subtree_cols(qpn, j) for j in sorted(qpn.network_edges[pid])]
+        got = cache[pid] = np.unique(np.concatenate(parts))
+    return got
 
 
 def node_record(qpn, pid: int, child_polys: Sequence[Poly] = ()) -> dict:
@@ -77,8 +92,19 @@ def node_record(qpn, pid: int, child_polys: Sequence[Poly] = ()) -> dict:
     st = _static(qpn, pid)
     dec = st["dec"]
     f = qpn.qps[pid].f
+    if not child_polys:
+        return dict(pid=pid, dec=dec, par=st["par"], Qd=st["Qd"], R=st["R"], qd=st["qd"], Ad=st["Ad"], B=st["B"], l=st["l"], u=st["u"])
+    supp = [P.support() for P in child_polys]
+    if all(_positions(st["reads"], c)[1].all() for c in supp):
+        # the usual case: the children's pieces live on variables the node reads anyway (its own and its static parameters)
+        par = st["par"]
+        return dict(pid=pid, dec=dec, par=par, Qd=st["Qd"], R=st["R"], qd=st["qd"],
+                    Ad=np.vstack([st["Ad"]] + [P.block(dec) for P in child_polys]),
+                    B=np.vstack([st["B"]] + [P.block(par) for P in child_polys]),
+                    l=np.concatenate([st["l"]] + [P.l for P in child_polys]),
+                    u=np.concatenate([st["u"]] + [P.u for P in child_polys]))
     if child_polys:
-        extra = np.unique(np.concatenate([P.support() for P in child_polys]))
+        extra = np.unique(np.concatenate(supp))
         par = np.union1d(st["par"], np.setdiff1d(extra, dec, assume_unique=True))
         Ad = np.vstack([st["Ad"]] + [P.block(dec) for P in child_polys])
         l = np.concatenate([st["l"]] + [P.l for P in child_polys])
@@ -91,8 +117,36 @@ def node_record(qpn, pid: int, child_polys: Sequence[Poly] = ()) -> dict:
     return dict(pid=pid, dec=dec, par=par, Qd=st["Qd"], R=R, qd=st["qd"], Ad=Ad, B=B, l=l, u=u)
 
 
+def free_equalities(rec: dict) -> dict:
+    """The same node with its equality rows (l = u) moved into the free block: an equality row's multiplier mu is a FREE variable
+    of the node's AVI (src/avi.jl:113-128: the row a'x + b'w = e pairs with an unbounded multiplier), so z = [x; mu_E; lambda_I]
+    with the free block [[Qd, -A_E'], [A_E, 0]] (right-hand side [qd; -e], parameter rows [R; B_E]) and the remaining rows
+    [A_I 0] is the identical complementarity system.  The fused node kernels eliminate the free block without pivoting -- in this
+    order: x first (Qd, definite), then mu (its block has become A_E Qd^-1 A_E', definite for independent rows) -- and run the
+    complementary pivoting on the inequality rows alone; a record that keeps an equality row is declined by every one of them
+    (the multiplier would have to be crashed in) and falls to the general kernel.  Every parent of a net has such rows: the
+    stationarity rows of its children's pieces.  `nx` = the number of leading free variables that are decision variables."""
+    l, u = rec["l"], rec["u"]
+    eq = np.isfinite(l) & (l == u)
+    if not eq.any():
+        return rec
+    E = np.nonzero(eq)[0]; I = np.nonzero(~eq)[0]
+    n, ne = rec["Qd"].shape[0], E.size
+    AE, BE = rec["Ad"][E], rec["B"][E]
+    out = dict(rec)
+    out["Qd"] = np.block([[rec["Qd"], -AE.T], [AE, np.zeros((ne, ne))]])
+    out["R"] = np.vstack([rec["R"], BE])
+    out["qd"] = np.concatenate([rec["qd"], -l[E]])
+    out["Ad"] = np.hstack([rec["Ad"][I], np.zeros((I.size, ne))])
+    out["B"] = rec["B"][I]
+    out["l"], out["u"] = l[I], u[I]
+    out["nx"] = n
+    return out
+
+
 class RecordBatch:
-    """Records of equal shape (n, padded m, padded p) stacked in the ABI layout (column-major per item)."""
+    """Records of equal shape (n, padded m, padded p) stacked in the ABI layout (column-major per item).  n counts the free
+    block (Qd is n x n); its first nx entries are the node's decision variables (nx < n after free_equalities)."""
 
     def __init__(self, recs: List[dict], where: List[int], n: int, m: int, p: int):
         nb = len(recs)
@@ -102,7 +156,8 @@ class RecordBatch:
         self.Qc = np.zeros((nb, n, n)); self.Rc = np.zeros((nb, p, n)); self.qd = np.zeros((nb, n))
         self.Ac = np.zeros((nb, n, m)); self.Bc = np.zeros((nb, p, m))
         self.l = np.full((nb, m), -INF); self.u = np.full((nb, m), INF)      # missing rows: 0'x in (-inf, inf) -- inert
-        self.dec = np.zeros((nb, n), dtype=np.int64)
+        self.nx = recs[0]["dec"].size
+        self.dec = np.zeros((nb, self.nx), dtype=np.int64)
         self.par = np.full((nb, p), -1, dtype=np.int64)                      # missing parameters: a zero column, w = 0
         for b, r in enumerate(recs):
             mi, pi = len(r["l"]), r["par"].size
@@ -141,9 +196,9 @@ def batch_records(recs: List[dict], row_pad: int = ROW_PAD) -> List[RecordBatch]
     for i, r in enumerate(recs):
         m = len(r["l"])
         mp = max(row_pad, -(-m // row_pad) * row_pad) if m else 0
-        groups.setdefault((r["dec"].size, mp), []).append(i)
+        groups.setdefault((r["Qd"].shape[0], mp, r["dec"].size), []).append(i)
     out = []
-    for (n, mp), idx in sorted(groups.items()):
+    for (n, mp, _nx), idx in sorted(groups.items()):
         p = max(1, max(recs[i]["par"].size for i in idx))
         out.append(RecordBatch([recs[i] for i in idx], idx, n, mp, p))
     return out
@@ -224,14 +279,16 @@ def _pool_blocks_local(qpn, pool: List[int], assign: Dict[int, Poly]):
 # ---------------------------------------------------------------------------------------------------------------------
 # solve_qep for a level: src/avi.jl:382-444 over the components
 # ---------------------------------------------------------------------------------------------------------------------
-def _leaf_batches(qpn, players, engine):
+def _leaf_batches(qpn, players, engine, free_eq=False):
     """Record batches of the childless nodes among `players`: they depend on the net alone, so they are built once per
-    (net, player set) and keep a resident handle."""
+    (net, player set) and keep a resident handle.  free_eq: the solve's form of the records (free_equalities)."""
     cache = qpn.__dict__.setdefault("_leaf_batches", {})
-    key = tuple(players)
+    key = (tuple(players), bool(free_eq))
     got = cache.get(key)
     if got is None:
         recs = [node_record(qpn, i) for i in players]
+        if free_eq:
+            recs = [free_equalities(r) for r in recs]
         got = cache[key] = (recs, batch_records(recs))
     return got
 
@@ -264,8 +321,16 @@ def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]
     leaf = [i for i in singles if not qpn.network_edges[i]]
     inner = [i for i in singles if qpn.network_edges[i]]
     work = []
+    take = None
     if leaf and not reference_form:
-        work += [(b, True) for b in _leaf_batches(qpn, leaf, eng)[1]]
+        # ONE resident batch per level for all its childless players (built once per net): every record is solved -- one launch
+        # whatever the subset -- and only the players asked for are written back (a batch per subset would upload a new copy of
+        # the records whenever the set of unsettled players changes)
+        universe = [i for i in sorted(players) if not qpn.network_edges[i]]
+        recs_u, batches_u = _leaf_batches(qpn, universe, eng, free_eq=True)
+        wanted = set(leaf)
+        take = {id(b): np.array([recs_u[i]["pid"] in wanted for i in b.where]) for b in batches_u}
+        work += [(b, True) for b in batches_u if take[id(b)].any()]
     elif leaf:
         inner = sorted(inner + leaf)
     if inner:
@@ -273,14 +338,14 @@ def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]
         if reference_form:
             work += [(r, None) for r in recs]
         else:
-            work += [(b, False) for b in batch_records(recs)]
+            work += [(b, False) for b in batch_records([free_equalities(r) for r in recs])]
     for item, static in work:
         if static is None:
             _solve_single_reference_form(item, x, x_opt, eng, bad)
             continue
         b = item
         xd, w = b.gather(x)
-        z0 = np.zeros((len(b), b.n + b.m)); z0[:, :b.n] = xd                        # duals cold, :404
+        z0 = np.zeros((len(b), b.n + b.m)); z0[:, :b.nx] = xd                       # duals cold, :404
         h = b.resident(eng) if static else None
         if h is not None:
             res = h.solve(w, want=("z", "resid", "pivots"))
@@ -288,10 +353,11 @@ def solve_level(qpn, players: Sequence[int], x, assign: Optional[Dict[int, Poly]
             res = eng.solve_nodes(b.Qc, b.Rc, b.qd, b.Ac, b.Bc, b.l, b.u, w, z0=z0)
         st = np.asarray(res["status"])
         z = np.asarray(res["z"])
-        if np.any(st != StatusCode.SUCCESS):
-            k = int(np.nonzero(st != StatusCode.SUCCESS)[0][0])
+        sel = take[id(b)] if (static and take is not None) else np.ones(len(b), bool)
+        if np.any(st[sel] != StatusCode.SUCCESS):
+            k = int(np.nonzero((st != StatusCode.SUCCESS) & sel)[0][0])
             bad.append((int(b.dec[k][0]), int(st[k])))
-        x_opt[b.dec.ravel()] = z[:, :b.n].ravel()                                    # :440-443
+        x_opt[b.dec[sel].ravel()] = z[sel][:, :b.nx].ravel()                         # :440-443
     # ---- multi-node components: pool AVIs, one assemble + one solve per pool shape
     if multis:
         blocks = [_pool_blocks_local(qpn, c, assign) for c in multis]
@@ -436,29 +502,35 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         Ar = np.asarray(Ar); lr = np.asarray(lr); ur = np.asarray(ur); rows = np.asarray(rows); flags = np.asarray(flags)
         for k in sel:
             out[b.where[k]] = []
+        colsel = {}                                          # per record: the piece's columns [x_d; x_p present] in ascending order
+        for k in sel:
+            pk = np.nonzero(b.par[k] >= 0)[0]
+            cols = np.concatenate([b.dec[k], b.par[k][pk]])
+            order = np.argsort(cols, kind="stable")
+            colsel[k] = (cols[order], np.concatenate([np.arange(n), n + pk])[order])
         seen = {b.where[k]: set() for k in sel}
         fallback = {}                                        # per node: the piece the point misses least, for a node none of whose
                                                              # pieces passes (a solution graph is never empty, src/qp_processing.jl:233)
         for t in range(len(node_of)):
             k = int(rec_of[t]); i = b.where[k]
+            cols_k, take_k = colsel[k]
             if flags[t]:
                 P = _reduce_on_host(b, k, np.asarray(K)[t], eng)
+                if P is None:
+                    continue
+                Al = np.ascontiguousarray(P[0][:, take_k]); ll, ul = P[1], P[2]
             else:
                 r = int(rows[t])
-                P = (Ar[t, :, :r].T, lr[t, :r], ur[t, :r])             # [rows, n + p] over [x_d; x_p]
-            if P is None:
-                continue
-            Al, ll, ul = P
-            pk = b.par[k] >= 0
-            cols = np.concatenate([b.dec[k], b.par[k][pk]])
-            Pg = _dedupe(Poly.from_local(qpn.num_vars, cols, np.hstack([Al[:, :n], Al[:, n:][:, pk]]), ll, ul))
+                Al = np.ascontiguousarray(Ar[t, take_k, :r].T)          # [rows, columns ascending] out of [n + p, rows]
+                ll, ul = lr[t, :r], ur[t, :r]
+            Pg = _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, Al, ll, ul))
             # the parent's verify_solution tests feasibility on exactly these normalised rows with 1e-3 (src/qp_processing.jl:86):
             # a piece the point fails here would be "infeasible" there by construction (MEMBER_TOL)
             cl, Al_ = Pg.local()
             ax = Al_ @ x[cl]
             miss = float(np.max(np.maximum(Pg.l - ax, ax - Pg.u), initial=0.0))
             if miss <= member_tol:
-                key = (cl.tobytes(), (np.round(Al_, 6) + 0.0).tobytes(), np.round(Pg.l, 6).tobytes(), np.round(Pg.u, 6).tobytes())
+                key = (cl.tobytes(), (np.round(Al_, 6) + 0.0).tobytes(), np.round(np.concatenate([Pg.l, Pg.u]), 6).tobytes())
                 if key not in seen[i]:                       # the reference collects the pieces in a Set (src/avi_solutions.jl:104)
                     seen[i].add(key)
                     out[i].append(Pg)
@@ -518,6 +590,22 @@ def process_level(qpn, players: Sequence[int], x, S: Dict[int, list], engine=Non
     from .qp_processing import combine_many
     eng = _eng(engine)
     x = np.asarray(x, dtype=np.float64)
+    # process_qp is a function of x on the node's subtree columns and of its children's solution graphs: a node for which
+    # neither has changed since the last sweep gets the result it got then (the reference recomputes it, src/algorithm.jl:47 --
+    # to the same value).  On a net of many independent clusters most nodes are at rest after the first sweeps.
+    memo = qpn.__dict__.setdefault("_process_memo", {})
+    all_players = list(players)
+    xkey = {pid: x[_subtree_cols(qpn, pid)].tobytes() for pid in all_players}
+    hits = {}
+    for pid in all_players:
+        ent = memo.get(pid)
+        if ent is not None and ent["xkey"] == xkey[pid] and ent["ev"] == exploration_vertices and \
+                all(S.get(j) is g for j, g in ent["kids"].items()):
+            hits[pid] = ent["result"]
+    all_leaf_level = all(not qpn.network_edges[pid] for pid in all_players)
+    if not all_leaf_level:
+        players = [pid for pid in all_players if pid not in hits]      # (a level of childless nodes keeps its one resident batch:
+                                                                       #  all are verified in one launch, hits skip the pieces)
     items, owner = [], []
     combos_of = {}
     for pid in players:
@@ -549,6 +637,8 @@ def process_level(qpn, players: Sequence[int], x, S: Dict[int, list], engine=Non
             continue
         gen = (pid not in qpn.network_depth_map[1]) or qpn.options.gen_solution_map
         results[pid] = dict(solution=True, S=None, failed=False)
+        if pid in hits:
+            continue
         if gen:
             for t in range(len(combos)):
                 want[i0 + t] = True
@@ -575,4 +665,10 @@ def process_level(qpn, players: Sequence[int], x, S: Dict[int, list], engine=Non
         for pid in players:
             if results[pid].get("solution") and want[first[pid]] and len(results[pid]["S"]) == 0:
                 raise RuntimeError("This shouldn't happen. Solution graph is empty.")
-    return [results[pid] for pid in players]
+    for pid in all_players:
+        if pid in hits:
+            results[pid] = hits[pid]
+        else:
+            memo[pid] = dict(xkey=xkey[pid], ev=exploration_vertices, result=results[pid],
+                             kids={j: S.get(j) for j in qpn.network_edges[pid]})
+    return [results[pid] for pid in all_players]

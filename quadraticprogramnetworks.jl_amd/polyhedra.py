@@ -81,16 +81,26 @@ def issubset_batch(pairs, engine, tol=1e-6):
     one emptiness query per bound, all pairs and bounds in one `isempty_batch` call.  An empty P1 is a subset of
     anything (the reference's LP is infeasible there and it answers false; noted, not mirrored)."""
     queries, owner = [], []
+    keyed = {}                                   # per polyhedron (the same object shows up in many pairs): its rows as hashable keys
+
+    def rows_of(P):
+        got = keyed.get(id(P))
+        if got is None:
+            A, l, u = (P.vectorize() if hasattr(P, "vectorize") else P)
+            A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+            Ar = np.round(A, 9) + 0.0
+            got = keyed[id(P)] = (A, np.asarray(l, dtype=np.float64), np.asarray(u, dtype=np.float64), [Ar[r].tobytes() for r in range(A.shape[0])], P)
+        return got
+
     for k, (P1, P2) in enumerate(pairs):
-        A1, l1, u1 = (P1.vectorize() if hasattr(P1, "vectorize") else P1)
-        A2, l2, u2 = (P2.vectorize() if hasattr(P2, "vectorize") else P2)
-        A1 = np.atleast_2d(np.asarray(A1, dtype=np.float64)); A2 = np.atleast_2d(np.asarray(A2, dtype=np.float64))
+        A1, l1, u1, k1, _ = rows_of(P1)
+        A2, l2, u2, k2, _ = rows_of(P2)
         # a bound of P2 that P1 carries itself -- the same normal (to 1e-9) with a bound at least as tight -- holds on all of P1: no LP
         own = {}
-        for r in range(A1.shape[0]):
-            own.setdefault((np.round(A1[r], 9) + 0.0).tobytes(), []).append(r)
+        for r, key in enumerate(k1):
+            own.setdefault(key, []).append(r)
         for i in range(A2.shape[0]):
-            mine = own.get((np.round(A2[i], 9) + 0.0).tobytes(), ())
+            mine = own.get(k2[i], ())
             lo1 = max((l1[r] for r in mine), default=-INF); hi1 = min((u1[r] for r in mine), default=INF)
             if np.isfinite(l2[i]) and not lo1 >= l2[i] - tol:          # a violation is a point of P1 with a'x <= l2 - tol
                 queries.append((np.vstack([A1, A2[i:i + 1]]), np.append(l1, -INF), np.append(u1, l2[i] - tol))); owner.append(k)

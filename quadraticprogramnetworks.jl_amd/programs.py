@@ -154,6 +154,14 @@ class Poly:
         P._init(int(ncols), cols[order], A, l, u, normalise, tol, open_lo, open_hi)
         return P
 
+    @classmethod
+    def from_sorted(cls, ncols: int, cols, A, l, u) -> "Poly":
+        """from_local for columns already ascending and without repeats (the caller vouches: the level batches, whose column
+        lists are a record's own sorted index sets); A [rows, len(cols)] is taken over, not copied."""
+        P = cls.__new__(cls)
+        P._init(int(ncols), cols, A, l, u, True, 1e-8, None, None)
+        return P
+
     def _init(self, ncols, cols, A, l, u, normalise, tol, open_lo, open_hi):
         l = np.asarray(l, dtype=np.float64).copy()
         u = np.asarray(u, dtype=np.float64).copy()
