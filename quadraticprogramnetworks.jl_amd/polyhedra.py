@@ -159,29 +159,73 @@ def issubset_batch_chunked(pairs, engine, tol=1e-6, chunk_bytes=None):
     return out
 
 
-def interior_members_batch(trips, engine, slack_cap=1.0, chunk=20000):
-    """One member per polyhedron (A, l, u), as far inside as its INEQUALITY rows allow: the slack LP of `exemplar`
-    (src/sets.jl:608-619) with the equality rows (l == u) kept as equalities, so that a lower-dimensional piece gets a point of its
-    relative interior instead of eps = 0 at an arbitrary feasible point.  -> list of x or None (empty / no answer)."""
+def interior_members_batch(trips, engine, delta=1e-2, chunk=20000):
+    """One member per polyhedron (A, l, u), well inside its INEQUALITY rows: the slack program of `exemplar` (src/sets.jl:608-619)
+    with the equality rows (l == u) kept as equalities -- a lower-dimensional piece gets a point of its relative interior instead
+    of eps = 0 at an arbitrary feasible point -- and a small proximal term,
+
+        min  eps + delta/2 (|x|^2 + eps^2)   s.t.  a_i'x = l_i (equality rows),  a_i'x + eps >= l_i,  a_i'x - eps <= u_i (the others),
+
+    so that every query is a strictly convex node: with the equality multipliers in the free block (level_batch.free_equalities)
+    the fused node kernels take it, where the plain LP -- no pivots in its H block -- fell to the general kernel, the slowest
+    call of a level's sweep.  The proximal term caps the slack at 1 / delta and picks the least-norm point among the deepest ones;
+    the answer is used as ONE member of the polyhedron (remove_subsets_many), never as an optimum.
+    -> list of x or None (empty / no answer)."""
     out = [None] * len(trips)
-    for c0 in range(0, len(trips), chunk):
-        part = trips[c0:c0 + chunk]
-        dmax = max(np.atleast_2d(t[0]).shape[1] for t in part) + 1
-        mmax = max(2 * np.atleast_2d(t[0]).shape[0] for t in part) + 1
-        B = len(part)
-        A2 = np.zeros((B, mmax, dmax)); l2 = np.full((B, mmax), -INF); u2 = np.full((B, mmax), INF)
-        cost = np.zeros((B, dmax)); cost[:, dmax - 1] = 1.0
-        for k, (A, l, u) in enumerate(part):
-            A = np.atleast_2d(A); n, d = A.shape
-            eq = (l == u)
-            A2[k, :n, :d] = A; A2[k, n:2 * n, :d] = -A
-            A2[k, :n, dmax - 1] = np.where(eq, 0.0, 1.0); A2[k, n:2 * n, dmax - 1] = np.where(eq, 0.0, 1.0)
-            l2[k, :n] = l; l2[k, n:2 * n] = -u                     # A x + eps >= l, -A x + eps >= -u  (eps off on equality rows)
-            A2[k, mmax - 1, dmax - 1] = 1.0; l2[k, mmax - 1] = -slack_cap
-        st, x, _ = _solve_lps(cost, A2, l2, u2, engine)
-        for k, (A, l, u) in enumerate(part):
-            if st[k] == 1 and x[k, dmax - 1] <= 1e-6:
-                out[c0 + k] = x[k, :np.atleast_2d(A).shape[1]].copy()
+    # queries over polyhedra of one size (rows, columns) are packed together, straight into the ABI's column-major blocks: a level
+    # asks tens of thousands of them, a Python loop per record costs more than their solve.  The counts of equality / lower /
+    # upper rows differ from piece to piece: the free block is padded with idle multipliers (a unit diagonal entry, no coupling:
+    # mu = 0) and the rows with inert ones (0'z in (-inf, inf)) up to the group's largest, so that a level is a handful of calls
+    groups = {}
+    prepared = []
+    for i, (A, l, u) in enumerate(trips):
+        A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+        l = np.asarray(l, dtype=np.float64); u = np.asarray(u, dtype=np.float64)
+        prepared.append((A, l, u))
+        groups.setdefault((A.shape[0], A.shape[1]), []).append(i)
+    for (r, d), idx_all in sorted(groups.items()):
+        for c0 in range(0, len(idx_all), chunk):
+            idx = idx_all[c0:c0 + chunk]
+            B = len(idx)
+            A = np.stack([prepared[i][0] for i in idx]).reshape(B, r, d)
+            l = np.stack([prepared[i][1] for i in idx]).reshape(B, r); u = np.stack([prepared[i][2] for i in idx]).reshape(B, r)
+            eq = np.isfinite(l) & (l == u)
+            lo = ~eq & np.isfinite(l); hi = ~eq & np.isfinite(u)
+            ne, nlo, nhi = int(eq.sum(1).max(initial=0)), int(lo.sum(1).max(initial=0)), int(hi.sum(1).max(initial=0))
+
+            def pick(mask, cnt):                                  # first `cnt` row indices with the mask set, ascending; valid flags
+                order = np.argsort(~mask, axis=1, kind="stable")[:, :cnt]
+                return order, np.take_along_axis(mask, order, axis=1)
+
+            (E, Ev), (LO, LOv), (HI, HIv) = pick(eq, ne), pick(lo, nlo), pick(hi, nhi)
+            rows_of = lambda sel, valid: np.take_along_axis(A, sel[:, :, None], axis=1) * valid[:, :, None]
+            nf = d + 1 + ne                                       # free block: [x; eps; mu_E]
+            mi = nlo + nhi
+            mp = max(16, -(-mi // 16) * 16)
+            Qc = np.zeros((B, nf, nf)); qd = np.zeros((B, nf)); Ac = np.zeros((B, nf, mp))
+            ll = np.full((B, mp), -INF); uu = np.full((B, mp), INF)
+            ar = np.arange(d + 1)
+            Qc[:, ar, ar] = delta
+            qd[:, d] = 1.0
+            if ne:
+                AE = rows_of(E, Ev)                               # [B, ne, d], zero rows in the idle slots
+                # math layout: Qd' = [[delta I, -A_E'], [A_E, 0]] (eps column of A_E is 0); Qc is its transpose per item
+                Qc[:, d + 1:, :d] = -AE
+                Qc[:, :d, d + 1:] = np.swapaxes(AE, 1, 2)
+                je = d + 1 + np.arange(ne)
+                Qc[:, je, je] = np.where(Ev, 0.0, 1.0)            # idle multipliers: 1 * mu = 0
+                qd[:, d + 1:] = np.where(Ev, -np.take_along_axis(l, E, axis=1), 0.0)
+            if nlo:
+                Ac[:, :d, :nlo] = np.swapaxes(rows_of(LO, LOv), 1, 2); Ac[:, d, :nlo] = np.where(LOv, 1.0, 0.0)
+                ll[:, :nlo] = np.where(LOv, np.take_along_axis(l, LO, axis=1), -INF)
+            if nhi:
+                Ac[:, :d, nlo:mi] = np.swapaxes(rows_of(HI, HIv), 1, 2); Ac[:, d, nlo:mi] = np.where(HIv, -1.0, 0.0)
+                uu[:, nlo:mi] = np.where(HIv, np.take_along_axis(u, HI, axis=1), INF)
+            res = engine.solve_nodes(Qc, np.zeros((B, 1, nf)), qd, Ac, np.zeros((B, 1, mp)), ll, uu, np.zeros(1))
+            st = np.asarray(res["status"]); z = np.asarray(res["z"])
+            ok = (st == 1) & (z[:, d] <= 1e-6)
+            for k in np.nonzero(ok)[0]:
+                out[idx[k]] = z[k, :d].copy()
     return out
 
 
