@@ -711,10 +711,11 @@ __global__ __launch_bounds__(TPB) void schur_big_finish(AviBatchArgs a, SchurBig
 #define LSTAMP(slot) do { } while (0)
 #endif
 template <int KP>
-__global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigWs w, double *dict, int m_lo, int m_hi)
+__global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigWs w, double *dict, int m_lo, int m_hi, int after_bpp)
 {
     const int tid = threadIdx.x, b = blockIdx.x;
     if (a.status[b] != -2) return;
+    if (after_bpp && w.st2[b] == QPN_SUCCESS) return;       // schur_big_bpp (below) has finished this node and written lambda
 #ifdef QPN_STAMPS
     // (diagnostic builds: thread 0's clocks per phase, second half of a [2][batch][8] buffer -- tools/big2_stamps.py)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1002,6 +1003,315 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
     if (tid == 0) { w.st2[b] = status; w.piv2[b] = pivots; }
 }
 
+
+// ---- Stage B by BLOCK PRINCIPAL PIVOTING (symmetric Schur problems) ----------------------------------------------------------
+// The m x m problem of the kernel above -- s = S lambda + c in [l, u], lambda >= 0 only where s = l, <= 0 only where s = u -- with
+// S = Ad H^-1 Ad' SYMMETRIC positive definite on the active rows (the caller vouches for a symmetric H: resident records whose Qd
+// blocks are bitwise symmetric).  Lemke's method changes ONE basic variable per pivot and each pivot walks a row and a column
+// of the 256 x 257 dictionary (plus its share of the folds): ~100 pivots x 75 KB per node.  Block principal pivoting (Judice &
+// Pires) changes ALL violated complementarity pairs at once: with the set A of rows held at a bound,
+//       lambda_A = S_AA^-1 (t_A - c_A),   lambda_I = 0,   s = S(:, A) lambda_A + c,
+// rows of A whose multiplier has the wrong sign leave, rows outside A that violate their interval enter, and that is repeated
+// until nothing changes: 6 - 9 rounds on config 5's nodes, each round a Cholesky factorisation of the |A| <= 112 active rows in
+// LDS (16 x 16 tiles, packed lower triangle, the updates on the matrix cores) and two passes over the |A| active ROWS of S
+// (coalesced; symmetry turns the column block S(:, A) into rows).  Safeguard: the number of violated pairs has to reach a new
+// minimum within three rounds, otherwise only the violated pair with the highest index is changed (Murty's rule: finite for
+// the P-matrices at hand).  More than KMAX rows at a bound are admitted lowest index first (the rest waits: the set shrinks
+// towards the ~80 that are active at the solution).  A node this kernel does not finish -- a pivot of the factorisation below
+// 1e-13 of its diagonal, more than BPP_MAX_IT rounds, m > 256 -- keeps st2 = BPP_NOT_SOLVED and the Lemke kernel takes it as
+// before; the post-check on the original blocks certifies the result either way.
+constexpr int BPP_KMAX = 112, BPP_TLD = 17, BPP_TSZ = 16 * BPP_TLD, BPP_MAX_IT = 30;
+constexpr int BPP_NOT_SOLVED = -7;
+__host__ __device__ constexpr int bpp_tiles(int T) { return T * (T + 1) / 2; }
+__device__ __forceinline__ int bpp_toff(int i, int j) { return (i * (i + 1) / 2 + j) * BPP_TSZ; }
+
+struct BppShared {
+    double rhs[BPP_KMAX + 16];      // t_A - c_A, then y, then lambda_A (by position in the active list)
+    int aidx[BPP_KMAX + 16];        // active list: position -> row
+    int posof[TPB];                 // row -> position in the active list, or -1
+    int cnt[TPB / 64];
+    double red[TPB / 64];
+    int redi[TPB / 64];
+    int fail;
+};
+
+__device__ __forceinline__ void bpp_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive prefix count of `flag` over the block in thread order, and the total
+__device__ __forceinline__ int bpp_prefix(bool flag, int &total, BppShared &B, int tid)
+{
+    const unsigned long long bal = qpn_ballot(flag);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) B.cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < TPB / 64; ++k) { const int c = B.cnt[k]; if (k < wv) before += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return before + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(TPB, 2) void schur_big_bpp(AviBatchArgs a, SchurBigWs w, double *dict)
+{
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (a.status[b] != -2) return;
+    const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
+    const int m = w.nred[b];
+    if (m < 1 || m > TPB || w.s_rowmajor != 2) { if (tid == 0) w.st2[b] = BPP_NOT_SOLVED; return; }
+    const int ldp = (m + 1 + 15) & ~15;
+    const int ld = ((long long)m * ldp <= (long long)a.N * (a.N + 1)) ? ldp : m + 1;      // (as the Lemke kernel reads T_base)
+    const size_t vo = (size_t)b * (size_t)a.N;
+    const double *Tb = dict + (size_t)b * (size_t)a.N * (size_t)(a.N + 1);
+    __shared__ BppShared B;
+    extern __shared__ __attribute__((aligned(16))) double tiles[];       // packed lower triangle of 16 x 16 tiles, row stride 17
+
+    const bool act = tid < m;
+    const double ci = act ? w.c[vo + tid] : 0.0;
+    const double li = act ? w.l2[vo + tid] : -QINF, ui = act ? w.u2[vo + tid] : QINF;
+    // an equality row (its multiplier is free) is not this method's case
+    if (__syncthreads_or(act && li == ui)) { if (tid == 0) w.st2[b] = BPP_NOT_SOLVED; return; }
+    for (int e = tid; e < bpp_tiles(BPP_KMAX / 16) * BPP_TSZ; e += TPB) tiles[e] = 0.0;
+    if (tid == 0) B.fail = 0;
+    // scale of the problem for the two tests below
+    double cs = act ? fabs(ci) : 0.0;
+    if (act && li > -QINF) cs = fmax(cs, fabs(li));
+    if (act && ui < QINF) cs = fmax(cs, fabs(ui));
+    const double scale = fmax(1.0, sb_block_max(cs, B, tid));
+    const double tol_s = 1e-10 * scale;
+
+    int st = 0;                         // 0: lambda = 0, s free in [l, u]; 1: s = l; 2: s = u
+    double lam = 0.0, s = ci;
+    {
+        const bool viol = act && (s < li - tol_s || s > ui + tol_s);
+        int total;
+        const int pos = bpp_prefix(viol, total, B, tid);
+        if (viol && pos < BPP_KMAX) st = s < li ? 1 : 2;
+    }
+    int nbest = m + 1, patience = 3, changes = 0;
+    bool solved = false, failed = false;
+    for (int it = 0; it < BPP_MAX_IT; ++it) {
+        // ---- the active list (ascending rows)
+        int k;
+        const int mypos = bpp_prefix(st != 0, k, B, tid);
+        B.posof[tid] = st != 0 ? mypos : -1;
+        if (st != 0) { B.aidx[mypos] = tid; B.rhs[mypos] = (st == 1 ? li : ui) - ci; }
+        const int T = (k + 15) >> 4, kp = 16 * T;
+        if (tid >= k && tid < kp) { B.aidx[tid] = 0; B.rhs[tid] = 0.0; }
+        __syncthreads();
+        if (k > 0) {
+            // ---- S_AA (lower triangle) into the tiles: wave <-> active row, lanes <-> the row's 256 entries (coalesced)
+            // (four rows of a wave in flight: 16 loads, then their scatter)
+            for (int a0 = wave; a0 < kp; a0 += 16) {
+                double v[4][TPB / 64];
+                int pc[TPB / 64];
+#pragma unroll
+                for (int q = 0; q < TPB / 64; ++q) { const int col = lane + 64 * q; pc[q] = col < m ? B.posof[col] : -1; }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ar = a0 + 4 * rr;
+                    const double *row = Tb + (size_t)B.aidx[ar < k ? ar : 0] * ld;
+#pragma unroll
+                    for (int q = 0; q < TPB / 64; ++q) { const int col = lane + 64 * q; v[rr][q] = (ar < k && pc[q] >= 0 && pc[q] <= ar) ? row[col] : 0.0; }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ar = a0 + 4 * rr;
+                    if (ar >= kp) break;                                  // (wave-uniform)
+                    const int ti = ar >> 4, ri = ar & 15;
+                    if (ar < k) {
+#pragma unroll
+                        for (int q = 0; q < TPB / 64; ++q) {
+                            const int p = pc[q];
+                            if (p >= 0 && p <= ar) tiles[bpp_toff(ti, p >> 4) + ri * BPP_TLD + (p & 15)] = v[rr][q];
+                        }
+                    } else {
+                        // padding up to a whole tile: the identity
+                        for (int p = lane; p <= ar; p += 64) tiles[bpp_toff(ti, p >> 4) + ri * BPP_TLD + (p & 15)] = p == ar ? 1.0 : 0.0;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- blocked Cholesky, right-looking; the diagonal tiles end up holding the INVERSES of their factors
+            for (int j = 0; j < T; ++j) {
+                if (wave == 0) {
+                    double *const D = tiles + bpp_toff(j, j);
+                    const int r = lane & 15;
+                    double av[16], dinv[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) av[c] = D[r * BPP_TLD + c];
+                    const double d0 = fabs(readlane_f64(av[0], 0));
+                    bool bad = false;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const double pv = readlane_f64(av[c], c);
+                        if (!(pv > 1e-13 * fmax(d0, 1.0))) bad = true;
+                        // 1 / sqrt(pv): the hardware estimate and three Newton steps (no fp64 sqrt / division on the serial chain)
+                        const double pq = bad ? 1.0 : pv;
+                        double rs = __builtin_amdgcn_rsq(pq);
+#pragma unroll
+                        for (int nw = 0; nw < 3; ++nw) { const double e_ = fma(-pq * rs, rs, 1.0); rs = fma(0.5 * rs, e_, rs); }
+                        dinv[c] = rs;
+                        const double lcol = av[c] * rs;
+                        av[c] = lcol;
+#pragma unroll
+                        for (int c2 = c + 1; c2 < 16; ++c2) av[c2] = fma(-lcol, readlane_f64(lcol, c2), av[c2]);
+                    }
+                    // column `r` of the inverse: x_i = (delta_ir - sum_{t < i} L_it x_t) / L_ii
+                    double x[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        double acc = i == r ? 1.0 : 0.0;
+#pragma unroll
+                        for (int t = 0; t < i; ++t) acc = fma(-readlane_f64(av[t], i), x[t], acc);
+                        x[i] = acc * dinv[i];
+                    }
+                    if (lane < 16) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) D[i * BPP_TLD + r] = x[i];
+                    }
+                    if (bad && lane == 0) B.fail = 1;
+                }
+                __syncthreads();
+                if (B.fail) break;                                        // (uniform)
+                // panel: L(i, j) = A(i, j) Linv' -- one tile per wave at a time
+                {
+                    const double *const Li = tiles + bpp_toff(j, j);
+                    for (int i = j + 1 + wave; i < T; i += 4) {
+                        double *const Aij = tiles + bpp_toff(i, j);
+                        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) acc = MFMA(Aij[lc * BPP_TLD + 4 * s4 + lq], Li[lc * BPP_TLD + 4 * s4 + lq], acc);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) Aij[(4 * g + lq) * BPP_TLD + lc] = acc[g];
+                    }
+                }
+                __syncthreads();
+                // trailing update: A(i, l) -= L(i, j) L(l, j)' for j < l <= i
+                {
+                    const int nt = T - 1 - j, np_ = nt * (nt + 1) / 2;
+                    for (int idx = wave; idx < np_; idx += 4) {
+                        int ii = 0, rem = idx;
+                        while (rem > ii) { rem -= ii + 1; ii++; }         // idx = ii (ii + 1) / 2 + rem, rem <= ii
+                        const int i = j + 1 + ii, l2 = j + 1 + rem;
+                        const double *const Lij = tiles + bpp_toff(i, j), *const Llj = tiles + bpp_toff(l2, j);
+                        double *const C = tiles + bpp_toff(i, l2);
+                        d4 acc;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g] = C[(4 * g + lq) * BPP_TLD + lc];
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) acc = MFMA(-Lij[lc * BPP_TLD + 4 * s4 + lq], Llj[lc * BPP_TLD + 4 * s4 + lq], acc);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) C[(4 * g + lq) * BPP_TLD + lc] = acc[g];
+                    }
+                }
+                __syncthreads();
+            }
+            if (B.fail) { failed = true; break; }
+            // ---- L y = b, L' x = y on wave 0 (two rows per lane; diagonal tiles hold inverses)
+            if (wave == 0) {
+                for (int j = 0; j < T; ++j) {
+                    const double *const Li = tiles + bpp_toff(j, j);
+                    double yv = 0.0;
+                    if (lane < 16) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) yv = fma(Li[lane * BPP_TLD + c], B.rhs[16 * j + c], yv);
+                    }
+                    bpp_wave_sync();
+                    if (lane < 16) B.rhs[16 * j + lane] = yv;
+                    bpp_wave_sync();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = lane + 64 * h;
+                        if (row >= 16 * (j + 1) && row < kp) {
+                            const double *const Lr = tiles + bpp_toff(row >> 4, j) + (row & 15) * BPP_TLD;
+                            double acc = B.rhs[row];
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) acc = fma(-Lr[c], B.rhs[16 * j + c], acc);
+                            B.rhs[row] = acc;
+                        }
+                    }
+                    bpp_wave_sync();
+                }
+                for (int j = T - 1; j >= 0; --j) {
+                    // x_j = Linv_jj' r_j (lane <-> column c of tile column j: x_c = sum_{r >= c} Linv(r, c) r_r) ...
+                    const double *const Li = tiles + bpp_toff(j, j);
+                    double xv = 0.0;
+                    if (lane < 16) {
+#pragma unroll
+                        for (int r2 = 0; r2 < 16; ++r2) xv = fma(Li[r2 * BPP_TLD + lane], B.rhs[16 * j + r2], xv);
+                    }
+                    bpp_wave_sync();
+                    if (lane < 16) B.rhs[16 * j + lane] = xv;
+                    bpp_wave_sync();
+                    // ... then every earlier position gives up its share: r_p -= sum_r L(16 j + r, p) x_r  (two positions per lane)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int pcol = lane + 64 * h;
+                        if (pcol < 16 * j) {
+                            const double *const Lc = tiles + bpp_toff(j, pcol >> 4) + (pcol & 15);
+                            double acc = B.rhs[pcol];
+#pragma unroll
+                            for (int r2 = 0; r2 < 16; ++r2) acc = fma(-Lc[r2 * BPP_TLD], B.rhs[16 * j + r2], acc);
+                            B.rhs[pcol] = acc;
+                        }
+                    }
+                    bpp_wave_sync();
+                }
+            }
+            __syncthreads();
+        }
+        // ---- lambda, s = c + S(:, A) lambda_A (S symmetric: rows A of T_base, coalesced over this thread's column)
+        lam = st != 0 ? B.rhs[mypos] : 0.0;
+        double acc0 = ci, acc1 = 0.0;
+        if (act) {
+            int a0 = 0;
+            for (; a0 + 8 <= k; a0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = Tb[(size_t)B.aidx[a0 + q] * ld + tid];
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) { acc0 = fma(v[q], B.rhs[a0 + q], acc0); acc1 = fma(v[q + 1], B.rhs[a0 + q + 1], acc1); }
+            }
+            for (; a0 < k; ++a0) acc0 = fma(Tb[(size_t)B.aidx[a0] * ld + tid], B.rhs[a0], acc0);
+        }
+        s = st == 1 ? li : (st == 2 ? ui : acc0 + acc1);
+        // ---- violated pairs
+        const double lmax = sb_block_max(fabs(lam), B, tid);
+        const double tol_l = 1e-10 * fmax(1.0, lmax);
+        const bool bad_l = (st == 1 && lam < -tol_l) || (st == 2 && lam > tol_l);
+        const bool bad_s = act && st == 0 && (s < li - tol_s || s > ui + tol_s);
+        const bool bad = bad_l || bad_s;
+        const int nb = sb_block_sum_i(bad ? 1 : 0, B, tid);
+        if (nb == 0) { solved = true; break; }
+        bool flip = bad;
+        if (nb < nbest) { nbest = nb; patience = 3; }
+        else if (patience > 0) patience--;
+        else {
+            const int last = -sb_block_min_i(bad ? -tid : 1, B, tid);     // the violated pair with the highest index alone
+            flip = bad && tid == last;
+        }
+        const bool leave = flip && st != 0, enter = flip && st == 0;
+        const int nleave = sb_block_sum_i(leave ? 1 : 0, B, tid);
+        int nenter;
+        const int rank = bpp_prefix(enter, nenter, B, tid);
+        const int room = BPP_KMAX - (k - nleave);
+        if (leave) st = 0;
+        if (enter && rank < room) st = s < li ? 1 : 2;
+        changes += nleave + (nenter < room ? nenter : room);
+        __syncthreads();                // (B.rhs / aidx are rewritten at the top of the next round)
+    }
+    if (solved && !failed) {
+        if (act) w.lam[vo + tid] = lam;
+        if (tid == 0) { w.st2[b] = QPN_SUCCESS; w.piv2[b] = changes; }
+    } else if (tid == 0) w.st2[b] = BPP_NOT_SOLVED;
+}
+
 } // namespace
 
 size_t qpn_schur_big_workspace_bytes(int batch, int N)
@@ -1072,7 +1382,7 @@ hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &
 
 // Lemke on the Schur problems of the accepted items (status -2) with delayed updates; `dict` is the large-item
 // kernel's dictionary workspace (batch x N x (N+1) doubles), reused here as T_base.
-hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream)
+hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream, int after_bpp)
 {
     static QpnPerDeviceOnce attr_once;
     const int attr_dev = attr_once.device();
@@ -1103,10 +1413,26 @@ hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w
         const int KP = bytes_for(16, m_hi) <= 78 * 1024 ? 16 : 8;
         const size_t bytes = bytes_for(KP, m_hi);
         if (bytes > 150 * 1024) return hipErrorInvalidValue;
-        if (KP == 16) hipLaunchKernelGGL(schur_big_lemke<16>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict, m_lo, m_hi);
-        else hipLaunchKernelGGL(schur_big_lemke<8>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict, m_lo, m_hi);
+        if (KP == 16) hipLaunchKernelGGL(schur_big_lemke<16>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict, m_lo, m_hi, after_bpp);
+        else hipLaunchKernelGGL(schur_big_lemke<8>, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict, m_lo, m_hi, after_bpp);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// Stage B by block principal pivoting for the nodes whose Schur problem is symmetric (the caller's promise); what it does not
+// finish keeps st2 = BPP_NOT_SOLVED for the Lemke kernel (launch it with after_bpp = 1).
+hipError_t qpn_launch_schur_big_bpp(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream)
+{
+    const size_t bytes = (size_t)bpp_tiles(BPP_KMAX / 16) * BPP_TSZ * sizeof(double);       // 60 928 B: two workgroups per CU
+    static QpnPerDeviceOnce attr_once;
+    const int attr_dev = attr_once.device();
+    if (!attr_once.done[attr_dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(schur_big_bpp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        attr_once.done[attr_dev] = true;
+    }
+    hipLaunchKernelGGL(schur_big_bpp, dim3((unsigned)a.batch), dim3(TPB), bytes, stream, a, w, dict);
+    return hipGetLastError();
 }

@@ -1001,7 +1001,12 @@ int solve_nodes_launch(qpn_ctx *ctx, qpn_nodes *h, int32_t batch, int32_t n, int
         double *dict = wbig;
         void *sb = wbig + (size_t)batch * (size_t)N * (size_t)(N + 1);
         HIPCHK(ctx, qpn_launch_schur_big2_stage_a(a, sb, dict, &sw, s));
-        HIPCHK(ctx, qpn_launch_schur_big_lemke(a, sw, dict, s));
+        // Stage B: resident records with symmetric Qd blocks (a.nd.sym) go through block principal pivoting first; whatever it
+        // leaves (and every node otherwise) is the delayed-update Lemke kernel's
+        // (a caller-set pivot budget is Lemke's to count: its pivots are the unit of max_pivots)
+        const bool bpp = a.nd.sym && o.max_pivots <= 0;
+        if (bpp) HIPCHK(ctx, qpn_launch_schur_big_bpp(a, sw, dict, s));
+        HIPCHK(ctx, qpn_launch_schur_big_lemke(a, sw, dict, s, bpp ? 1 : 0));
         HIPCHK(ctx, qpn_launch_schur_big2_finish(a, sw, s));
         HIPCHK(ctx, qpn_launch_assemble_nodes(batch, n, m, p, d.Q, d.R, d.q, d.A, d.B, d.l, d.u, d.w, stride_w, wM, wq, wl,
                                               wu, wk, s, d.st, -1));

@@ -111,7 +111,8 @@ struct SchurBigWs {
 size_t qpn_schur_big_workspace_bytes(int batch, int N);
 hipError_t qpn_launch_schur_big_stage_a(const AviBatchArgs &a, void *ws, SchurBigWs *out, int s_rowmajor, hipStream_t stream);
 hipError_t qpn_launch_schur_big_finish(const AviBatchArgs &a, const SchurBigWs &w, hipStream_t stream);
-hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream);
+hipError_t qpn_launch_schur_big_lemke(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream, int after_bpp = 0);
+hipError_t qpn_launch_schur_big_bpp(const AviBatchArgs &a, const SchurBigWs &w, double *dict, hipStream_t stream);   // symmetric S only
 
 // qpn_avi_schur_big2.hip: the same stage A straight from node records (64 < n <= 256, m <= 256), rank-64 block pivots, one
 // workgroup of 16 wavefronts per node; its finish reads the records too.  Same workspace views: the Lemke kernel above runs

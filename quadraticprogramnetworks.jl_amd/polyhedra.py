@@ -269,17 +269,14 @@ def remove_subsets_many(lists, engine, tol=1e-6, prefilter=True):
                 ax = A2 @ pts[:A2.shape[1]]
                 out = np.any(ax < (l2 - 10 * tol)[:, None], axis=0) | np.any(ax > (u2 + 10 * tol)[:, None], axis=0)
                 refuted[have, j] = out
-        for i in range(k):
-            for j in range(k):
-                if i == j:
-                    continue
-                if refuted[i, j]:
-                    sub[(a, i, j)] = False
-                else:
-                    jobs.append((trips[i], trips[j])); where.append((a, i, j))
+        sub[a] = np.zeros((k, k), bool)                     # (refuted pairs: not a subset)
+        open_ = ~refuted
+        np.fill_diagonal(open_, False)
+        for i, j in np.argwhere(open_).tolist():
+            jobs.append((trips[i], trips[j])); where.append((a, i, j))
     res = issubset_batch_chunked(jobs, engine, tol=tol) if jobs else []
-    for key, r in zip(where, res):
-        sub[key] = bool(r)
+    for (a, i, j), r in zip(where, res):
+        sub[a][i, j] = bool(r)
     out = []
     for a, polys in enumerate(lists):
         if comp[a] is None:
@@ -288,7 +285,7 @@ def remove_subsets_many(lists, engine, tol=1e-6, prefilter=True):
         k = len(polys)
         is_subset = np.zeros(k, bool)
         for i in range(k):
-            if any(j != i and not is_subset[j] and sub[(a, i, j)] for j in range(k)):
+            if np.any(sub[a][i] & ~is_subset):              # (the diagonal is never set)
                 is_subset[i] = True
         out.append([P for P, s_ in zip(polys, is_subset) if not s_])
     return out

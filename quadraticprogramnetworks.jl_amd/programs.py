@@ -208,6 +208,8 @@ class Poly:
         cols = np.asarray(cols, dtype=np.int64)
         if self._cols is None:
             return self._A[:, cols]
+        if cols.size == self._cols.size and np.array_equal(cols, self._cols):
+            return self._A                                         # (the rows' own columns: no copy -- callers read it or stack it)
         pos, ok = _positions(self._cols, cols)
         return np.where(ok[None, :], self._A[:, pos] if self._cols.size else 0.0, 0.0)
 

@@ -63,11 +63,15 @@ def test_config5_handle_route_and_shards(engine, full5):
     from qpn_amd import _lib
     nodes = engine.upload_nodes(*dev[:-1])
     assert nodes.info()["symmetric"]
-    # resident records with symmetric Qd blocks form only the upper triangle of S = A H^-1 A' (QPN_OPT_SYM_ROUTE): equal to the
-    # per-call route to rounding; with the option off the handle runs the per-call route's kernels -- bit for bit its answer
+    # resident records with symmetric Qd blocks (QPN_OPT_SYM_ROUTE, the default): at this size Stage B of every node is block
+    # principal pivoting (schur_big_bpp) with the delayed-update Lemke kernel behind it for what it leaves -- another method on the
+    # same Schur problem: the same solution to rounding, the same active sets, its own count of basis changes (in `pivots`: the n
+    # crash pivots + the complementarity pairs it switched); with the option off the handle runs the per-call route's kernels --
+    # bit for bit its answer
     sym = {k: v.cpu().numpy() for k, v in nodes.solve(dev[-1]).items()}
-    for k in ("status", "active", "pivots"):
+    for k in ("status", "active"):
         assert np.array_equal(sym[k], res[k]), k
+    assert np.all(sym["pivots"] > N_) and np.max(sym["resid"]) <= 1e-8
     assert np.max(np.abs(sym["z"] - res["z"])) <= 1e-10 * max(1.0, np.max(np.abs(res["z"])))
     engine.set_option(_lib.OPT_SYM_ROUTE, 0)
     try:
