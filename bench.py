@@ -646,8 +646,9 @@ def cpu_baseline(np, Q, R, qd, A, B, l, u, w, budget_s=1.0):
 
 def run_config5(env, args):
     """BASELINE configs[4]: 512 nodes x 256 variables (n = m = 256, N_red = 512), the large per-node KKT path (blocked MFMA
-    crash + delayed-update Lemke, csrc/qpn_avi_schur_big.hip).  Bound: fp64 matrix/vector pipe; flops per solve =
-    N^3/3 (one factorisation) + 2 N^2 per Lemke pivot, pivots from the kernel's own counter."""
+    crash, then Stage B by block principal pivoting with the delayed-update Lemke kernel behind it, csrc/qpn_avi_schur_big*.hip).
+    Bound: fp64 matrix/vector pipe; flops per solve = N^3/3 (one factorisation) + 2 N^2 per Lemke pivot,
+    the pivots counted by the Lemke kernel on the same records (one untimed sweep)."""
     np, torch = env["np"], env["torch"]
     eng, world, rank, dev = env["eng"], env["world"], env["rank"], env["dev"]
     from qpn_amd import sharding, synthetic
@@ -667,6 +668,13 @@ def run_config5(env, args):
         ring_host = ring_host + 0.25 * np.random.Generator(np.random.Philox(key=[synthetic.SEED, 2 ** 41])).standard_normal((RING, p))
     ring = t(ring_host)
     from qpn_amd import _lib as qlib
+    # the work of a solve by SURVEY.md section 8(d)'s count is that of the pivotal method (N^3/3 + 2 N^2 per complementary pivot):
+    # the pivots are counted ONCE, untimed, on the Lemke route (QPN_OPT_SYM_ROUTE = 0), so that the figure does not move with the
+    # method Stage B runs in the timed loop (block principal pivoting switches ~220 pairs in ~7 rounds where Lemke makes ~100 pivots)
+    eng.set_option(qlib.OPT_SYM_ROUTE, 0)
+    handle = eng.upload_nodes(*drec)
+    ref_piv = float(handle.solve(t(w_host))["pivots"].double().mean().item())
+    handle.close()
     eng.set_option(qlib.OPT_SYM_ROUTE, args.sym_route)
     handle = eng.upload_nodes(*drec)
     steps = min(args.steps, 50)
@@ -697,11 +705,12 @@ def run_config5(env, args):
     mean_piv = float(piv_sum.item()) / (steps * cnt)
     # the kernel's counter includes the n crash pivots (all free variables enter): those ARE the factorisation (N^3/3);
     # the 2 N^2 term is per complementary (Lemke) pivot after it
-    flops = N ** 3 / 3.0 + 2.0 * N * N * max(mean_piv - n, 0.0)
+    lemke_piv = max(ref_piv - n, 0.0)
+    flops = N ** 3 / 3.0 + 2.0 * N * N * lemke_piv
     achieved = flops * cnt / (ms * 1e-3) / 1e12
     # what the Lemke phase EXECUTES: an exchange on the m x (m + 1) Schur dictionary is 2 m (m + 1) flops, not the 2 N^2 of the
     # N x N formula (the crash took the n free variables out first); the factorisation term is left as the formula has it
-    flops_exec = N ** 3 / 3.0 + 2.0 * m * (m + 1) * max(mean_piv - n, 0.0)
+    flops_exec = N ** 3 / 3.0 + 2.0 * m * (m + 1) * lemke_piv
     traffic = None; traffic_src = None
     try:
         pj = os.path.join(ROOT, "profiles", "r04_c5_pmc_summary.json")
@@ -718,17 +727,21 @@ def run_config5(env, args):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic {total}-node x {n}-var QPNet (n=m={n}, N_red={N}, p={p}; BASELINE.json configs[4]); step = "
                                "KKT assembly + cold-start AVI solve + check + active sets + primal write-back over resident node "
-                               f"records (qpn_solve_nodes_h -> blocked MFMA crash straight from the records + delayed-update Lemke); ring of {RING} "
-                               "parameter vectors",
-                   "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p, "mean_pivots": mean_piv, "mean_lemke_pivots": mean_piv - n,
+                               f"records (qpn_solve_nodes_h -> blocked MFMA crash straight from the records + Stage B by "
+                               + ("block principal pivoting, the delayed-update Lemke kernel behind it" if args.sym_route else "the delayed-update Lemke kernel")
+                               + f"); ring of {RING} parameter vectors",
+                   "nodes": total, "nodes_per_gpu": cnt, "n": n, "m": m, "params": p,
+                   "mean_lemke_pivots": lemke_piv, "mean_lemke_pivots_source": "one untimed sweep of the same records on the Lemke route",
+                   "mean_pivots_reported_by_timed_route": mean_piv,
+                   "stage_b": "block principal pivoting (pivots = n + complementarity pairs switched)" if args.sym_route else "Lemke",
                    "max_resid": float(out["resid"].max().item()), "solved": solved},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                      "traffic": traffic, "counters_source": traffic_src,
                      "algorithmic_bytes_per_step": synthetic.algorithmic_bytes(n, m) * cnt,
-                     "kernel": "schur_big2_convert + schur_big2_eliminate + schur_big2_sprod + schur_big_lemke + schur_big2_finish (per step)", "kernel_ms": ms,
+                     "kernel": "schur_big2_convert + schur_big2_eliminate + schur_big2_sprod + schur_big_bpp / schur_big_lemke + schur_big2_finish (per step)", "kernel_ms": ms,
                      "flops_per_solve": flops, "solves_per_launch": cnt,
-                     "flops_per_solve_executed_in_lemke_phase": flops_exec,
-                     "frac_with_executed_lemke_flops": flops_exec * cnt / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                     "flops_per_solve_with_schur_sized_pivots": flops_exec,
+                     "frac_with_schur_sized_pivots": flops_exec * cnt / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
     }
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         k = min(cnt, 16)

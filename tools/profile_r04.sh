@@ -29,7 +29,7 @@ if [[ $part == verify ]]; then
   done
   calib
   MODE=0 REPS=10 pmc_all verify python3 $R/tools/verify_rate.py
-  for shape in "48 48 4000" "64 64 4000" "64 96 2000" "256 256 512"; do
+  for shape in "48 48 4000" "64 64 4000" "64 96 2000" "128 200 1024" "256 256 512"; do
     set -- $shape
     N=$1 M=$2 CNT=$3 REPS=10 python3 $R/tools/verify_rate.py >> "$O/verify_rate_other.txt" 2>&1
     N=$1 M=$2 CNT=$3 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/verify_trace_$1x$2" -- python3 $R/tools/verify_rate.py > "$O/verify_trace_$1x$2.log" 2>&1

@@ -73,7 +73,8 @@ def family(tag, kname, extra=None):
 for run, name in (("verify_trace", "r04_verify_kernel_stats.csv"), ("verify_trace_mode0", "r04_verify_solution_kernel_stats.csv"),
                   ("verify_trace_mode2", "r04_verify_fallback_kernel_stats.csv"), ("verify_trace_48x48", "r04_verify_48_kernel_stats.csv"),
                   ("verify_trace_64x64", "r04_verify_64_kernel_stats.csv"), ("verify_trace_64x96", "r04_verify_64x96_kernel_stats.csv"),
-                  ("verify_trace_256x256", "r04_verify_256_kernel_stats.csv"), ("trace", "r04_kernel_stats.csv"),
+                  ("verify_trace_256x256", "r04_verify_256_kernel_stats.csv"), ("verify_trace_128x200", "r04_verify_128x200_kernel_stats.csv"),
+                  ("trace", "r04_kernel_stats.csv"),
                   ("trace20", "r04_trace20_kernel_stats.csv"), ("trace5", "r04_trace5_kernel_stats.csv")):
     copy_stats(run, name)
 for f_ in ("verify_rate.txt", "verify_rate_other.txt"):
@@ -106,11 +107,21 @@ if latest("c5_fetch/*/*counter_collection.csv"):
            "workload": "bench.py --config 5: 512 nodes, n = m = 256, one sweep = the launches below", "kernels": {}}
     shorts = sorted({re.search(r"(schur_big\w*(?:<\d+>)?)", r["Kernel_Name"]).group(1)
                      for r in rows("c5_fetch/*/*counter_collection.csv") if "schur_big" in r["Kernel_Name"]})
+    # per SWEEP: a kernel's bytes summed over all its launches, divided by the number of sweeps (= launches of the finish kernel;
+    # some kernels run twice a sweep, the Lemke kernel's launches are empty when block principal pivoting finished every node)
+    sweeps = max(1, len(pmc("c5_fetch/*/*counter_collection.csv", "FETCH_SIZE", "schur_big2_finish(")))
+    out["sweeps_profiled"] = sweeps
     total = 0.0
     for kn in shorts:
         fam = family("c5", kn + "(")
-        out["kernels"][kn] = {k: v for k, v in fam.items() if k in ("hbm", "sq_per_launch")}
-        total += fam.get("hbm", {}).get("hbm_bytes_per_launch", 0.0)
+        ent = {k: v for k, v in fam.items() if k in ("hbm", "sq_per_launch")}
+        f = pmc("c5_fetch/*/*counter_collection.csv", "FETCH_SIZE", kn + "(")
+        wv = pmc("c5_write/*/*counter_collection.csv", "WRITE_SIZE", kn + "(")
+        if f and wv:
+            ent["launches_per_sweep"] = len(f) / sweeps
+            ent["hbm_bytes_per_sweep"] = (sum(f) * cal.get("read8", 2.0) + sum(wv) * cal.get("write8", 1.0)) * 1024.0 / sweeps
+            total += ent["hbm_bytes_per_sweep"]
+        out["kernels"][kn] = ent
     out["hbm_bytes_per_sweep"] = total
     json.dump(out, open(os.path.join(dst, "r04_c5_pmc_summary.json"), "w"), indent=1)
-    print(json.dumps({k: v.get("hbm", {}).get("hbm_bytes_per_launch") for k, v in out["kernels"].items()}, indent=1), total)
+    print(json.dumps({k: v.get("hbm_bytes_per_sweep") for k, v in out["kernels"].items()}, indent=1), total)
