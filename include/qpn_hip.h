@@ -252,9 +252,12 @@ int qpn_ctx_set_auto_schedule(qpn_ctx *ctx, int32_t period);
  *                      records, BASELINE config 5); round 2's route over an assembled M is gone as a node-record switch -- the
  *                      same kernels serve large node-shaped items passed as M through qpn_solve_avi_batch.
  *   QPN_OPT_SYM_ROUTE  resident records (qpn_nodes_upload) whose Qd blocks are ALL bitwise symmetric: 1 = kernel variants that
- *                      use the symmetry of H and of S = A H^-1 A' (default; today n = m = 32: 8 of 88 fp64 MFMAs per solve less),
- *                      0 = the general variants.  Records with any asymmetric Qd, and records passed per call, always take
- *                      the general variants.
+ *                      use the symmetry of H and of S = A H^-1 A' (default; n = m = 32: 8 of 88 fp64 MFMAs per solve less; large
+ *                      nodes, 64 < n <= 256 and m <= 256: the complementarity phase runs as block principal pivoting on the
+ *                      symmetric Schur problem, the Lemke kernel behind it for what it leaves -- `pivots` then reports n + the
+ *                      number of complementarity pairs switched; with a caller-set max_pivots the Lemke kernel, whose pivots
+ *                      that budget counts, runs alone), 0 = the general variants.  Records with any asymmetric Qd, and records
+ *                      passed per call, always take the general variants.
  * A resident handle remembers under which option values it learned that none of its nodes declines; after a change it asks again
  * on its next sweep (another kernel variant applies its pivot test to slightly different numbers). */
 #define QPN_OPT_MID_ROUTE 1
