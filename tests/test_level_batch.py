@@ -214,3 +214,89 @@ def test_engine_double_pieces_agree_with_the_host_restatement(eng):
         got = Poly(Ar[t, :, :r].T, lr[t, :r], ur[t, :r])
         assert got.A.shape == want.A.shape
         assert np.allclose(got.A, want.A, atol=1e-12) and np.allclose(got.l, want.l) and np.allclose(got.u, want.u)
+
+
+# ---- second half of round 4: what keeps a large net's sweeps cheap ------------------------------------------------------------
+def test_free_equalities_is_the_same_complementarity_system(eng):
+    """A record with equality rows, solved as it is and with the equality multipliers moved into the free block
+    (level_batch.free_equalities): the same x, the multipliers of the equality rows equal to the extra free variables, those of the
+    other rows equal -- src/avi.jl:113-128 pairs an equality row with an unbounded multiplier."""
+    from qpn_amd.engine import colmajor
+    import problems as P
+    g = np.random.default_rng(11)
+    n, m, p, cnt = 7, 9, 3, 5
+    Q, R, qd, A, B, l, u = P.synth_nodes(40, cnt, n, m, p)
+    w = g.standard_normal(p)
+    for b in range(cnt):
+        x0 = g.standard_normal(n)
+        E = g.choice(m, 3, replace=False)
+        l[b, E] = u[b, E] = A[b, E] @ x0 + B[b, E] @ w          # three equality rows through a common point: feasible
+    for b in range(cnt):
+        rec = dict(pid=b, dec=np.arange(n), par=np.arange(p), Qd=Q[b], R=R[b], qd=qd[b], Ad=A[b], B=B[b], l=l[b], u=u[b])
+        fr = level_batch.free_equalities(rec)
+        eq = l[b] == u[b]
+        assert fr["nx"] == n and fr["Qd"].shape == (n + 3, n + 3) and fr["Ad"].shape == (m - 3, n + 3) and not np.any(fr["l"] == fr["u"])
+        one = lambda r: eng.solve_nodes(colmajor(r["Qd"][None]), colmajor(r["R"][None]), r["qd"][None], colmajor(r["Ad"][None]),
+                                        colmajor(r["B"][None]), r["l"][None], r["u"][None], w)
+        a, c = one(rec), one(fr)
+        assert int(np.asarray(a["status"])[0]) == 1 == int(np.asarray(c["status"])[0])
+        za, zc = np.asarray(a["z"])[0], np.asarray(c["z"])[0]
+        assert np.max(np.abs(za[:n] - zc[:n])) <= 1e-9
+        assert np.max(np.abs(za[n:][eq] - zc[n:n + 3])) <= 1e-8 and np.max(np.abs(za[n:][~eq] - zc[n + 3:])) <= 1e-8
+    plain = dict(pid=0, dec=np.arange(n), par=np.arange(p), Qd=Q[0], R=R[0], qd=qd[0], Ad=A[0], B=B[0], l=l[0] - 1.0, u=u[0] + 1.0)
+    assert level_batch.free_equalities(plain) is plain          # nothing to move: the record itself
+
+
+def test_results_kept_across_sweeps_change_nothing(eng):
+    """process_level's memo (a node whose subtree variables and children's graphs are unchanged keeps its result) against the same
+    run with the memo cleared before every sweep: the same iterate, bit for bit, and fewer nodes processed."""
+    seen = {"memo": 0, "plain": 0}
+    orig = level_batch.solution_pieces
+
+    def run(clear):
+        def counting(qpn, recs, batches, rets, x, engine, want, **kw):
+            seen["plain" if clear else "memo"] += int(sum(want))
+            return orig(qpn, recs, batches, rets, x, engine, want, **kw)
+        level_batch.solution_pieces = counting
+        orig_pl = level_batch.process_level
+
+        def pl(qpn, players, x, S, engine=None, exploration_vertices=0):
+            if clear:
+                qpn.__dict__["_process_memo"] = {}
+                qpn.__dict__["_subset_memo"] = {}
+            return orig_pl(qpn, players, x, S, engine=engine, exploration_vertices=exploration_vertices)
+        algorithm.process_level = pl
+        try:
+            return algorithm.solve(examples.setup("synthetic_pairs", pairs=10, n=4, m=6), engine=eng)
+        finally:
+            algorithm.process_level = orig_pl
+            level_batch.solution_pieces = orig
+    a, b = run(False), run(True)
+    assert a["solved"] and b["solved"] and np.array_equal(a["x_opt"], b["x_opt"])
+    assert seen["memo"] < seen["plain"]
+
+
+def test_interior_members_are_members_well_inside(eng):
+    """polyhedra.interior_members_batch: the point it returns satisfies the equality rows and sits strictly inside every
+    inequality row that has room; an empty polyhedron gets None; polyhedra of one size with different row kinds share a call."""
+    from qpn_amd import polyhedra
+    g = np.random.default_rng(3)
+    d = 5
+    trips = []
+    for t in range(8):
+        A = g.standard_normal((7, d)); x0 = g.standard_normal(d)
+        s = A @ x0
+        l = s - g.uniform(0.2, 1.0, 7); u = s + g.uniform(0.2, 1.0, 7)
+        l[:t % 3] = u[:t % 3] = s[:t % 3]                       # 0, 1 or 2 equality rows
+        l[5] = -INF
+        trips.append((A, l, u))
+    trips.append((np.array([[1.0, 0, 0, 0, 0], [1.0, 0, 0, 0, 0]]), np.array([1.0, -INF]), np.array([INF, 0.0])))      # x1 >= 1 and x1 <= 0
+    eng.calls.clear()
+    pts = polyhedra.interior_members_batch(trips, eng)
+    assert pts[-1] is None
+    for (A, l, u), x in zip(trips[:-1], pts[:-1]):
+        ax = A @ x
+        eq = l == u
+        assert np.max(np.abs(ax[eq] - l[eq]), initial=0.0) <= 1e-8
+        assert np.all(ax[~eq] >= l[~eq] + 0.05) and np.all(ax[~eq] <= u[~eq] - 0.05)
+    assert eng.calls["solve_nodes"] == 2                          # one call per polyhedron size (7 x 5 and 2 x 5)
