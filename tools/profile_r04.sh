@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Round-4 profile recipe (run on the GPU box through gpurun: `bash tools/profile_r04.sh <part>`, part = verify | bench | c5 | sizes).
+# Round-4 profile recipe (run on the GPU box through gpurun: `bash tools/profile_r04.sh <part>`, part = verify | bench | c5 | mid).
 # Kernel traces and counter passes are separate runs (never --pmc together with tracing); the program itself follows `--`.
 # Raw output under gpurun_out/prof_r04/; tools/summarize_r04.py turns it into the files under profiles/.
 set -euo pipefail
@@ -46,5 +46,14 @@ if [[ $part == c5 ]]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace5" -- python3 $R/bench.py --config 5 --no-cpu-baseline > "$O/trace5.log" 2>&1
   calib
   pmc_all c5 python3 $R/bench.py --config 5 --no-cpu-baseline --steps 12 --warmup 2
+fi
+if [[ $part == mid ]]; then
+  # the mid-size classes (one wavefront per node up to 48, one workgroup per node up to 128) and the wide verify: traces + counters
+  calib
+  for n in 48 64 96 128; do
+    REPS=20 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/mid${n}_trace" -- python3 $R/tools/mid_rate.py $n > "$O/mid${n}_trace.log" 2>&1
+    REPS=6 pmc_all mid$n python3 $R/tools/mid_rate.py $n
+  done
+  N=256 M=256 CNT=512 MODE=0 REPS=10 pmc_all vwide python3 $R/tools/verify_rate.py
 fi
 find "$O" -name "*kernel_stats.csv" | head -40

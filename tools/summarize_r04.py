@@ -125,3 +125,18 @@ if latest("c5_fetch/*/*counter_collection.csv"):
     out["hbm_bytes_per_sweep"] = total
     json.dump(out, open(os.path.join(dst, "r04_c5_pmc_summary.json"), "w"), indent=1)
     print(json.dumps({k: v.get("hbm_bytes_per_sweep") for k, v in out["kernels"].items()}, indent=1), total)
+
+# ---- mid-size classes and the wide verify: counters per launch of the class's kernel
+for n_, kname, nodes in ((48, "avi_solve_schur48", 4000), (64, "schur_wg_nodes", 4000), (96, "schur_wg2_nodes", 1024), (128, "schur_wg2_nodes", 1024)):
+    copy_stats(f"mid{n_}_trace", f"r04_mid{n_}_kernel_stats.csv")
+    if latest(f"mid{n_}_fetch/*/*counter_collection.csv"):
+        rec = 8 * (n_ * n_ + n_ * 8 + n_ + n_ * n_ + n_ * 8 + 2 * n_) * nodes
+        s_ = family(f"mid{n_}", kname, {"workload": f"{nodes} resident node records, n = m = {n_}, p = 8 (tools/mid_rate.py)",
+                                        "records_bytes_per_launch": rec, "outputs_bytes_per_launch": (8 * 2 * n_ + 2 * n_ + 16 + 8 * n_) * nodes})
+        json.dump(s_, open(os.path.join(dst, f"r04_mid{n_}_pmc_summary.json"), "w"), indent=1)
+if latest("vwide_fetch/*/*counter_collection.csv"):
+    n_ = 256; nodes = 512
+    s_ = family("vwide", "verify_wide_node", {"workload": "512 nodes, n = m = 256, p = 8, at the solution (least-squares path on every node)",
+                                              "records_and_point_bytes_per_launch": 8 * (2 * n_ * n_ + 2 * n_ * 8 + 3 * n_ + n_ + 8) * nodes,
+                                              "outputs_bytes_per_launch": (8 * n_ + 8) * nodes})
+    json.dump(s_, open(os.path.join(dst, "r04_verify_wide_pmc_summary.json"), "w"), indent=1)
