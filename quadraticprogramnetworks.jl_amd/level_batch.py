@@ -511,31 +511,61 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         seen = {b.where[k]: set() for k in sel}
         fallback = {}                                        # per node: the piece the point misses least, for a node none of whose
                                                              # pieces passes (a solution graph is never empty, src/qp_processing.jl:233)
-        for t in range(len(node_of)):
-            k = int(rec_of[t]); i = b.where[k]
-            cols_k, take_k = colsel[k]
-            if flags[t]:
-                P = _reduce_on_host(b, k, np.asarray(K)[t], eng)
-                if P is None:
-                    continue
-                Al = np.ascontiguousarray(P[0][:, take_k]); ll, ul = P[1], P[2]
-            else:
-                r = int(rows[t])
-                Al = np.ascontiguousarray(Ar[t, take_k, :r].T)          # [rows, columns ascending] out of [n + p, rows]
-                ll, ul = lr[t, :r], ur[t, :r]
-            Pg = _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, Al, ll, ul))
+        def admit(i, Pg, miss):
             # the parent's verify_solution tests feasibility on exactly these normalised rows with 1e-3 (src/qp_processing.jl:86):
             # a piece the point fails here would be "infeasible" there by construction (MEMBER_TOL)
-            cl, Al_ = Pg.local()
-            ax = Al_ @ x[cl]
-            miss = float(np.max(np.maximum(Pg.l - ax, ax - Pg.u), initial=0.0))
             if miss <= member_tol:
+                cl, Al_ = Pg.local()
                 key = (cl.tobytes(), (np.round(Al_, 6) + 0.0).tobytes(), np.round(np.concatenate([Pg.l, Pg.u]), 6).tobytes())
                 if key not in seen[i]:                       # the reference collects the pieces in a Set (src/avi_solutions.jl:104)
                     seen[i].add(key)
                     out[i].append(Pg)
             elif i not in fallback or miss < fallback[i][0]:
                 fallback[i] = (miss, Pg)
+
+        Rmax = Ar.shape[2]
+        starts = np.searchsorted(rec_of, np.asarray(sel), side="left"); stops = np.searchsorted(rec_of, np.asarray(sel), side="right")
+        for k, t0, t1 in zip(sel, starts.tolist(), stops.tolist()):             # (recipes come record by record, ascending)
+            if t1 <= t0:
+                continue
+            i = b.where[k]
+            cols_k, take_k = colsel[k]
+            ts = np.arange(t0, t1)
+            plain = ts[flags[t0:t1] == 0]
+            miss_of = {}
+            if plain.size:
+                # all of the record's pieces at once: rows over the columns in ascending order, normalised as Poly does
+                # (src/sets.jl:76-89: 1e-8 drop, leading coefficient +1), the point's worst violation per piece
+                A3 = np.ascontiguousarray(np.swapaxes(Ar[plain][:, take_k, :], 1, 2))        # [pieces, Rmax, columns]
+                L2 = lr[plain].astype(np.float64, copy=True); U2 = ur[plain].astype(np.float64, copy=True)
+                A3[np.abs(A3) < 1e-8] = 0.0
+                nzm = A3 != 0
+                has = nzm.any(axis=2)
+                lead = np.where(has, np.take_along_axis(A3, nzm.argmax(axis=2)[..., None], axis=2)[..., 0], 1.0)
+                nrm = np.abs(lead); neg = has & (lead < 0)
+                A3 /= np.where(neg, -nrm, nrm)[..., None]
+                with np.errstate(invalid="ignore"):
+                    ln, un = L2 / nrm, U2 / nrm
+                L2 = np.where(neg, -un, ln); U2 = np.where(neg, -ln, un)
+                ax = A3 @ x[cols_k]
+                live = has & (np.arange(Rmax)[None, :] < rows[plain][:, None])
+                viol = np.where(live, np.maximum(L2 - ax, ax - U2), 0.0)
+                worst = np.max(viol, axis=1, initial=0.0)
+                for j, t in enumerate(plain.tolist()):
+                    r = int(rows[t])
+                    miss_of[t] = (float(worst[j]), A3[j, :r].copy(), L2[j, :r].copy(), U2[j, :r].copy())
+            for t in ts.tolist():
+                if flags[t]:
+                    P = _reduce_on_host(b, k, np.asarray(K)[t], eng)
+                    if P is None:
+                        continue
+                    Pg = _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, np.ascontiguousarray(P[0][:, take_k]), P[1], P[2]))
+                    cl, Al_ = Pg.local()
+                    axp = Al_ @ x[cl]
+                    admit(i, Pg, float(np.max(np.maximum(Pg.l - axp, axp - Pg.u), initial=0.0)))
+                else:
+                    miss, Aj, lj, uj = miss_of[t]
+                    admit(i, _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, Aj, lj, uj, normalise=False)), miss)
         for i, (miss, Pg) in fallback.items():
             if not out[i]:
                 out[i].append(Pg)

@@ -155,11 +155,12 @@ class Poly:
         return P
 
     @classmethod
-    def from_sorted(cls, ncols: int, cols, A, l, u) -> "Poly":
+    def from_sorted(cls, ncols: int, cols, A, l, u, normalise=True) -> "Poly":
         """from_local for columns already ascending and without repeats (the caller vouches: the level batches, whose column
-        lists are a record's own sorted index sets); A [rows, len(cols)] is taken over, not copied."""
+        lists are a record's own sorted index sets); A [rows, len(cols)] is taken over, not copied.  normalise=False: the rows
+        are normalised already (level_batch does that for all pieces of a record at once)."""
         P = cls.__new__(cls)
-        P._init(int(ncols), cols, A, l, u, True, 1e-8, None, None)
+        P._init(int(ncols), cols, A, l, u, normalise, 1e-8, None, None)
         return P
 
     def _init(self, ncols, cols, A, l, u, normalise, tol, open_lo, open_hi):
