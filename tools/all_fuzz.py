@@ -69,7 +69,10 @@ for t in range(trials):
         assert np.array_equal(np.asarray(r["status"]), rc["status"]), (tag, np.asarray(r["status"]), rc["status"])
         ok = rc["status"] == 1
         assert np.array_equal(np.asarray(r["active"])[ok], rc["active"][ok]), tag
-        if name != "explicit":
+        # (resident symmetric records of the large class run Stage B by block principal pivoting unless a pivot budget is set: the
+        #  same solution, its own count of basis changes)
+        bpp = name == "handle" and n > 64 and n <= 256 and m <= 256 and max(n, m) > 128 and og is None
+        if name != "explicit" and not bpp:
             assert np.array_equal(np.asarray(r["pivots"])[ok], rc["pivots"][ok]), (tag, np.asarray(r["pivots"]), rc["pivots"])
         if ok.any():
             d = np.max(np.abs(np.asarray(r["z"])[ok] - rc["z"][ok])) / max(1.0, np.max(np.abs(rc["z"][ok])))
