@@ -22,6 +22,7 @@
 // are solved by the general kernel in a gated launch.  Results: same bar as the small MFMA kernel
 // (summation order differs from the scalar crash; primals to ~1e-12, masks and pivot counts identical).
 #include "qpn_internal.h"
+#include "qpn_tile_chol.h"
 
 #define QINF __builtin_huge_val()
 
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(TPB) void schur_big_lemke(AviBatchArgs a, SchurBigW
 // towards the ~80 that are active at the solution).  A node this kernel does not finish -- a pivot of the factorisation below
 // 1e-13 of its diagonal, more than BPP_MAX_IT rounds, m > 256 -- keeps st2 = BPP_NOT_SOLVED and the Lemke kernel takes it as
 // before; the post-check on the original blocks certifies the result either way.
-constexpr int BPP_KMAX = 112, BPP_TLD = 17, BPP_TSZ = 16 * BPP_TLD, BPP_MAX_IT = 30;
+constexpr int BPP_KMAX = 112, BPP_TLD = TC_TLD, BPP_TSZ = TC_TSZ, BPP_MAX_IT = 30;
 constexpr int BPP_NOT_SOLVED = -7;
 __host__ __device__ constexpr int bpp_tiles(int T) { return T * (T + 1) / 2; }
 __device__ __forceinline__ int bpp_toff(int i, int j) { return (i * (i + 1) / 2 + j) * BPP_TSZ; }
@@ -1034,13 +1035,6 @@ struct BppShared {
     int redi[TPB / 64];
     int fail;
 };
-
-__device__ __forceinline__ void bpp_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // exclusive prefix count of `flag` over the block in thread order, and the total
 __device__ __forceinline__ int bpp_prefix(bool flag, int &total, BppShared &B, int tid)
@@ -1061,7 +1055,7 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_bpp(AviBatchArgs a, SchurBig
 {
     const int tid = threadIdx.x, b = blockIdx.x;
     if (a.status[b] != -2) return;
-    const int wave = tid >> 6, lane = tid & 63, lc = lane & 15, lq = lane >> 4;
+    const int wave = tid >> 6, lane = tid & 63;
     const int m = w.nred[b];
     if (m < 1 || m > TPB || w.s_rowmajor != 2) { if (tid == 0) w.st2[b] = BPP_NOT_SOLVED; return; }
     const int ldp = (m + 1 + 15) & ~15;
@@ -1137,133 +1131,9 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_bpp(AviBatchArgs a, SchurBig
                 }
             }
             __syncthreads();
-            // ---- blocked Cholesky, right-looking; the diagonal tiles end up holding the INVERSES of their factors
-            for (int j = 0; j < T; ++j) {
-                if (wave == 0) {
-                    double *const D = tiles + bpp_toff(j, j);
-                    const int r = lane & 15;
-                    double av[16], dinv[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) av[c] = D[r * BPP_TLD + c];
-                    const double d0 = fabs(readlane_f64(av[0], 0));
-                    bool bad = false;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const double pv = readlane_f64(av[c], c);
-                        if (!(pv > 1e-13 * fmax(d0, 1.0))) bad = true;
-                        // 1 / sqrt(pv): the hardware estimate and three Newton steps (no fp64 sqrt / division on the serial chain)
-                        const double pq = bad ? 1.0 : pv;
-                        double rs = __builtin_amdgcn_rsq(pq);
-#pragma unroll
-                        for (int nw = 0; nw < 3; ++nw) { const double e_ = fma(-pq * rs, rs, 1.0); rs = fma(0.5 * rs, e_, rs); }
-                        dinv[c] = rs;
-                        const double lcol = av[c] * rs;
-                        av[c] = lcol;
-#pragma unroll
-                        for (int c2 = c + 1; c2 < 16; ++c2) av[c2] = fma(-lcol, readlane_f64(lcol, c2), av[c2]);
-                    }
-                    // column `r` of the inverse: x_i = (delta_ir - sum_{t < i} L_it x_t) / L_ii
-                    double x[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        double acc = i == r ? 1.0 : 0.0;
-#pragma unroll
-                        for (int t = 0; t < i; ++t) acc = fma(-readlane_f64(av[t], i), x[t], acc);
-                        x[i] = acc * dinv[i];
-                    }
-                    if (lane < 16) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) D[i * BPP_TLD + r] = x[i];
-                    }
-                    if (bad && lane == 0) B.fail = 1;
-                }
-                __syncthreads();
-                if (B.fail) break;                                        // (uniform)
-                // panel: L(i, j) = A(i, j) Linv' -- one tile per wave at a time
-                {
-                    const double *const Li = tiles + bpp_toff(j, j);
-                    for (int i = j + 1 + wave; i < T; i += 4) {
-                        double *const Aij = tiles + bpp_toff(i, j);
-                        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) acc = MFMA(Aij[lc * BPP_TLD + 4 * s4 + lq], Li[lc * BPP_TLD + 4 * s4 + lq], acc);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) Aij[(4 * g + lq) * BPP_TLD + lc] = acc[g];
-                    }
-                }
-                __syncthreads();
-                // trailing update: A(i, l) -= L(i, j) L(l, j)' for j < l <= i
-                {
-                    const int nt = T - 1 - j, np_ = nt * (nt + 1) / 2;
-                    for (int idx = wave; idx < np_; idx += 4) {
-                        int ii = 0, rem = idx;
-                        while (rem > ii) { rem -= ii + 1; ii++; }         // idx = ii (ii + 1) / 2 + rem, rem <= ii
-                        const int i = j + 1 + ii, l2 = j + 1 + rem;
-                        const double *const Lij = tiles + bpp_toff(i, j), *const Llj = tiles + bpp_toff(l2, j);
-                        double *const C = tiles + bpp_toff(i, l2);
-                        d4 acc;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = C[(4 * g + lq) * BPP_TLD + lc];
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) acc = MFMA(-Lij[lc * BPP_TLD + 4 * s4 + lq], Llj[lc * BPP_TLD + 4 * s4 + lq], acc);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) C[(4 * g + lq) * BPP_TLD + lc] = acc[g];
-                    }
-                }
-                __syncthreads();
-            }
-            if (B.fail) { failed = true; break; }
-            // ---- L y = b, L' x = y on wave 0 (two rows per lane; diagonal tiles hold inverses)
-            if (wave == 0) {
-                for (int j = 0; j < T; ++j) {
-                    const double *const Li = tiles + bpp_toff(j, j);
-                    double yv = 0.0;
-                    if (lane < 16) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) yv = fma(Li[lane * BPP_TLD + c], B.rhs[16 * j + c], yv);
-                    }
-                    bpp_wave_sync();
-                    if (lane < 16) B.rhs[16 * j + lane] = yv;
-                    bpp_wave_sync();
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int row = lane + 64 * h;
-                        if (row >= 16 * (j + 1) && row < kp) {
-                            const double *const Lr = tiles + bpp_toff(row >> 4, j) + (row & 15) * BPP_TLD;
-                            double acc = B.rhs[row];
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) acc = fma(-Lr[c], B.rhs[16 * j + c], acc);
-                            B.rhs[row] = acc;
-                        }
-                    }
-                    bpp_wave_sync();
-                }
-                for (int j = T - 1; j >= 0; --j) {
-                    // x_j = Linv_jj' r_j (lane <-> column c of tile column j: x_c = sum_{r >= c} Linv(r, c) r_r) ...
-                    const double *const Li = tiles + bpp_toff(j, j);
-                    double xv = 0.0;
-                    if (lane < 16) {
-#pragma unroll
-                        for (int r2 = 0; r2 < 16; ++r2) xv = fma(Li[r2 * BPP_TLD + lane], B.rhs[16 * j + r2], xv);
-                    }
-                    bpp_wave_sync();
-                    if (lane < 16) B.rhs[16 * j + lane] = xv;
-                    bpp_wave_sync();
-                    // ... then every earlier position gives up its share: r_p -= sum_r L(16 j + r, p) x_r  (two positions per lane)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int pcol = lane + 64 * h;
-                        if (pcol < 16 * j) {
-                            const double *const Lc = tiles + bpp_toff(j, pcol >> 4) + (pcol & 15);
-                            double acc = B.rhs[pcol];
-#pragma unroll
-                            for (int r2 = 0; r2 < 16; ++r2) acc = fma(-Lc[r2 * BPP_TLD], B.rhs[16 * j + r2], acc);
-                            B.rhs[pcol] = acc;
-                        }
-                    }
-                    bpp_wave_sync();
-                }
-            }
+            // ---- blocked Cholesky and the two triangular solves (qpn_tile_chol.h)
+            if (!tc_factor(tiles, T, &B.fail, 1e-13, tid)) { failed = true; break; }
+            if (wave == 0) tc_solve(tiles, B.rhs, T, lane);
             __syncthreads();
         }
         // ---- lambda, s = c + S(:, A) lambda_A (S symmetric: rows A of T_base, coalesced over this thread's column)

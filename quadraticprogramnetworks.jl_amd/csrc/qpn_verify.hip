@@ -14,6 +14,7 @@
 //   avi_solve_lds1  (qpn_avi_solve.hip) gated on path == -1.
 //   verify_stage2   accepts iff || Ad' lambda - q~ ||_2 <= 1e-4 (:138).
 #include "qpn_internal.h"
+#include "qpn_tile_chol.h"
 #include <type_traits>
 
 #define QINF __builtin_huge_val()
@@ -1186,6 +1187,9 @@ __global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (pn + 1 < npanel) store_panel(nxt);
         __syncthreads();
     }
+    // (full-rank least squares first try the blocked, unpivoted factorisation of qpn_tile_chol.h on LDS tiles: k <= 112 -> 28 tiles
+    //  = 61 KB of the dynamic block; a pivot below 1e-9 -- dependent active rows -- hands over to the pivoted factorisation below)
+    const bool fast_chol = k <= 112 && tc_tiles(T) * TC_TSZ <= dyn_doubles;
     // ---- equilibration from the raw diagonal, then G (signed, scaled) to the workspace, both triangles
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -1203,11 +1207,16 @@ __global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int i = 16 * tI[q] + lq + 4 * g, j = 16 * tJ[q] + lc;
+            double v = 0.0;
             if (i < k && j < k) {
-                const double v = acc[q][g] * (sdv[i] * ssgv[i]) * (sdv[j] * ssgv[j]);
+                v = acc[q][g] * (sdv[i] * ssgv[i]) * (sdv[j] * ssgv[j]);
                 G[(size_t)j * ldg + i] = v;
                 if (tI[q] != tJ[q]) G[(size_t)i * ldg + j] = v;
             }
+            // ... and into the packed lower tiles of the blocked factorisation (the panels are done with): the accumulator holds
+            // (row i of tile row tI, column j of tile column tJ >= tI), the lower tile (tJ, tI) takes its transpose; the padding up
+            // to whole tiles is the identity
+            if (fast_chol) dynp[tc_toff(tJ[q], tI[q]) + lc * TC_TLD + (lq + 4 * g)] = (i < k && j < k) ? v : (i == j ? 1.0 : 0.0);
         }
     }
     const bool mine = tid < k;
@@ -1347,8 +1356,21 @@ __global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         return block_sum_f64(ss, red);
     };
 
-    double y; bool piv;
-    lsq_on(mine, y, piv);
+    double y = 0.0; bool piv = false;
+    bool solved_fast = false;
+    if (fast_chol) {                                               // (uniform)
+        if (tid < 16 * T) sco[tid] = mine ? rhs : 0.0;
+        if (tid == 0) s_pv = 0;
+        __syncthreads();
+        if (tc_factor(dynp, T, &s_pv, 1e-9, tid)) {
+            if (wave == 0) tc_solve(dynp, sco, T, lane);
+            __syncthreads();
+            y = mine ? sco[tid] : 0.0; piv = mine;
+            solved_fast = true;
+        }
+        __syncthreads();
+    }
+    if (!solved_fast) lsq_on(mine, y, piv);
     if (tid == 0) s_flag = 0;
     __syncthreads();
     if (tid < npn && !(y * dcol > -a.tol)) s_flag = 1;           // :119 signs (y scaled back)
