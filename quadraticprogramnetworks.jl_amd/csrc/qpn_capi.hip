@@ -1460,7 +1460,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     const size_t mm = (size_t)(m > 0 ? m : 1);
     // scratch of the bounded-LSQ fallback (src/qp_processing.jl:129-137): Gram block + vectors
     double *sG, *sq, *slb, *sub, *sz, *sres, *gws = nullptr; int32_t *sst;
-    const bool wide = n > 64 || m > 64;
+    const bool wide = n > QPN_VERIFY_WIDE_FROM || m > QPN_VERIFY_WIDE_FROM;
     const size_t mp16 = (size_t)((m + 15) & ~15);
     if (mem == QPN_MEM_DEVICE) {
         Carver cv(ctx);

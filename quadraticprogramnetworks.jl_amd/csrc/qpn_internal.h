@@ -100,6 +100,11 @@ int qpn_avi_big_max_n();
 size_t qpn_avi_big_workspace_bytes(int batch, int N);
 hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hipStream_t stream);
 
+// A8: nodes with n or m above this take the workgroup kernel verify_wide_node (qpn_verify.hip), the others one wavefront per node
+#ifndef QPN_VERIFY_WIDE_FROM
+#define QPN_VERIFY_WIDE_FROM 64
+#endif
+
 // qpn_avi_schur_big.hip: blocked MFMA crash for large node-shaped items (workspace views filled by stage A)
 struct SchurBigWs {
     double *Tt, *S, *c, *l2, *u2, *lam;

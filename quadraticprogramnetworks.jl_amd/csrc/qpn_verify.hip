@@ -651,8 +651,11 @@ __global__ __launch_bounds__(WAVE, 2) void verify_node64(VerifyArgs a)
     }
     vwave_sync();
     // ---- pass 1: q~ (:58-60) and ax (:84), 16 columns of Qd and of Ad in flight per panel
+    // (the rows' squared lengths come out of the same values: a second pass over Ad for them and for Ad q~ is not needed -- the
+    //  right-hand side is only wanted on the active rows, which pass 2 reads anyway)
+    double rn2 = 0.0;
     {
-        double q1 = 0.0, a1 = 0.0;
+        double q1 = 0.0, a1 = 0.0, r1 = 0.0;
         for (int c = 0; c < nch; ++c) {
             double vq[16], va[16];
 #pragma unroll
@@ -667,9 +670,10 @@ __global__ __launch_bounds__(WAVE, 2) void verify_node64(VerifyArgs a)
                 const vd2 xx = xh[j];
                 qt = fma(vq[2 * j], xx[0], qt); q1 = fma(vq[2 * j + 1], xx[1], q1);
                 ax = fma(va[2 * j], xx[0], ax); a1 = fma(va[2 * j + 1], xx[1], a1);
+                rn2 = fma(va[2 * j], va[2 * j], rn2); r1 = fma(va[2 * j + 1], va[2 * j + 1], r1);
             }
         }
-        qt += q1; ax += a1;
+        qt += q1; ax += a1; rn2 += r1;
     }
     // :86  feasibility, tol 1e-3
     const bool infeas = isrow && !(lr - 1e-3 <= ax && ax - 1e-3 <= ur);
@@ -697,27 +701,8 @@ __global__ __launch_bounds__(WAVE, 2) void verify_node64(VerifyArgs a)
     vwave_sync();                                             // (the x reads are done)
     sx[l] = isx ? qt : 0.0;
     vwave_sync();
-    // ---- pass 2: row lengths and (Ad q~)_r first, then (Ad again) the signed, equilibrated active rows to LDS
-    double aq = 0.0, rn2 = 0.0;
-    {
-        double g1 = 0.0, r1 = 0.0;
-        for (int c = 0; c < nch; ++c) {
-            double va[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int cj = 16 * c + t;
-                va[t] = (cj < n && isrow) ? A_[(size_t)cj * m + l] : 0.0;
-            }
-            const vd2 *qh = reinterpret_cast<const vd2 *>(sx + 16 * c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const vd2 qq = qh[j];
-                aq = fma(va[2 * j], qq[0], aq); g1 = fma(va[2 * j + 1], qq[1], g1);
-                rn2 = fma(va[2 * j], va[2 * j], rn2); r1 = fma(va[2 * j + 1], va[2 * j + 1], r1);
-            }
-        }
-        aq += g1; rn2 += r1;
-    }
+    // ---- pass 2: the active rows of Ad again (L2 / Infinity Cache): (Ad q~)_r, and the signed, equilibrated rows to LDS
+    double aq = 0.0;
     const double dinv = rn2 > 0.0 ? 1.0 / sqrt(rn2) : 0.0;
     const double rsc = mysgr * dinv;
     if (qpn_ballot(mycol >= 0)) {
@@ -731,6 +716,11 @@ __global__ __launch_bounds__(WAVE, 2) void verify_node64(VerifyArgs a)
             if (mycol >= 0) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) sM[mycol * V64_LDA + 16 * c + t] = rsc * va[t];
+                const vd2 *qh = reinterpret_cast<const vd2 *>(sx + 16 * c);
+                double g1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const vd2 qq = qh[j]; aq = fma(va[2 * j], qq[0], aq); g1 = fma(va[2 * j + 1], qq[1], g1); }
+                aq += g1;
             }
         }
     }
