@@ -1100,21 +1100,21 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_bpp(AviBatchArgs a, SchurBig
         __syncthreads();
         if (k > 0) {
             // ---- S_AA (lower triangle) into the tiles: wave <-> active row, lanes <-> the row's 256 entries (coalesced)
-            // (four rows of a wave in flight: 16 loads, then their scatter)
-            for (int a0 = wave; a0 < kp; a0 += 16) {
-                double v[4][TPB / 64];
+            // (eight rows of a wave in flight: 32 loads, then their scatter)
+            for (int a0 = wave; a0 < kp; a0 += 32) {
+                double v[8][TPB / 64];
                 int pc[TPB / 64];
 #pragma unroll
                 for (int q = 0; q < TPB / 64; ++q) { const int col = lane + 64 * q; pc[q] = col < m ? B.posof[col] : -1; }
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
+                for (int rr = 0; rr < 8; ++rr) {
                     const int ar = a0 + 4 * rr;
                     const double *row = Tb + (size_t)B.aidx[ar < k ? ar : 0] * ld;
 #pragma unroll
                     for (int q = 0; q < TPB / 64; ++q) { const int col = lane + 64 * q; v[rr][q] = (ar < k && pc[q] >= 0 && pc[q] <= ar) ? row[col] : 0.0; }
                 }
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
+                for (int rr = 0; rr < 8; ++rr) {
                     const int ar = a0 + 4 * rr;
                     if (ar >= kp) break;                                  // (wave-uniform)
                     const int ti = ar >> 4, ri = ar & 15;
@@ -1141,12 +1141,19 @@ __global__ __launch_bounds__(TPB, 2) void schur_big_bpp(AviBatchArgs a, SchurBig
         double acc0 = ci, acc1 = 0.0;
         if (act) {
             int a0 = 0;
-            for (; a0 + 8 <= k; a0 += 8) {
-                double v[8];
+            for (; a0 + 16 <= k; a0 += 16) {
+                double v[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = Tb[(size_t)B.aidx[a0 + q] * ld + tid];
+                for (int q = 0; q < 16; ++q) v[q] = Tb[(size_t)B.aidx[a0 + q] * ld + tid];
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) { acc0 = fma(v[q], B.rhs[a0 + q], acc0); acc1 = fma(v[q + 1], B.rhs[a0 + q + 1], acc1); }
+                for (int q = 0; q < 16; q += 2) { acc0 = fma(v[q], B.rhs[a0 + q], acc0); acc1 = fma(v[q + 1], B.rhs[a0 + q + 1], acc1); }
+            }
+            for (; a0 + 4 <= k; a0 += 4) {
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = Tb[(size_t)B.aidx[a0 + q] * ld + tid];
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) { acc0 = fma(v[q], B.rhs[a0 + q], acc0); acc1 = fma(v[q + 1], B.rhs[a0 + q + 1], acc1); }
             }
             for (; a0 < k; ++a0) acc0 = fma(Tb[(size_t)B.aidx[a0] * ld + tid], B.rhs[a0], acc0);
         }
