@@ -381,6 +381,24 @@ function sweep_status!(out_dev::Ptr{Cvoid}, status_dev::Ptr{Cvoid}, resid_dev::P
     nothing
 end
 
+# A node record with its equality rows (l == u) moved into the free block: z = [x; mu_E; lambda_I].  The multiplier of an equality
+# row is a free variable of the node's AVI (src/avi.jl:113-128), so this is the same complementarity system -- but the fused node
+# kernels, which decline a record that carries an equality row, take it (DESIGN.md section 5a; the Python mirror's
+# level_batch.free_equalities).  Every parent's record has such rows: its children's pieces.  Arrays in MATH layout (row-major
+# meaning: Qd n x n, R n x p, Ad m x n, B m x p); returns the rewritten record and nx = n (the first nx entries of z are x).
+function free_equalities(Qd::AbstractMatrix, R::AbstractMatrix, qd::AbstractVector, Ad::AbstractMatrix, B::AbstractMatrix,
+                         l::AbstractVector, u::AbstractVector)
+    E = findall(i -> isfinite(l[i]) && l[i] == u[i], eachindex(l))
+    isempty(E) && return (Qd, R, qd, Ad, B, l, u, size(Qd, 1))
+    I = setdiff(collect(eachindex(l)), E)
+    ne = length(E)
+    Qd2 = [Qd -transpose(Ad[E, :]); Ad[E, :] zeros(ne, ne)]
+    R2 = [R; B[E, :]]
+    qd2 = [qd; -l[E]]
+    Ad2 = [Ad[I, :] zeros(length(I), ne)]
+    return (Qd2, R2, qd2, Ad2, B[I, :], l[I], u[I], size(Qd, 1))
+end
+
 # ---- drop-in bodies -------------------------------------------------------------------------------
 # src/avi.jl:63-77 with the PATH call replaced; StatusCode / check_avi_solution stay the reference's.
 function solve_avi_hip(QPN, avi, z0, w; convergence_tolerance = 1e-10)
