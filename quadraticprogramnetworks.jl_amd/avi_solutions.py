@@ -7,7 +7,6 @@ comp_indices masks: bit (c-1) set for code c.  Codes (src/avi_solutions.jl:390-3
 """
 from __future__ import annotations
 
-import itertools
 
 import numpy as np
 

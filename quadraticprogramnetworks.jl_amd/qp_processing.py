@@ -4,12 +4,11 @@ arithmetic runs on the GPU (qpn_verify_nodes / qpn_solve_avi_batch)."""
 from __future__ import annotations
 
 import itertools
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 
 from .avi import StatusCode, _eng
-from .avi_solutions import solution_graph_pieces
 from .engine import colmajor
 from .programs import Poly
 
