@@ -538,6 +538,14 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
                 # (src/sets.jl:76-89: 1e-8 drop, leading coefficient +1), the point's worst violation per piece
                 A3 = np.ascontiguousarray(np.swapaxes(Ar[plain][:, take_k, :], 1, 2))        # [pieces, Rmax, columns]
                 L2 = lr[plain].astype(np.float64, copy=True); U2 = ur[plain].astype(np.float64, copy=True)
+                # (first to unit largest coefficient: the rows come out of the elimination at any scale -- a stationarity row of
+                #  size 1e-4 whose 1e-8 entry is dropped, then divided by a leading coefficient of 1e-6, misses its own point by
+                #  7e-3, and the parent calls the point infeasible: one pair in 5 000 at n = m = 32 cycled on exactly that)
+                big = np.max(np.abs(A3), axis=2)
+                sc = np.where(big > 0.0, 1.0 / np.where(big > 0.0, big, 1.0), 1.0)
+                A3 *= sc[..., None]
+                with np.errstate(invalid="ignore"):
+                    L2 = L2 * sc; U2 = U2 * sc
                 A3[np.abs(A3) < 1e-8] = 0.0
                 nzm = A3 != 0
                 has = nzm.any(axis=2)
@@ -559,7 +567,10 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
                     P = _reduce_on_host(b, k, np.asarray(K)[t], eng)
                     if P is None:
                         continue
-                    Pg = _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, np.ascontiguousarray(P[0][:, take_k]), P[1], P[2]))
+                    Ah = np.ascontiguousarray(P[0][:, take_k]); big = np.max(np.abs(Ah), axis=1, initial=0.0)
+                    sc = np.where(big > 0.0, 1.0 / np.where(big > 0.0, big, 1.0), 1.0)
+                    with np.errstate(invalid="ignore"):
+                        Pg = _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, Ah * sc[:, None], P[1] * sc, P[2] * sc))
                     cl, Al_ = Pg.local()
                     axp = Al_ @ x[cl]
                     admit(i, Pg, float(np.max(np.maximum(Pg.l - axp, axp - Pg.u), initial=0.0)))
