@@ -300,3 +300,12 @@ def test_interior_members_are_members_well_inside(eng):
         assert np.max(np.abs(ax[eq] - l[eq]), initial=0.0) <= 1e-8
         assert np.all(ax[~eq] >= l[~eq] + 0.05) and np.all(ax[~eq] <= u[~eq] - 0.05)
     assert eng.calls["solve_nodes"] == 2                          # one call per polyhedron size (7 x 5 and 2 x 5)
+
+
+def test_pair_4287_a_tiny_stationarity_row_does_not_reject_its_own_point(eng):
+    """Pair 4287 of the 5 000-pair net of n = m = 32 (BASELINE configs[3]'s net): one row of the follower's reduced piece comes out
+    of the elimination at size 1e-4 with a 1e-8 entry and a leading coefficient of 1e-6; dropped and normalised as the reference
+    normalises rows (src/sets.jl:76-89) it misses the piece's own point by 7e-3, the leader calls the point infeasible, moves the
+    follower back, and solve() ends in "Cycling detected".  The rows go to unit largest coefficient first (level_batch)."""
+    ret = algorithm.solve(examples.setup("synthetic_pairs", pairs=1, n=32, m=32, first=4287), engine=eng)
+    assert ret["solved"], ret.get("error")
