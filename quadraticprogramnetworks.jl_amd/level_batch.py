@@ -457,7 +457,7 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
     comp_indices -> all_Ks, src/avi_solutions.jl:200-215 -> local_piece, :400-496 -> the multipliers eliminated, the
     columns permuted back, :86-87), batched: per record shape one comp_indices pair, one recipes call, one pieces call.
     Returns a list (per item; None where `want` is False) of lists of Poly in global coordinates."""
-    from .avi_solutions import _dedupe
+    from .avi_solutions import _dedupe, _probe_vector
     eng = engine
     x = np.asarray(x, dtype=np.float64)
     out: List[Optional[list]] = [None] * len(recs)
@@ -511,12 +511,13 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
         seen = {b.where[k]: set() for k in sel}
         fallback = {}                                        # per node: the piece the point misses least, for a node none of whose
                                                              # pieces passes (a solution graph is never empty, src/qp_processing.jl:233)
-        def admit(i, Pg, miss):
+        def admit(i, Pg, miss, key=None):
             # the parent's verify_solution tests feasibility on exactly these normalised rows with 1e-3 (src/qp_processing.jl:86):
             # a piece the point fails here would be "infeasible" there by construction (MEMBER_TOL)
             if miss <= member_tol:
-                cl, Al_ = Pg.local()
-                key = (cl.tobytes(), (np.round(Al_, 6) + 0.0).tobytes(), np.round(np.concatenate([Pg.l, Pg.u]), 6).tobytes())
+                if key is None:
+                    cl, Al_ = Pg.local()
+                    key = (cl.tobytes(), (np.round(Al_, 6) + 0.0).tobytes(), np.round(np.concatenate([Pg.l, Pg.u]), 6).tobytes())
                 if key not in seen[i]:                       # the reference collects the pieces in a Set (src/avi_solutions.jl:104)
                     seen[i].add(key)
                     out[i].append(Pg)
@@ -559,9 +560,20 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
                 live = has & (np.arange(Rmax)[None, :] < rows[plain][:, None])
                 viol = np.where(live, np.maximum(L2 - ax, ax - U2), 0.0)
                 worst = np.max(viol, axis=1, initial=0.0)
+                # _dedupe's own quick test (equal normals project equally on a random vector; all-zero rows) for all pieces at once:
+                # the few that have something to merge go through it, the others are taken as they are
+                valid = np.arange(Rmax)[None, :] < rows[plain][:, None]
+                with np.errstate(invalid="ignore"):
+                    hs = np.sort(np.where(valid, A3 @ _probe_vector(A3.shape[2]), np.inf), axis=1)
+                    close = np.diff(hs, axis=1) <= 1e-7 * (1.0 + np.abs(hs[:, 1:]))
+                merge = np.any(close & np.isfinite(hs[:, 1:]), axis=1) | np.any(valid & ~has, axis=1)
+                A6 = np.round(A3, 6) + 0.0                      # (the keys of the node's piece SET, rounded once for all pieces)
+                LU6 = np.round(np.concatenate([L2, U2], axis=1), 6)
+                ckey = cols_k.tobytes()
                 for j, t in enumerate(plain.tolist()):
                     r = int(rows[t])
-                    miss_of[t] = (float(worst[j]), A3[j, :r].copy(), L2[j, :r].copy(), U2[j, :r].copy())
+                    key = None if merge[j] else (ckey, A6[j, :r].tobytes(), np.concatenate([LU6[j, :r], LU6[j, Rmax:Rmax + r]]).tobytes())
+                    miss_of[t] = (float(worst[j]), A3[j, :r].copy(), L2[j, :r].copy(), U2[j, :r].copy(), bool(merge[j]), key)
             for t in ts.tolist():
                 if flags[t]:
                     P = _reduce_on_host(b, k, np.asarray(K)[t], eng)
@@ -575,8 +587,9 @@ def solution_pieces(qpn, recs, batches, rets, x, engine, want: Sequence[bool], t
                     axp = Al_ @ x[cl]
                     admit(i, Pg, float(np.max(np.maximum(Pg.l - axp, axp - Pg.u), initial=0.0)))
                 else:
-                    miss, Aj, lj, uj = miss_of[t]
-                    admit(i, _dedupe(Poly.from_sorted(qpn.num_vars, cols_k, Aj, lj, uj, normalise=False)), miss)
+                    miss, Aj, lj, uj, mg, key = miss_of[t]
+                    Pg = Poly.from_sorted(qpn.num_vars, cols_k, Aj, lj, uj, normalise=False)
+                    admit(i, _dedupe(Pg) if mg else Pg, miss, key)
         for i, (miss, Pg) in fallback.items():
             if not out[i]:
                 out[i].append(Pg)

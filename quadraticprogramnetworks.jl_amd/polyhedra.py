@@ -198,7 +198,8 @@ def interior_members_batch(trips, engine, delta=1e-2, chunk=20000):
                 return order, np.take_along_axis(mask, order, axis=1)
 
             (E, Ev), (LO, LOv), (HI, HIv) = pick(eq, ne), pick(lo, nlo), pick(hi, nhi)
-            rows_of = lambda sel, valid: np.take_along_axis(A, sel[:, :, None], axis=1) * valid[:, :, None]
+            bidx = np.arange(B)[:, None]
+            rows_of = lambda sel, valid: A[bidx, sel] * valid[:, :, None]        # (whole rows by index pairs: no index broadcast over d)
             nf = d + 1 + ne                                       # free block: [x; eps; mu_E]
             mi = nlo + nhi
             mp = max(16, -(-mi // 16) * 16)
