@@ -159,6 +159,22 @@ class RecordBatch:
         self.nx = recs[0]["dec"].size
         self.dec = np.zeros((nb, self.nx), dtype=np.int64)
         self.par = np.full((nb, p), -1, dtype=np.int64)                      # missing parameters: a zero column, w = 0
+        mis = {len(r["l"]) for r in recs}; pis = {r["par"].size for r in recs}
+        if len(mis) == 1 and len(pis) == 1:
+            # the usual batch -- one row count, one parameter count: stacked and transposed in one go each
+            mi, pi = mis.pop(), pis.pop()
+            self.Qc[:] = np.stack([r["Qd"] for r in recs]).transpose(0, 2, 1)
+            self.qd[:] = np.stack([r["qd"] for r in recs])
+            self.dec[:] = np.stack([r["dec"] for r in recs])
+            if pi:
+                self.Rc[:, :pi] = np.stack([r["R"] for r in recs]).transpose(0, 2, 1)
+                self.par[:, :pi] = np.stack([r["par"] for r in recs])
+            if mi:
+                self.Ac[:, :, :mi] = np.stack([r["Ad"] for r in recs]).transpose(0, 2, 1)
+                self.l[:, :mi] = np.stack([r["l"] for r in recs]); self.u[:, :mi] = np.stack([r["u"] for r in recs])
+                if pi:
+                    self.Bc[:, :pi, :mi] = np.stack([r["B"] for r in recs]).transpose(0, 2, 1)
+            recs = []
         for b, r in enumerate(recs):
             mi, pi = len(r["l"]), r["par"].size
             self.Qc[b] = r["Qd"].T
