@@ -1364,7 +1364,16 @@ __global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     if (tid == 0) s_flag = 0;
     __syncthreads();
     if (tid < npn && !(y * dcol > -a.tol)) s_flag = 1;           // :119 signs (y scaled back)
-    double res = residual(y);
+    double res;
+    if (solved_fast) {
+        // y solves the normal equations G y = b of the full column set, so |A_bar y - q~|^2 = |q~|^2 - y'b: no third pass over Ad
+        // for the accept test (rounding: 1e-16 |q~|^2, i.e. a residual norm resolved to ~1e-7 against the tolerance 1e-4); the
+        // bounded least squares below forms its residuals explicitly
+        const double qq = block_sum_f64(qt[0] * qt[0] + qt[1] * qt[1], red);
+        const double yb = block_sum_f64(mine ? y * rhs : 0.0, red);
+        res = qq > yb ? qq - yb : 0.0;
+        if (mine) sco[tid] = y * dcol * ssgv[tid];                // (what residual() leaves there: the unscaled multipliers)
+    } else res = residual(y);
     __syncthreads();
     if (!s_flag && sqrt(res) <= a.tol) {
         for (int r = tid; r < m; r += WTPB) lam[r] = 0.0;
