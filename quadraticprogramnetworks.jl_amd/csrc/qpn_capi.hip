@@ -1461,6 +1461,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     // scratch of the bounded-LSQ fallback (src/qp_processing.jl:129-137): Gram block + vectors
     double *sG, *sq, *slb, *sub, *sz, *sres, *gws = nullptr; int32_t *sst;
     const bool wide = n > QPN_VERIFY_WIDE_FROM || m > QPN_VERIFY_WIDE_FROM;
+    const bool mid = !wide && (n > 32 || m > 32);      // verify_node64's class: a small slot workspace for the nodes it hands on
     const size_t mp16 = (size_t)((m + 15) & ~15);
     if (mem == QPN_MEM_DEVICE) {
         Carver cv(ctx);
@@ -1470,6 +1471,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
         cv.add((void **)&sst, (size_t)batch * 4);
         if (wide_avi) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, m));
         if (wide && m > 0) cv.add((void **)&gws, (size_t)batch * 2 * mp16 * mp16 * 8);
+        else if (mid && m > 0) cv.add((void **)&gws, (size_t)QPN_VERIFY_MID_SLOTS * 2 * mp16 * mp16 * 8 + 64);
         int rc = cv.commit();
         if (rc != QPN_OK) return rc;
         HIPCHK(ctx, qpn_launch_verify_nodes(batch, n, m, p, Qd, R, qd, Ad, B, l, u, xd, w, stride_w, tol,
@@ -1496,6 +1498,7 @@ int verify_nodes_any(qpn_ctx *ctx, bool records_on_device, int32_t batch, int32_
     cv.add((void **)&sst, (size_t)batch * 4);
     if (wide_avi) cv.add((void **)&wbig, qpn_avi_big_workspace_bytes(batch, m));
     if (wide && m > 0) cv.add((void **)&gws, (size_t)batch * 2 * mp16 * mp16 * 8);
+    else if (mid && m > 0) cv.add((void **)&gws, (size_t)QPN_VERIFY_MID_SLOTS * 2 * mp16 * mp16 * 8 + 64);
     int rc = cv.commit();
     if (rc != QPN_OK) return rc;
     if (!records_on_device) {

@@ -104,6 +104,9 @@ hipError_t qpn_launch_avi_solve_big(const AviBatchArgs &a, double *workspace, hi
 #ifndef QPN_VERIFY_WIDE_FROM
 #define QPN_VERIFY_WIDE_FROM 64
 #endif
+// ... and the few nodes of the 33 .. 64 class with more than 32 active rows (verify_node64 flags them) take the same kernel out
+// of a workspace of this many slots (a device counter hands them out; nodes beyond it go to round 1's kernels)
+constexpr int QPN_VERIFY_MID_SLOTS = 256;
 
 // qpn_avi_schur_big.hip: blocked MFMA crash for large node-shaped items (workspace views filled by stage A)
 struct SchurBigWs {

@@ -994,7 +994,7 @@ __device__ __forceinline__ double block_max_f64(double v, double *red)
 constexpr int VW_KMAX = 128;
 __device__ __forceinline__ int vw_ld(int m) { return m | 1; }
 
-__global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void verify_wide_node(VerifyArgs a, double *gws, int wp, int dyn_doubles)
+__global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void verify_wide_node(VerifyArgs a, double *gws, int wp, int dyn_doubles, int *slot_ctr, int nslots)
 {
     const int n = a.n, m = a.m, p = a.p;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1017,7 +1017,18 @@ __global__ __launch_bounds__(WTPB) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const double *w_ = a.w + (size_t)b * (size_t)a.stride_w;
     double *lam = a.lambda + (size_t)b * m;
     const int mp = (m + 15) & ~15;
-    double *G = gws + (size_t)b * 2 * mp * mp;       // k x k, leading dimension ldg
+    // (behind verify_node64 -- a.gate set --: only the nodes it flagged, each with a slot of the small workspace; a node that finds no
+    //  slot keeps its flag for round 1's kernels)
+    int slot = b;
+    if (a.gate) {
+        if (a.path[b] != -2) return;
+        if (tid == 0) s_flag = atomicAdd(slot_ctr, 1);
+        __syncthreads();
+        slot = s_flag;
+        __syncthreads();
+        if (slot >= nslots) return;
+    }
+    double *G = gws + (size_t)slot * 2 * mp * mp;       // k x k, leading dimension ldg
     double *L = G + (size_t)mp * mp;
 
     for (int i = tid; i < n; i += WTPB) sx[i] = a.xd[(size_t)b * n + i];
@@ -1697,7 +1708,7 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
             size_t dyn = (size_t)2 * wp * (size_t)(m | 1) * sizeof(double);
             const size_t km = (size_t)(m < 128 ? m : 128), want = km * km * sizeof(double), cap = 71 * 1024;
             if (dyn < (want < cap ? want : cap)) dyn = want < cap ? want : cap;
-            hipLaunchKernelGGL(verify_wide_node, dim3((unsigned)batch), dim3(WTPB), dyn, stream, a, gws, wp, (int)(dyn / sizeof(double)));
+            hipLaunchKernelGGL(verify_wide_node, dim3((unsigned)batch), dim3(WTPB), dyn, stream, a, gws, wp, (int)(dyn / sizeof(double)), (int *)nullptr, 0);
             hipError_t e1 = hipGetLastError();
             if (e1 != hipSuccess) return e1;
             a.gate = 1;
@@ -1725,6 +1736,27 @@ hipError_t qpn_launch_verify_nodes(int32_t batch, int32_t n, int32_t m, int32_t 
     if (m >= 1) {
         hipLaunchKernelGGL(verify_node64, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
         a.gate = 1;
+        if (gws) {
+            // the nodes it flagged (more than 32 active rows: a handful in thousands) go to the workgroup kernel first -- ~35 us for
+            // such a node instead of ~130 us on the one-wavefront kernels of round 1, which bound the whole call's tail
+            static QpnPerDeviceOnce attr_once;
+            const int dv = attr_once.device();
+            if (!attr_once.done[dv]) {
+                hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(verify_wide_node), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                if (e0 != hipSuccess) return e0;
+                attr_once.done[dv] = true;
+            }
+            const size_t mp16 = (size_t)((m + 15) & ~15);
+            int *ctr = reinterpret_cast<int *>(gws + (size_t)QPN_VERIFY_MID_SLOTS * 2 * mp16 * mp16);
+            hipError_t e0 = hipMemsetAsync(ctr, 0, 4, stream);
+            if (e0 != hipSuccess) return e0;
+            size_t dyn = (size_t)2 * 16 * (size_t)(m | 1) * sizeof(double);
+            const size_t want = (size_t)m * m * sizeof(double);
+            if (dyn < want) dyn = want;
+            hipLaunchKernelGGL(verify_wide_node, dim3((unsigned)batch), dim3(WTPB), dyn, stream, a, gws, 16, (int)(dyn / sizeof(double)), ctr, QPN_VERIFY_MID_SLOTS);
+            e0 = hipGetLastError();
+            if (e0 != hipSuccess) return e0;
+        }
     }
     hipLaunchKernelGGL(verify_stage1<65>, dim3((unsigned)batch), dim3(WAVE), 0, stream, a);
     hipError_t e = hipGetLastError();
